@@ -1,0 +1,78 @@
+"""TEST INFRASTRUCTURE — the parity cases (model constructor kwargs + batch geometry).
+
+Shared by oracle/gen_golden.py (runs the *reference* in the build container and writes tests/golden/*.npz),
+by the CPU-oracle tests and by the GPU parity tests.  Config numbering follows BASELINE.json `configs`
+/ SURVEY.md §8d.
+"""
+import copy
+
+_ADAM = dict(optim_type='adam', lr=1e-3, weight_decay=3e-5, grad_clipping=100)
+
+
+def _conv(C, K=64, **kw):
+    d = dict(input_shape=(3, 32, 32), num_labels=C, type='cvae',
+             features='conv32', upsampler='deconv32', encoder=[], decoder=[], classifier=[],
+             batch_norm='both', latent_dim=K, latent_sampling=1, test_latent_sampling=1,
+             sigma={'value': 1.0, 'learned': True}, gamma=0, beta=1., output_activation='linear',
+             prior=dict(distribution='gaussian', init_mean=0., learned_means=True, var_dim='scalar',
+                        freeze_means=0),
+             optimizer=dict(_ADAM))
+    d.update(kw)
+    return d
+
+
+CASES = {
+    # config 2 (CIFAR-10 conv CVAE) at a batch the oracle runs in < 1 s
+    'c2_n8': dict(net=_conv(10), N=8, kl_var_weighting=1.0, gamma_weighting=1.0),
+    # same, warm-up weight != 1 and L=2 latent samples, fixed sigma
+    'c2_n6_L2_warm': dict(net=_conv(10, latent_sampling=2, test_latent_sampling=2, sigma={'value': 0.7}),
+                          N=6, kl_var_weighting=0.25, gamma_weighting=1.0),
+    # config 3 (CIFAR-100): scalar / diag / full prior variance
+    'c3_n8_scalar': dict(net=_conv(100), N=8, kl_var_weighting=1.0, gamma_weighting=1.0),
+    'c3_n8_diag': dict(net=_conv(100, prior=dict(distribution='gaussian', init_mean=0., learned_means=True,
+                                                   var_dim='diag', freeze_means=0)),
+                       N=8, kl_var_weighting=1.0, gamma_weighting=1.0),
+    'c3_n8_full': dict(net=_conv(100, prior=dict(distribution='gaussian', init_mean=0., learned_means=True,
+                                                   var_dim='full', freeze_means=0)),
+                       N=8, kl_var_weighting=1.0, gamma_weighting=1.0),
+    # gamma > 0: classifier on z enters the loss
+    'c2_n8_gamma': dict(net=_conv(10, gamma=2.0, classifier=[20]), N=8, kl_var_weighting=1.0, gamma_weighting=0.5),
+    # alternative priors
+    'c2_n8_tilted': dict(net=_conv(10, prior=dict(distribution='tilted', init_mean=0., learned_means=True,
+                                                   tau=5., freeze_means=0)),
+                         N=8, kl_var_weighting=1.0, gamma_weighting=1.0),
+    'c2_n8_uniform': dict(net=_conv(10, prior=dict(distribution='uniform', init_mean=0., learned_means=True,
+                                                    tau=3., freeze_means=0)),
+                          N=8, kl_var_weighting=0.5, gamma_weighting=1.0),
+    # encoder-only batch norm, no learned means
+    'c2_n8_bnenc': dict(net=_conv(10, batch_norm='encoder',
+                                  prior=dict(distribution='gaussian', init_mean=0., learned_means=False,
+                                             var_dim='scalar', freeze_means=0)),
+                        N=8, kl_var_weighting=1.0, gamma_weighting=1.0),
+    # config 1: MNIST-shape MLP (784-512-256 -> 16 -> 256-512-784), gamma=1000, sigmoid output, fixed sigma
+    'c1_n16_mlp': dict(net=dict(input_shape=(1, 28, 28), num_labels=10, type='cvae',
+                                features=None, upsampler=None, encoder=[512, 256], decoder=[256, 512],
+                                classifier=[], batch_norm=False, latent_dim=16, latent_sampling=1,
+                                test_latent_sampling=1, sigma={'value': 0.1}, gamma=1000., beta=1.,
+                                output_activation='sigmoid',
+                                prior=dict(distribution='gaussian', init_mean=0., learned_means=True,
+                                           var_dim='scalar', freeze_means=0),
+                                optimizer=dict(_ADAM)),
+                       N=16, kl_var_weighting=1.0, gamma_weighting=1.0),
+    # config 5 geometry (ours): 3x64x64, conv32+/deconv32+, K=200, C=20 (fp32 here)
+    'c5_n4': dict(net=dict(_conv(20, K=200), input_shape=(3, 64, 64), features='conv32+', upsampler='deconv32+'),
+                  N=4, kl_var_weighting=1.0, gamma_weighting=1.0),
+}
+
+
+def get_case(name):
+    return copy.deepcopy(CASES[name])
+
+
+def full_config(which, N=512):
+    """Full-size configs of BASELINE.json (no goldens: checked through size-independent properties)."""
+    if which == 2:
+        return dict(net=_conv(10), N=N, kl_var_weighting=1.0, gamma_weighting=1.0)
+    if which == 3:
+        return dict(net=_conv(100), N=N, kl_var_weighting=1.0, gamma_weighting=1.0)
+    raise KeyError(which)

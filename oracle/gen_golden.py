@@ -1,0 +1,165 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE — golden-vector generator.  Runs ONLY in the build container (needs /root/reference).
+
+Imports the *reference* implementation (moxime/joint-vae, read-only at /root/reference) with inert
+`torchvision` / `setproctitle` placeholder modules (neither is installed; neither is on the hot path, see
+SURVEY.md §8c), builds the model of every case in oracle/cases.py, loads deterministic weights
+(oracle/det_init.py), runs ONE training step exactly as cvae.py:2424-2461 does
+
+    zero_grad -> evaluate(x, y, with_beta=True, kl_var_weighting=w, gamma_weighting=g) -> total.mean().backward()
+    -> optimizer.clip(params) -> optimizer.step()
+
+with epsilon injected (cvae's Sampling draws from the global RNG, layers.py:235), and writes the inputs'
+seeds and the expected outputs to tests/golden/<case>.npz.  Only DATA is written - no reference source.
+
+Usage:  python oracle/gen_golden.py [case ...]
+"""
+import os
+import sys
+import types
+import contextlib
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+REF = '/root/reference'
+sys.path.insert(0, REPO)
+
+from oracle.cases import CASES, get_case            # noqa: E402
+from oracle.det_init import load_det_state, det_inputs  # noqa: E402
+
+FULL_GRAD_MAX = 8192      # parameters up to this many elements get their full gradient stored
+
+
+def import_reference():
+    class _Dummy:
+        def __init__(self, *a, **k):
+            raise RuntimeError('placeholder for a package that is not installed')
+
+    def _stub(name):
+        m = types.ModuleType(name)
+
+        def _ga(attr):
+            if attr.startswith('__'):
+                raise AttributeError(attr)
+            return type(attr, (_Dummy,), {})
+        m.__getattr__ = _ga
+        return m
+    tv = _stub('torchvision')
+    for s in ('models', 'datasets', 'transforms', 'utils'):
+        sub = _stub('torchvision.' + s)
+        setattr(tv, s, sub)
+        sys.modules['torchvision.' + s] = sub
+    sys.modules['torchvision'] = tv
+    sys.modules['setproctitle'] = _stub('setproctitle')
+    sys.path.insert(0, REF)
+    os.chdir(REF)                       # data/sets.ini, utils/filters.ini are cwd-relative
+    from cvae import ClassificationVariationalNetwork
+    return ClassificationVariationalNetwork
+
+
+@contextlib.contextmanager
+def inject_eps(eps):
+    """Make the next torch.randn / torch.rand of shape eps.shape return `eps` (layers.py:233-237)."""
+    real_randn, real_rand = torch.randn, torch.rand
+    inv = 1.0 / float(np.sqrt(12))
+
+    def fake_randn(*size, **kw):
+        size = size[0] if len(size) == 1 and not isinstance(size[0], int) else size
+        assert tuple(size) == tuple(eps.shape), (size, eps.shape)
+        return eps.clone()
+
+    def fake_rand(*size, **kw):          # reference computes (rand - 0.5) * sqrt(12)
+        size = size[0] if len(size) == 1 and not isinstance(size[0], int) else size
+        assert tuple(size) == tuple(eps.shape), (size, eps.shape)
+        return eps.clone() * inv + 0.5
+    torch.randn, torch.rand = fake_randn, fake_rand
+    try:
+        yield
+    finally:
+        torch.randn, torch.rand = real_randn, real_rand
+
+
+def run_case(Net, name):
+    case = get_case(name)
+    kw = case['net']
+    N = case['N']
+    torch.manual_seed(0)
+    net = Net(**kw)
+    load_det_state(net, seed=0)
+    net.train()
+    L = net.latent_sampling
+    K = kw['latent_dim']
+    C = kw['num_labels']
+    uniform = kw['prior'].get('distribution') == 'uniform'
+    x, y, eps = det_inputs(N, kw['input_shape'], C, L, K, uniform_eps=uniform)
+
+    out = {}
+    net.optimizer.zero_grad()
+    with inject_eps(eps):
+        x_reco, y_est, losses, measures, mu, log_var, z = net.evaluate(
+            x, y, batch=0, with_beta=True, kl_var_weighting=case['kl_var_weighting'],
+            gamma_weighting=case['gamma_weighting'], current_measures=None, z_output=True)
+    out['x_reco'] = x_reco.detach().numpy()
+    out['y_est'] = y_est.detach().numpy()
+    out['mu'] = mu.detach().numpy()
+    out['log_var'] = log_var.detach().numpy()
+    out['z'] = z.detach().numpy()
+    for k, v in losses.items():
+        out['loss.' + k] = v.detach().numpy()
+    for k, v in measures.items():
+        out['measure.' + k] = np.float64(v)
+    loss = losses['total'].mean()
+    out['batch_loss'] = np.float64(loss.item())
+    loss.backward()
+
+    names = [n for n, _ in net.named_parameters()]
+    has_grad = []
+    for n_, p in net.named_parameters():
+        if p.grad is None:
+            continue
+        has_grad.append(n_)
+        g = p.grad.detach()
+        out['gnorm.' + n_] = np.float64(g.double().norm().item())
+        if g.numel() <= FULL_GRAD_MAX:
+            out['grad.' + n_] = g.numpy().copy()
+    out['param_names'] = np.array(names)
+    out['grad_names'] = np.array(has_grad)
+    total_norm = torch.sqrt(sum(p.grad.double().pow(2).sum() for p in net.parameters() if p.grad is not None))
+    out['total_grad_norm'] = np.float64(total_norm.item())
+
+    net.optimizer.clip(net.parameters())
+    net.optimizer.step()
+    for n_, p in net.named_parameters():
+        out['pnorm_after.' + n_] = np.float64(p.detach().double().norm().item())
+        if p.numel() <= FULL_GRAD_MAX:
+            out['param_after.' + n_] = p.detach().numpy().copy()
+    for n_, b in net.named_buffers():
+        if b.dtype.is_floating_point:
+            out['buffer_after.' + n_] = b.detach().numpy().copy()
+        else:
+            out['buffer_after.' + n_] = b.detach().numpy().copy()
+    out['state_keys'] = np.array(list(net.state_dict().keys()))
+    out['state_shapes'] = np.array([','.join(str(s) for s in v.shape) for v in net.state_dict().values()])
+    out['nparams'] = np.int64(sum(p.numel() for p in net.parameters()))
+
+    # second evaluate in eval mode on the updated model is NOT part of the train step -> not recorded
+    path = os.path.join(REPO, 'tests', 'golden', name + '.npz')
+    np.savez_compressed(path, **out)
+    kb = os.path.getsize(path) / 1024
+    print(f'{name}: total={out["batch_loss"]:.6f} kl={out["loss.kl"].mean():.5f} '
+          f'|g|={out["total_grad_norm"]:.5f} nparams={out["nparams"]} -> {path} ({kb:.0f} KiB)')
+
+
+def main():
+    names = sys.argv[1:] or list(CASES)
+    Net = import_reference()
+    torch.set_num_threads(8)
+    for n in names:
+        run_case(Net, n)
+
+
+if __name__ == '__main__':
+    main()

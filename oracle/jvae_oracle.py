@@ -1,0 +1,422 @@
+"""TEST INFRASTRUCTURE — CPU oracle: a from-scratch restatement of the reference's per-batch joint-CVAE
+training step in plain PyTorch-CPU fp32 (the reference's own arithmetic IS PyTorch ops).
+
+NOT product code.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+Pinned by tests/test_oracle_golden.py against tests/golden/*.npz, which oracle/gen_golden.py produced by
+running the reference itself (moxime/joint-vae @ /root/reference) in the build container.
+
+Design: purely functional.  A model is (spec, P) where `spec` is a small description derived from the
+constructor kwargs and `P` is a flat dict {state_dict key -> tensor} that uses the reference's key names
+(features.0.weight, encoder.dense_mean.bias, encoder.prior.mean, imager.18.weight, sigma, ...).
+
+Reference anchors (file:line under /root/reference):
+  layer DSL ............ module/vae_layers/conv.py:20-86,128-244 + conv-models.ini:11-30
+  encoder / sampling ... module/vae_layers/layers.py:230-244,350-403
+  forward .............. cvae.py:426-521
+  evaluate (train) ..... cvae.py:523-917
+  losses ............... module/losses.py:8-27,52-86
+  priors ............... module/priors.py:142-148,173-250,252-326,389-408,429-476
+  step ................. cvae.py:2424-2461, module/optimizers.py:79-121 (clip_grad_norm_ + Adam, L2 in grad)
+"""
+import math
+import re
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+NAMED_FEATURES = {            # conv-models.ini:13-21
+    'conv32': '[x5+2]32-32:2-64-64:2-200x7+0',
+    'conv32-': '[x3+1]32-32-32-32:2-64-64-64-64:2-200x7+0',
+    'conv32+': '[x5+2]32-32:2-64-64:2-128-128:2-200x3+0',
+}
+NAMED_UPSAMPLERS = {          # conv-models.ini:25-27
+    'deconv32': '[x5+2]64x8+0-64-64:2++1-32-32:2++1-32-!3x5+2',
+    'deconv32-': '[x3+1]64x8+0-64-64-64-64:2++1-32-32-32-32:2++1-32-!3x5+2',
+    'deconv32+': '[x5+2]128x4+0-128-128:2++1-64-64:2++1-32-32:2++1-32-!3x5+2',
+}
+
+
+# ----------------------------------------------------------------------------------------------- DSL
+def _tok(token, upsampler, dflt):
+    """One '-' separated token -> dict(kind, c, k, p, s, op).  conv.py:20-86 (conv/deconv tokens only)."""
+    d = dict(dflt)
+    kind = 'deconv' if upsampler else 'conv'
+    t = token
+    if upsampler and t.startswith('!'):
+        kind = 'conv'
+        t = t[1:]
+    m = re.match(r'^(\d+)', t)
+    if m:
+        d['c'] = int(m.group(1))
+    m = re.search(r'x(\d+)', t)
+    if m:
+        d['k'] = int(m.group(1))
+    m = re.search(r'\+\+(\d+)', t)
+    if m and upsampler:
+        d['op'] = int(m.group(1))
+    m = re.search(r'(?<!\+)\+(\d+)', t)      # a single '+': padding
+    if m:
+        d['p'] = int(m.group(1))
+    m = re.search(r':(\d+)', t)
+    if m:
+        d['s'] = int(m.group(1))
+    d['kind'] = kind
+    return d
+
+
+def parse_stack(layers_name, in_shape, upsampler):
+    """-> list of dict(kind,cin,c,k,p,s,op, h_in,w_in,h,w).  conv.py:128-230 restricted to (de)conv tokens."""
+    table = NAMED_UPSAMPLERS if upsampler else NAMED_FEATURES
+    s = table.get(layers_name, layers_name)
+    dflt = dict(c=32, k=5, p=None, s=1, op=0)
+    if s[0] == '[':
+        end = s.index(']')
+        for t in s[1:end].split('-'):
+            if t[0] in 'MAUmau!':
+                continue
+            dflt = {**dflt, **{k: v for k, v in _tok(t, upsampler, dflt).items() if k != 'kind'}}
+        s = s[end + 1:]
+    cin, h, w = in_shape
+    out = []
+    for t in s.split('-'):
+        d = _tok(t, upsampler, dflt)
+        if d['p'] is None:
+            d['p'] = d['k'] // 2 if not upsampler else 0
+        if d['kind'] == 'conv':
+            d['op'] = 0
+            ho = (h + 2 * d['p'] - d['k']) // d['s'] + 1
+            wo = (w + 2 * d['p'] - d['k']) // d['s'] + 1
+        else:
+            ho = (h - 1) * d['s'] - 2 * d['p'] + d['k'] + d['op']
+            wo = (w - 1) * d['s'] - 2 * d['p'] + d['k'] + d['op']
+        d.update(cin=cin, h_in=h, w_in=w, h=ho, w=wo)
+        out.append(d)
+        cin, h, w = d['c'], ho, wo
+    return out
+
+
+def find_imager_hw(upsampler, target_hw):
+    """Smallest (h, w) input that the upsampler maps to target_hw.  conv.py:108-125."""
+    h, w = 1, 1
+    while True:
+        st = parse_stack(upsampler, (1, h, w), True)
+        oh, ow = st[-1]['h'], st[-1]['w']
+        if (oh, ow) == tuple(target_hw):
+            return h, w
+        if oh > target_hw[0] or ow > target_hw[1]:
+            raise ValueError('no input shape for ' + upsampler)
+        h += int(oh < target_hw[0])
+        w += int(ow < target_hw[1])
+
+
+# ----------------------------------------------------------------------------------------------- spec
+def make_spec(input_shape, num_labels, type='cvae', features=None, upsampler=None, encoder=(), decoder=(),
+              classifier=(), batch_norm=False, latent_dim=32, latent_sampling=1, test_latent_sampling=None,
+              sigma=None, gamma=0., beta=1., output_activation='linear', activation='relu', prior=None,
+              optimizer=None, **_):
+    assert type == 'cvae' and activation == 'relu'
+    sp = dict(input_shape=tuple(input_shape), C=num_labels, K=latent_dim, L=latent_sampling,
+              beta=beta, gamma=gamma, out_act=output_activation,
+              enc=list(encoder), dec=list(decoder), clf=list(classifier) if gamma else [],
+              prior=dict(prior or {}), opt=dict(optimizer or {}), sigma=dict(sigma or {'value': 1}))
+    bn_e = bool(features) and batch_norm in ('encoder', 'both')     # cvae.py:235-240
+    bn_d = bool(features) and batch_norm == 'both'
+    sp['bn_e'], sp['bn_d'] = bn_e, bn_d
+    if features:
+        sp['features'] = parse_stack(features, input_shape, False)
+        last = sp['features'][-1]
+        enc_in = last['c'] * last['h'] * last['w']
+    else:
+        sp['features'] = None
+        enc_in = int(np.prod(input_shape))
+    sp['enc_in'] = enc_in
+    dec_out = sp['dec'][-1] if sp['dec'] else latent_dim
+    if upsampler:
+        hw = find_imager_hw(upsampler, input_shape[1:])
+        f = hw[0] * hw[1]
+        assert dec_out % f == 0
+        sp['imager_in'] = (dec_out // f, hw[0], hw[1])          # cvae.py:305-310
+        sp['imager'] = parse_stack(upsampler, sp['imager_in'], True)
+    else:
+        sp['imager'] = None
+        sp['imager_in'] = (dec_out,)
+    sp['sampled'] = latent_sampling > 1 or beta > 0            # cvae.py:276
+    return sp
+
+
+def param_keys(sp):
+    """(key, shape) for every state_dict entry the reference model of this spec has, in its order."""
+    out = [('sigma', (1,))]
+
+    def stack(prefix, layers, bn):
+        i = 0
+        for d in layers:
+            if d['kind'] == 'conv':
+                out.append((f'{prefix}.{i}.weight', (d['c'], d['cin'], d['k'], d['k'])))
+            else:
+                out.append((f'{prefix}.{i}.weight', (d['cin'], d['c'], d['k'], d['k'])))
+            out.append((f'{prefix}.{i}.bias', (d['c'],)))
+            i += 1
+            if bn:
+                for leaf in ('weight', 'bias', 'running_mean', 'running_var'):
+                    out.append((f'{prefix}.{i}.{leaf}', (d['c'],)))
+                out.append((f'{prefix}.{i}.num_batches_tracked', ()))
+                i += 1
+            i += 1                                            # the activation slot
+    if sp['features']:
+        stack('features', sp['features'], sp['bn_e'])
+    d_in = sp['enc_in']
+    for j, d in enumerate(sp['enc']):
+        out += [(f'encoder.dense_projs.{2 * j}.weight', (d, d_in)), (f'encoder.dense_projs.{2 * j}.bias', (d,))]
+        d_in = d
+    K, C = sp['K'], sp['C']
+    out += [('encoder.dense_mean.weight', (K, d_in)), ('encoder.dense_mean.bias', (K,)),
+            ('encoder.dense_log_var.weight', (K, d_in)), ('encoder.dense_log_var.bias', (K,)),
+            ('encoder.prior.mean', (C, K))]
+    vd = sp['prior'].get('var_dim', 'scalar') if sp['prior'].get('distribution', 'gaussian') == 'gaussian' else 'scalar'
+    out.append(('encoder.prior._var_parameter', {'scalar': (C,), 'diag': (C, K), 'full': (C, K, K)}[vd]))
+    d_in = K
+    for j, d in enumerate(sp['dec']):
+        out += [(f'decoder.{2 * j}.weight', (d, d_in)), (f'decoder.{2 * j}.bias', (d,))]
+        d_in = d
+    if sp['imager']:
+        stack('imager', sp['imager'], sp['bn_d'])
+    else:
+        D = int(np.prod(sp['input_shape']))
+        out += [('imager.0.weight', (D, d_in)), ('imager.0.bias', (D,))]
+    d_in = K
+    for j, d in enumerate(sp['clf']):
+        out += [(f'classifier.{2 * j}.weight', (d, d_in)), (f'classifier.{2 * j}.bias', (d,))]
+        d_in = d
+    j = len(sp['clf'])
+    out += [(f'classifier.{2 * j}.weight', (C, d_in)), (f'classifier.{2 * j}.bias', (C,))]
+    return out
+
+
+BUFFER_LEAVES = ('running_mean', 'running_var', 'num_batches_tracked')
+
+
+def trainable(sp, key):
+    """Which state entries are nn.Parameters with requires_grad (priors.py:79,105-106,122; layers.py:84-89)."""
+    leaf = key.rsplit('.', 1)[-1]
+    if leaf in BUFFER_LEAVES:
+        return False
+    if key == 'sigma':
+        return bool(sp['sigma'].get('learned', False))
+    if key == 'encoder.prior.mean':
+        return bool(sp['prior'].get('learned_means', False)) and not sp['prior'].get('freeze_means', 0) > 0
+    if key == 'encoder.prior._var_parameter':
+        return sp['prior'].get('distribution', 'gaussian') == 'gaussian' and sp['prior'].get('var_dim', 'scalar') != 'scalar'
+    return True
+
+
+def init_state(sp, seed=0):
+    from .det_init import det_tensor
+    P = {}
+    for key, shape in param_keys(sp):
+        if key == 'sigma':
+            v = float(sp['sigma'].get('value', 1))
+            P[key] = torch.full((1,), math.log(v) if sp['sigma'].get('learned') else v)   # layers.py:84-89
+        elif key.endswith('num_batches_tracked'):
+            P[key] = torch.zeros((), dtype=torch.int64)
+        else:
+            P[key] = det_tensor(key, shape, seed)
+    for key in P:
+        if trainable(sp, key):
+            P[key].requires_grad_(True)
+    return P
+
+
+# ----------------------------------------------------------------------------------------------- forward
+def run_stack(P, prefix, layers, bn, x, last_act, training=True, momentum=0.1, eps=1e-5):
+    """conv.py:186-230: (de)conv -> [BatchNorm2d] -> ReLU; the LAST activation is `last_act` for upsamplers."""
+    i = 0
+    for li, d in enumerate(layers):
+        w, b = P[f'{prefix}.{i}.weight'], P[f'{prefix}.{i}.bias']
+        if d['kind'] == 'conv':
+            x = F.conv2d(x, w, b, stride=d['s'], padding=d['p'])
+        else:
+            x = F.conv_transpose2d(x, w, b, stride=d['s'], padding=d['p'], output_padding=d['op'])
+        i += 1
+        if bn:
+            x = F.batch_norm(x, P[f'{prefix}.{i}.running_mean'], P[f'{prefix}.{i}.running_var'],
+                             P[f'{prefix}.{i}.weight'], P[f'{prefix}.{i}.bias'], training, momentum, eps)
+            if training:
+                P[f'{prefix}.{i}.num_batches_tracked'] += 1
+            i += 1
+        act = 'relu' if (last_act is None or li < len(layers) - 1) else last_act
+        x = _act(x, act)
+        i += 1
+    return x
+
+
+def _act(x, name):
+    return {'relu': torch.relu, 'linear': lambda t: t, 'sigmoid': torch.sigmoid}[name](x)
+
+
+def prior_T(sp, P):
+    vp = P['encoder.prior._var_parameter']
+    return vp.tril() if vp.ndim == 3 else vp                     # priors.py:142-148
+
+
+def prior_kl(sp, P, mu, log_var, y, w):
+    """priors.py:252-326 (gaussian), 389-408 (tilted), 429-476 (uniform).  y: (N,) int64."""
+    dist = sp['prior'].get('distribution', 'gaussian')
+    K = sp['K']
+    m = P['encoder.prior.mean'].index_select(0, y)
+    if dist == 'uniform':
+        tau = float(sp['prior'].get('tau', 5))
+        phi = 0.5 * (1 + math.erf(tau / math.sqrt(2)))
+        alpha = math.log(2 * tau) - math.log(2 * phi - 1)
+        c = math.log(2 * math.pi)
+        span = 2 * math.sqrt(3) * (0.5 * log_var).exp()
+        d = mu - m
+        dist2 = d.square()
+        a_ = tau * F.hardtanh((d - 0.5 * span) / tau)
+        b_ = tau * F.hardtanh((d + 0.5 * span) / tau)
+        elogq = -0.5 * log_var - 0.5 * math.log(12)
+        nel = (c + dist2 + span.square() / 12) / 2
+        nel = nel + (alpha - c / 2) * (b_ - a_) / span
+        nel = nel - (b_.pow(3) - a_.pow(3)) / span / 6
+        vkl = (elogq + alpha).sum(-1)
+        kl = torch.max(elogq.sum(-1) + nel.sum(-1), vkl)
+        if w != 1.0:
+            kl = kl + (w - 1) * vkl
+        return dict(distance=dist2.sum(-1), var_kl=2 * vkl, kl=kl)
+    T = prior_T(sp, P).index_select(0, y)
+    d = mu - m
+    if T.ndim == 3:
+        wd = torch.matmul(T, d.unsqueeze(-1)).squeeze(-1)       # priors.py:202-203
+        pdiag = T.pow(2).sum(-2)                                 # priors.py:231-233
+        logdet_p = -2 * torch.diagonal(T, dim1=-2, dim2=-1).abs().log().sum(-1)
+    elif T.ndim == 2:
+        wd = d * T
+        pdiag = T.pow(2)
+        logdet_p = -2 * T.abs().log().sum(-1)
+    else:
+        wd = d * T.unsqueeze(-1)
+        pdiag = T.pow(2).unsqueeze(-1)
+        logdet_p = -2 * K * T.log()
+    distance = wd.pow(2).sum(-1)
+    if dist == 'tilted':
+        tau = float(sp['prior'].get('tau', 25))
+        return dict(distance=distance, var_kl=torch.zeros_like(distance), kl=0.5 * (distance.sqrt() - tau) ** 2)
+    trace = (log_var.exp() * pdiag).sum(-1)
+    var_kl = trace - log_var.sum(-1) + logdet_p - K
+    return dict(distance=distance, var_kl=var_kl, kl=0.5 * (distance + w * var_kl))
+
+
+def evaluate(sp, P, x, y, eps, kl_var_weighting=1.0, gamma_weighting=1.0, with_beta=True, training=True):
+    """Training-branch evaluate (cvae.py:523-917) -> (x_reco, y_est, losses, measures, mu, log_var, z)."""
+    N = x.shape[0]
+    K, L = sp['K'], sp['L']
+    D = int(np.prod(sp['input_shape']))
+    if sp['features']:
+        t = run_stack(P, 'features', sp['features'], sp['bn_e'], x, None, training)
+    else:
+        t = x
+    u = t.reshape(N, -1)
+    for j in range(len(sp['enc'])):
+        u = torch.relu(F.linear(u, P[f'encoder.dense_projs.{2 * j}.weight'], P[f'encoder.dense_projs.{2 * j}.bias']))
+    mu = F.linear(u, P['encoder.dense_mean.weight'], P['encoder.dense_mean.bias'])
+    log_var = torch.clip(F.linear(u, P['encoder.dense_log_var.weight'], P['encoder.dense_log_var.bias']), -20, 20)
+    z = mu + torch.exp(0.5 * log_var) * eps * float(sp['sampled'])       # layers.py:243, eps[0] == 0
+    h = z
+    for j in range(len(sp['dec'])):
+        h = torch.relu(F.linear(h, P[f'decoder.{2 * j}.weight'], P[f'decoder.{2 * j}.bias']))
+    if sp['imager']:
+        xr = run_stack(P, 'imager', sp['imager'], sp['bn_d'], h.reshape(-1, *sp['imager_in']), sp['out_act'], training)
+    else:
+        xr = _act(F.linear(h, P['imager.0.weight'], P['imager.0.bias']), sp['out_act'])
+    x_reco = xr.reshape(L + 1, N, *sp['input_shape'])
+    c = z
+    nclf = len(sp['clf'])
+    for j in range(nclf):
+        c = torch.relu(F.linear(c, P[f'classifier.{2 * j}.weight'], P[f'classifier.{2 * j}.bias']))
+    logits = F.linear(c, P[f'classifier.{2 * nclf}.weight'], P[f'classifier.{2 * nclf}.bias'])
+
+    s = P['sigma']
+    if sp['sigma'].get('learned'):
+        sigma_, log_sigma = s.exp(), s.squeeze()
+    else:
+        sigma_, log_sigma = s, s.log().squeeze()
+    wmse_s = ((x_reco[1:] / sigma_ - (x / sigma_).unsqueeze(0)) ** 2).reshape(L, N, -1).mean(-1)   # losses.py:8-27
+    wmse = wmse_s.mean(0)
+    mse = wmse * sigma_ ** 2
+    kd = prior_kl(sp, P, mu, log_var, y, kl_var_weighting)
+    losses = dict(kl=kd['kl'], zdist=kd['distance'], var_kl=kd['var_kl'])
+    dic = P['encoder.prior.mean']
+    dmean = dic.mean(0)
+    losses['dzdist'] = (mu - dmean).pow(2).sum(1) + (dic.pow(2).sum(1).mean(0) - dmean.pow(2).sum())
+    losses['wmse'] = wmse
+    losses['cross_x'] = D * (2 * log_sigma + wmse + math.log(2 * math.pi)) / 2        # cvae.py:773-789, sdim=1
+    total = losses['cross_x']
+    if sp['gamma']:
+        # NB cvae.py:738 hands x_loss the full (L+1, N, C) logits: the eps=0 row is part of the average
+        ce = F.cross_entropy(logits.reshape(-1, logits.shape[-1]), y.repeat(L + 1),
+                             reduction='none').reshape(L + 1, N).mean(0)                   # losses.py:76-86
+        losses['cross_y'] = ce
+        cw = gamma_weighting * sp['gamma'] if training else 0
+        if cw:
+            total = total + cw * ce
+    total = total + (sp['beta'] if with_beta else 1.) * losses['kl']
+    losses['total'] = total
+
+    with torch.no_grad():
+        xpow = x.pow(2).mean().item()
+        mse_m = mse.mean().item()
+        cd = torch.cdist(dic, dic)
+        C = sp['C']
+        meas = {'sigma': float(sigma_.pow(2).mean().sqrt()), 'xpow': xpow, 'mse': mse_m,
+                'rmse': math.sqrt(mse_m), 'dB': 10 * math.log10(xpow / mse_m),
+                'zdist': kd['distance'].mean().item(), 'var_kl': kd['var_kl'].mean().item(),
+                'ld-norm': dic.pow(2).mean().item(),
+                'imut-zy': (math.log(C) - 1 / C * torch.exp(-cd.pow(2) / 4).sum(0).log().sum()).item(),
+                'd-mind': (cd + 2 * dic.norm(dim=1).max() * torch.eye(C)).min().item()}
+    return x_reco, logits[1:].mean(0), losses, meas, mu, log_var, z
+
+
+# ----------------------------------------------------------------------------------------------- step
+class AdamState:
+    """torch.optim.Adam(lr, betas=(.9,.999), eps=1e-8, weight_decay=L2-in-grad) + clip_grad_norm_
+    restated by hand (optimizers.py:39-47,79-81,120-121)."""
+
+    def __init__(self, sp):
+        o = sp['opt']
+        self.lr = o.get('lr') or 1e-3
+        self.wd = o.get('weight_decay', 0.)
+        self.clip = o.get('grad_clipping')
+        self.t = 0
+        self.m, self.v = {}, {}
+
+    def step(self, P, grads):
+        gn = torch.sqrt(sum(g.double().pow(2).sum() for g in grads.values())).float()
+        coef = 1.0
+        if self.clip:
+            coef = torch.clamp(self.clip / (gn + 1e-6), max=1.0)
+        self.t += 1
+        b1, b2 = 0.9, 0.999
+        with torch.no_grad():
+            for k, g in grads.items():
+                g = g * coef + self.wd * P[k]
+                m = self.m.setdefault(k, torch.zeros_like(g))
+                v = self.v.setdefault(k, torch.zeros_like(g))
+                m.mul_(b1).add_(g, alpha=1 - b1)
+                v.mul_(b2).addcmul_(g, g, value=1 - b2)
+                denom = (v.sqrt() / math.sqrt(1 - b2 ** self.t)).add_(1e-8)
+                P[k].addcdiv_(m, denom, value=-self.lr / (1 - b1 ** self.t))
+        return float(gn)
+
+
+def train_step(sp, P, opt, x, y, eps, kl_var_weighting=1.0, gamma_weighting=1.0):
+    """cvae.py:2424-2461: evaluate -> total.mean().backward() -> clip -> Adam.  Returns (losses, measures, grads)."""
+    for p in P.values():
+        if p.requires_grad:
+            p.grad = None
+    out = evaluate(sp, P, x, y, eps, kl_var_weighting, gamma_weighting, with_beta=True, training=True)
+    losses = out[2]
+    losses['total'].mean().backward()
+    grads = {k: p.grad for k, p in P.items() if p.requires_grad and p.grad is not None}
+    gn = opt.step(P, grads)
+    return out, grads, gn

@@ -1,0 +1,76 @@
+"""Pins the CPU oracle (oracle/jvae_oracle.py) against the reference's own outputs (tests/golden/*.npz,
+written by oracle/gen_golden.py which ran moxime/joint-vae itself).  Tolerance: 2e-5 relative fp32."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import jvae_oracle as O
+from oracle.cases import CASES, get_case
+from oracle.det_init import det_inputs
+
+RTOL = 2e-5
+
+
+def _close(a, b, rtol=RTOL, floor=1e-30, what=''):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    scale = max(np.abs(b).max(), floor)
+    err = np.abs(a - b).max() / scale
+    assert err <= rtol, f'{what}: rel err {err:.3e} (scale {scale:.3e})'
+
+
+def _dead_bias(key, state_keys):
+    """A conv bias directly in front of a BatchNorm has an exactly-zero true gradient (BN removes the mean):
+    what the reference stores for it is rounding noise, so element-wise comparison is meaningless."""
+    parts = key.split('.')
+    if parts[-1] != 'bias' or not parts[-2].isdigit():
+        return False
+    nxt = '.'.join(parts[:-2] + [str(int(parts[-2]) + 1), 'running_mean'])
+    return nxt in set(state_keys)
+
+
+@pytest.mark.parametrize('name', list(CASES))
+def test_oracle_matches_reference(name, golden_dir):
+    g = np.load(os.path.join(golden_dir, name + '.npz'))
+    case = get_case(name)
+    sp = O.make_spec(**case['net'])
+    P = O.init_state(sp, seed=0)
+    # state_dict contract: same keys / shapes as the reference model
+    keys = [k for k, _ in O.param_keys(sp)]
+    assert keys == list(g['state_keys']), (keys, list(g['state_keys']))
+    shapes = [','.join(str(s) for s in sh) for _, sh in O.param_keys(sp)]
+    assert shapes == list(g['state_shapes'])
+    uniform = case['net']['prior'].get('distribution') == 'uniform'
+    x, y, eps = det_inputs(case['N'], sp['input_shape'], sp['C'], sp['L'], sp['K'], uniform_eps=uniform)
+    opt = O.AdamState(sp)
+    out, grads, gn = O.train_step(sp, P, opt, x, y, eps, case['kl_var_weighting'], case['gamma_weighting'])
+    x_reco, y_est, losses, meas, mu, log_var, z = out
+    _close(mu.detach(), g['mu'], what='mu')
+    _close(log_var.detach(), g['log_var'], what='log_var')
+    _close(z.detach(), g['z'], what='z')
+    _close(x_reco.detach(), g['x_reco'], what='x_reco')
+    _close(y_est.detach(), g['y_est'], rtol=1e-4, what='y_est')
+    for k in [f[5:] for f in g.files if f.startswith('loss.')]:
+        if k == 'var_kl' and np.abs(g['loss.var_kl']).max() == 0:
+            continue
+        _close(losses[k].detach(), g['loss.' + k], what='loss.' + k)
+    for k in [f[8:] for f in g.files if f.startswith('measure.')]:
+        assert abs(meas[k] - float(g['measure.' + k])) <= 1e-4 * max(1.0, abs(float(g['measure.' + k]))), k
+    assert set(grads) == set(g['grad_names'])
+    _close(gn, g['total_grad_norm'], what='total grad norm')
+    for k in g['grad_names']:
+        gnorm = float(grads[k].double().norm())
+        ref = float(g['gnorm.' + k])
+        assert abs(gnorm - ref) <= 1e-4 * max(ref, 1e-3 * float(g['total_grad_norm'])), (k, gnorm, ref)
+        if 'grad.' + k in g.files:
+            if _dead_bias(k, g['state_keys']):
+                continue
+            _close(grads[k], g['grad.' + k], rtol=2e-4, floor=1e-6 * float(g['total_grad_norm']), what='grad.' + k)
+    for k in g['param_names']:
+        if 'param_after.' + k in g.files and not _dead_bias(k, g['state_keys']):   # Adam amplifies the noise sign
+            _close(P[k].detach(), g['param_after.' + k], rtol=1e-5, what='param_after.' + k)
+    for f in g.files:
+        if f.startswith('buffer_after.'):
+            _close(P[f[13:]].detach().double(), g[f], rtol=1e-5, what=f)
