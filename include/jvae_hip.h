@@ -1,0 +1,134 @@
+/* libjvae_hip.so — C ABI of the MI355X (gfx950) kernels behind the joint-CVAE training step.
+ *
+ * Drop-in boundary: the reference (moxime/joint-vae) has no FFI of its own — the path sits
+ * behind a Python import surface (cvae.py:8-15) and bottoms out in PyTorch ops.  Each entry point below
+ * names the PyTorch op / reference lines it replaces; the Python host in joint-vae_amd/ binds them with
+ * ctypes (joint-vae_amd/jvae_hip/lib.py) — INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *   - plain pointers to DEVICE memory (fp32 unless stated; class labels int64), sizes as int/long,
+ *     `stream` is a hipStream_t passed as void*; everything is stream-ordered, nothing synchronises,
+ *     nothing allocates: scratch comes from the caller (`ws`, size from the matching *_workspace_bytes).
+ *   - tensors are dense, NCHW for images.
+ *   - return 0 = ok, <0 = invalid argument (-1), unsupported (-2), workspace too small (-3),
+ *     >0 = hipError_t of the failing launch.
+ *   - thread-compatible: no global mutable state.
+ */
+#ifndef JVAE_HIP_H
+#define JVAE_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* jvae_version(void);
+
+/* ---- dense products -------------------------------------------------------------------------------
+ * C[b](m,n) (+)= sum_k A[b](m,k) B[b](k,n) [+ bias] [ReLU]; strides in elements; batch over b.
+ * bias_mode 0 none / 1 per-n / 2 per-m.  flags: 1 accumulate into C, 2 ReLU, 4 add with float atomics
+ * (C must hold the base value; implied by splitk > 1).
+ * Replaces nn.Linear forward/backward (module/vae_layers/layers.py:283-296,380-394; cvae.py:291-301,319-326;
+ * Classifier layers.py:456-483) and the GEMM inside every convolution. */
+int jvae_gemm_f32(int M, int N, int K, int batch,
+                  const float* A, long sAm, long sAk, long sAb,
+                  const float* B, long sBk, long sBn, long sBb,
+                  float* C, long sCm, long sCn, long sCb,
+                  const float* bias, int bias_mode, int flags, int splitk, void* stream);
+
+/* ---- (transposed) convolution ---------------------------------------------------------------------
+ * x: (N,Cin,H,W) layer input; y: (N,Cout,OH,OW) layer output; w in the PyTorch layout of the layer kind
+ * ((Cout,Cin,KH,KW) for Conv2d, (Cin,Cout,KH,KW) for ConvTranspose2d); S stride, P padding,
+ * OP output_padding (transposed only).  Replaces nn.Conv2d / nn.ConvTranspose2d built by
+ * build_de_conv_layers (module/vae_layers/conv.py:186-196) and their autograd backward.
+ * wgrad: accumulate != 0 adds into dw/dbias (autograd .grad accumulation), else overwrites. */
+size_t jvae_conv2d_workspace_bytes(int N, int Cin, int H, int W, int Cout, int KH, int KW, int S, int P, int OP,
+                                   int transposed);
+int jvae_conv2d_out_shape(int H, int W, int KH, int KW, int S, int P, int OP, int transposed, int* OH, int* OW);
+int jvae_conv2d_fwd_f32(const float* x, const float* w, const float* bias, float* y,
+                        int N, int Cin, int H, int W, int Cout, int KH, int KW, int S, int P, int OP, int transposed,
+                        void* ws, size_t ws_bytes, void* stream);
+int jvae_conv2d_dgrad_f32(const float* dy, const float* w, float* dx,
+                          int N, int Cin, int H, int W, int Cout, int KH, int KW, int S, int P, int OP, int transposed,
+                          void* ws, size_t ws_bytes, void* stream);
+int jvae_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, float* dbias, int accumulate,
+                          int N, int Cin, int H, int W, int Cout, int KH, int KW, int S, int P, int OP, int transposed,
+                          void* ws, size_t ws_bytes, void* stream);
+
+/* out[c] (+)= sum_{n,q} t[n][c][q]: bias gradient of a conv (P = OH*OW) or linear (P = 1) layer. */
+int jvae_channel_sum_f32(const float* t, float* out, int N, int C, int P, int accumulate, void* stream);
+
+/* ---- BatchNorm2d (+ fused ReLU) -------------------------------------------------------------------
+ * x,y,dx,dy: (N,C,P) with P = H*W.  training != 0: batch statistics (biased variance in the forward,
+ * unbiased into running_var, momentum update, num_batches_tracked += 1), else running statistics.
+ * relu != 0 fuses the following nn.ReLU (conv.py:214-220).  Backward recomputes the ReLU mask from x. */
+size_t jvae_bn_workspace_bytes(int C);
+int jvae_bn_fwd_f32(const float* x, const float* gamma, const float* beta,
+                    float* running_mean, float* running_var, long long* num_batches_tracked,
+                    float* y, float* save_mean, float* save_invstd,
+                    int N, int C, int P, float momentum, float eps, int training, int relu,
+                    void* ws, size_t ws_bytes, void* stream);
+int jvae_bn_bwd_f32(const float* dy, const float* x, const float* gamma, const float* beta,
+                    const float* save_mean, const float* save_invstd,
+                    float* dx, float* dgamma, float* dbeta, int accumulate,
+                    int N, int C, int P, int relu, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- activations (kind 0 identity, 1 ReLU, 2 sigmoid); backward takes the forward OUTPUT ---------- */
+int jvae_act_fwd_f32(const float* x, float* y, long n, int kind, void* stream);
+int jvae_act_bwd_f32(const float* dy, const float* y, float* dx, long n, int kind, void* stream);
+
+/* ---- latent: clip + reparameterise + KL to the class-conditional prior ----------------------------
+ * Replaces Encoder.forward's clip (layers.py:388-394), Sampling.forward (layers.py:230-244; eps is an
+ * input: eps (L+1,N,K) with eps[0] = 0), GaussianPrior.kl & helpers (priors.py:173-326),
+ * TiltedGaussianPrior.kl (priors.py:389-408), UniformWithGaussianTailPrior.kl (priors.py:429-476) and
+ * dzdist (cvae.py:747-753).
+ * prior: 0 gaussian, 1 tilted, 2 uniform.  var_dim: 0 scalar T (C,), 1 diag (C,K), 2 full (C,K,K).
+ * dict (K+1 floats from jvae_dict_stats_f32, or NULL): dictionary mean and its norm variance.
+ * Outputs: lv (N,K) clipped log-variance, z (L+1,N,K), kl / zdist / var_kl / dzdist (N,). */
+int jvae_dict_stats_f32(const float* means, float* dict, int C, int K, void* stream);
+int jvae_latent_fwd_f32(const float* mu, const float* lv_raw, const float* eps, const long long* y,
+                        const float* means, const float* T, const float* dict,
+                        float* lv, float* z, float* kl, float* zdist, float* var_kl, float* dzdist,
+                        int N, int K, int L, int C, int prior, int var_dim, float tau, float alpha, float w,
+                        int sampled, int has_forced, float forced_lv, void* stream);
+/* Upstream gradients (any may be NULL): gz (L+1,N,K), g_kl / g_zdist / g_vkl (N,), gmu_direct /
+ * glv_direct (N,K).  gmeans (C,K) and gT (shape of T; diag/full only) are ADDED to with float atomics.
+ * ws: 2*N floats for the uniform prior. */
+int jvae_latent_bwd_f32(const float* mu, const float* lv_raw, const float* lv, const float* eps, const long long* y,
+                        const float* means, const float* T,
+                        const float* gz, const float* g_kl, const float* g_zdist, const float* g_vkl,
+                        const float* gmu_direct, const float* glv_direct,
+                        float* gmu, float* glv_raw, float* gmeans, float* gT,
+                        int N, int K, int L, int C, int prior, int var_dim, float tau, float alpha, float w,
+                        int sampled, int has_forced, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- reconstruction term ---------------------------------------------------------------------------
+ * wmse[l][n] = mean_D((x_reco[l+1][n] - x[n])^2) / sigma^2   (mse_loss, module/losses.py:8-27, called at
+ * cvae.py:649-652 on x_reco[1:]/sigma, x/sigma).  sigma: 1 float on the device, log(sigma) if sigma_is_log
+ * (learned sigma, layers.py:84-89).  Backward fills ALL L+1 rows of g_x_reco (row 0 with zeros). */
+int jvae_recon_fwd_f32(const float* x_reco, const float* x, const float* sigma, int sigma_is_log,
+                       float* wmse, int L, int N, int D, void* stream);
+int jvae_recon_bwd_f32(const float* x_reco, const float* x, const float* sigma, int sigma_is_log,
+                       const float* g_wmse, const float* wmse, float* g_x_reco, float* gsigma, int accumulate_sigma,
+                       int L, int N, int D, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- classification term: per-row cross entropy, target y[r % N] (x_loss, module/losses.py:52-86) -- */
+int jvae_xent_fwd_f32(const float* logits, const long long* y, float* ce, int R, int N, int C, void* stream);
+int jvae_xent_bwd_f32(const float* logits, const long long* y, const float* g_ce, float* g_logits, int R, int N, int C,
+                      void* stream);
+
+/* ---- optimiser: clip_grad_norm_ + Adam (module/optimizers.py:39-47,79-81,120-121; cvae.py:2454-2461)
+ * jvae_sqnorm_accum_f32: *acc += sum g^2 (reset != 0 zeroes acc first).
+ * jvae_adam_step_f32: g' = g*min(1, max_norm/(sqrt(*sqnorm)+1e-6)) + weight_decay*p, Adam with bias
+ * correction for `step` (>= 1); *nonfinite_flag |= 1 when an updated parameter is NaN/Inf. */
+int jvae_sqnorm_accum_f32(const float* g, long n, float* acc, int reset, void* stream);
+int jvae_clip_scale_f32(float* g, long n, const float* sqnorm, float max_norm, void* stream);
+int jvae_adam_step_f32(float* p, const float* g, float* m, float* v, long n,
+                       float lr, float beta1, float beta2, float eps, float weight_decay, long step,
+                       float max_norm, const float* sqnorm, int* nonfinite_flag, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JVAE_HIP_H */

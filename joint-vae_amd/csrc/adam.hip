@@ -1,0 +1,133 @@
+// Global-norm gradient clipping + Adam over flat fp32 buffers (HBM-bound: 4 streams in, 3 out).
+//
+// Reference: Optimizer.clip -> nn.utils.clip_grad_norm_(params, max_norm) and Optimizer.step ->
+// torch.optim.Adam(lr, betas=(0.9, 0.999), eps=1e-8, weight_decay = L2 added to the gradient)
+// (module/optimizers.py:39-47,79-81,120-121, called at cvae.py:2460-2461), plus the per-parameter
+// NaN/Inf scan of cvae.py:2454-2457 folded into the update as one flag word.
+#include "common.h"
+#include "jvae_internal.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g, long n, float* acc) {
+    __shared__ float red[17];
+    float s = 0.f;
+    const long n4 = n >> 2;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const f32x4 v = reinterpret_cast<const f32x4*>(g)[i];
+        s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    }
+    if (blockIdx.x == 0)
+        for (long i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) s += g[i] * g[i];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) atomicAdd(acc, s);
+}
+
+struct AdamP {
+    float* p; const float* g; float* m; float* v; long n;
+    float lr_over_bc1, b1, b2, eps, wd, inv_sqrt_bc2, max_norm;
+    const float* sqnorm; int* flag;
+};
+
+__device__ __forceinline__ float adam1(float p, float g, float& m, float& v, const AdamP& a, float coef) {
+    g = fmaf(g, coef, a.wd * p);
+    m = a.b1 * m + (1.f - a.b1) * g;
+    v = a.b2 * v + (1.f - a.b2) * g * g;
+    const float denom = sqrtf(v) * a.inv_sqrt_bc2 + a.eps;
+    return p - a.lr_over_bc1 * (m / denom);
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(AdamP a) {
+    float coef = 1.f;
+    if (a.max_norm > 0.f && a.sqnorm) coef = fminf(1.f, a.max_norm / (sqrtf(a.sqnorm[0]) + 1e-6f));
+    bool bad = false;
+    const long n4 = a.n >> 2;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        f32x4 p = reinterpret_cast<f32x4*>(a.p)[i];
+        const f32x4 g = reinterpret_cast<const f32x4*>(a.g)[i];
+        f32x4 m = reinterpret_cast<f32x4*>(a.m)[i], v = reinterpret_cast<f32x4*>(a.v)[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float mj = m[j], vj = v[j];
+            p[j] = adam1(p[j], g[j], mj, vj, a, coef);
+            m[j] = mj; v[j] = vj;
+            bad |= !isfinite(p[j]);
+        }
+        reinterpret_cast<f32x4*>(a.p)[i] = p;
+        reinterpret_cast<f32x4*>(a.m)[i] = m;
+        reinterpret_cast<f32x4*>(a.v)[i] = v;
+    }
+    if (blockIdx.x == 0)
+        for (long i = (n4 << 2) + threadIdx.x; i < a.n; i += blockDim.x) {
+            float mj = a.m[i], vj = a.v[i];
+            const float pn = adam1(a.p[i], a.g[i], mj, vj, a, coef);
+            a.p[i] = pn; a.m[i] = mj; a.v[i] = vj;
+            bad |= !isfinite(pn);
+        }
+    if (a.flag && __any(bad) && (threadIdx.x & 63) == 0) atomicOr(a.flag, 1);
+}
+
+// g *= min(1, max_norm / (sqrt(sqnorm) + 1e-6))   (what clip_grad_norm_ leaves in .grad)
+__global__ __launch_bounds__(256) void clip_scale_kernel(float* g, long n, const float* sqnorm, float max_norm) {
+    const float coef = fminf(1.f, max_norm / (sqrtf(sqnorm[0]) + 1e-6f));
+    if (coef >= 1.f) return;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) g[i] *= coef;
+}
+
+inline int grid_for(long n4) {
+    long b = (n4 + 255) / 256;
+    return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b));
+}
+
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" {
+
+// *acc (device float) += sum(g^2); reset != 0 zeroes it first (stream-ordered)
+int jvae_sqnorm_accum_f32(const float* g, long n, float* acc, int reset, void* stream) {
+    if (!acc || n < 0 || (n > 0 && !g)) return JVAE_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (reset) {
+        hipError_t e = hipMemsetAsync(acc, 0, sizeof(float), st);
+        if (e != hipSuccess) return (int)e;
+    }
+    if (n == 0) return 0;
+    if (!al16(g)) return JVAE_EINVAL;
+    hipLaunchKernelGGL(sqnorm_kernel, dim3(grid_for(n / 4)), dim3(256), 0, st, g, n, acc);
+    JVAE_LAUNCH_CHECK();
+    return 0;
+}
+
+int jvae_clip_scale_f32(float* g, long n, const float* sqnorm, float max_norm, void* stream) {
+    if (!g || !sqnorm || n < 0 || !(max_norm > 0.f)) return JVAE_EINVAL;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(clip_scale_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, g, n, sqnorm, max_norm);
+    JVAE_LAUNCH_CHECK();
+    return 0;
+}
+
+// step >= 1.  sqnorm / flag may be null (no clipping / no non-finite report).
+int jvae_adam_step_f32(float* p, const float* g, float* m, float* v, long n,
+                       float lr, float beta1, float beta2, float eps, float weight_decay, long step,
+                       float max_norm, const float* sqnorm, int* nonfinite_flag, void* stream) {
+    if (n < 0 || step < 1) return JVAE_EINVAL;
+    if (n == 0) return 0;
+    if (!p || !g || !m || !v) return JVAE_EINVAL;
+    if (!al16(p) || !al16(g) || !al16(m) || !al16(v)) return JVAE_EINVAL;
+    AdamP a;
+    a.p = p; a.g = g; a.m = m; a.v = v; a.n = n;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    a.lr_over_bc1 = (float)((double)lr / bc1);
+    a.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+    a.b1 = beta1; a.b2 = beta2; a.eps = eps; a.wd = weight_decay; a.max_norm = max_norm;
+    a.sqnorm = sqnorm; a.flag = nonfinite_flag;
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, a);
+    JVAE_LAUNCH_CHECK();
+    return 0;
+}
+
+const char* jvae_version(void) { return "jvae_hip 0.1 (gfx950)"; }
+
+}  // extern "C"

@@ -1,0 +1,206 @@
+// Generic (any kernel size / stride / padding) convolution and transposed convolution for NCHW fp32:
+// unfold ("im2col") of the big-side tensor + the MFMA GEMM of gemm.hip, all three directions.
+//
+// Reference ops replaced: nn.Conv2d / nn.ConvTranspose2d built by build_de_conv_layers
+// (module/vae_layers/conv.py:186-196) and their autograd backward.
+//
+// Vocabulary (jvae_internal.h ConvGeom): the BIG side is the tensor that gets unfolded (conv input,
+// transposed-conv output), the SMALL side lives on the folded grid (conv output, transposed-conv input);
+// big position = small position * S + tap - P for both layer kinds, and both weight layouts are
+// row-major [Cs][Cb*KH*KW].  Three primitives cover six directions:
+//     fold_fwd   : Ys = W . unfold(Xb)        conv forward          | transposed-conv dgrad
+//     fold_bwd   : Xb = fold(W^T . Ys)        conv dgrad            | transposed-conv forward
+//     fold_wgrad : dW = Ys . unfold(Xb)^T     conv wgrad            | transposed-conv wgrad
+// The hot 5x5 layers are taken over by the implicit LDS-patch kernels in conv_mfma.hip; this file stays
+// the path for every other geometry (7x7 / 8x8 / 3x3 / 4x4 heads of conv32, deconv32, conv32+, ...).
+#include "common.h"
+#include "jvae_internal.h"
+
+namespace {
+
+// col(n,k,q) = Xb[n][cb][hs*S+kh-P][ws*S+kw-P]  (k = (cb,kh,kw), q = (hs,ws)), zero outside the image.
+// Output address = n*sn + k*sk + q*sq so that both col layouts ([n][k][q] and [q][n][k]) are served.
+// `kfast`: consecutive threads walk k (for the [q][n][k] layout) instead of q.
+__global__ __launch_bounds__(256) void unfold_kernel(const float* __restrict__ xb, float* __restrict__ col,
+                                                     ConvGeom g, int n0, int nimg, long sn, long sk, long sq,
+                                                     int kfast) {
+    const int Kd = g.Cb * g.KH * g.KW, Ps = g.Hs * g.Ws;
+    const long total = (long)nimg * Kd * Ps;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int n, k, q;
+        if (kfast) { k = (int)(i % Kd); long r = i / Kd; n = (int)(r % nimg); q = (int)(r / nimg); }
+        else       { q = (int)(i % Ps); long r = i / Ps; k = (int)(r % Kd);  n = (int)(r / Kd); }
+        const int kw = k % g.KW, kh = (k / g.KW) % g.KH, cb = k / (g.KW * g.KH);
+        const int hs = q / g.Ws, ws = q % g.Ws;
+        const int hb = hs * g.S + kh - g.P, wb = ws * g.S + kw - g.P;
+        float v = 0.f;
+        if (hb >= 0 && hb < g.Hb && wb >= 0 && wb < g.Wb)
+            v = xb[(((long)(n0 + n) * g.Cb + cb) * g.Hb + hb) * g.Wb + wb];
+        col[(long)n * sn + (long)k * sk + (long)q * sq] = v;
+    }
+}
+
+// Xb[n][cb][hb][wb] (=|+=) bias[cb] + sum over taps of col(n,(cb,kh,kw),(hs,ws)) with hs*S+kh-P == hb.
+__global__ __launch_bounds__(256) void fold_kernel(const float* __restrict__ col, float* __restrict__ xb,
+                                                   const float* __restrict__ bias, ConvGeom g, int n0, int nimg,
+                                                   long sn, long sk, long sq) {
+    const long total = (long)nimg * g.Cb * g.Hb * g.Wb;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int wb = (int)(i % g.Wb);
+        long r = i / g.Wb;
+        const int hb = (int)(r % g.Hb); r /= g.Hb;
+        const int cb = (int)(r % g.Cb);
+        const int n = (int)(r / g.Cb);
+        float acc = bias ? bias[cb] : 0.f;
+        for (int kh = 0; kh < g.KH; ++kh) {
+            const int th = hb + g.P - kh;
+            if (th < 0 || th % g.S) continue;
+            const int hs = th / g.S;
+            if (hs >= g.Hs) continue;
+            for (int kw = 0; kw < g.KW; ++kw) {
+                const int tw = wb + g.P - kw;
+                if (tw < 0 || tw % g.S) continue;
+                const int ws = tw / g.S;
+                if (ws >= g.Ws) continue;
+                const int k = (cb * g.KH + kh) * g.KW + kw;
+                acc += col[(long)n * sn + (long)k * sk + (long)(hs * g.Ws + ws) * sq];
+            }
+        }
+        xb[(((long)(n0 + n) * g.Cb + cb) * g.Hb + hb) * g.Wb + wb] = acc;
+    }
+}
+
+// out[c] (+)= sum_{n,q} t[n][c][q]      (bias gradients; reference: autograd of the conv bias add)
+__global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ t, float* __restrict__ out,
+                                                          int N, int C, int P, int accumulate) {
+    __shared__ float red[17];
+    const int c = blockIdx.x;
+    float s = 0.f;
+    const long per = (long)N * P;
+    for (long i = threadIdx.x; i < per; i += blockDim.x) {
+        const long n = i / P, q = i % P;
+        s += t[(n * C + c) * P + q];
+    }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) out[c] = accumulate ? out[c] + s : s;
+}
+
+inline int grid_for(long total) {
+    long b = (total + 255) / 256;
+    return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b));
+}
+
+// Small folded grids (E4 of conv32: 2x2) make per-image products degenerate: batch over positions instead.
+inline bool pixel_batched(const ConvGeom& g) { return g.Hs * g.Ws < 32; }
+
+inline long col_floats_per_image(const ConvGeom& g) { return (long)g.Cb * g.KH * g.KW * g.Hs * g.Ws; }
+
+}  // namespace
+
+size_t jvae_conv_generic_ws(const ConvGeom& g) {
+    // bounded: at most ~1 GiB of unfold buffer, at least one image
+    const long per = col_floats_per_image(g) * 4;
+    long imgs = (1L << 30) / (per > 0 ? per : 1);
+    if (imgs < 1) imgs = 1;
+    if (imgs > g.N) imgs = g.N;
+    if (pixel_batched(g)) imgs = g.N;            // [q][n][k] layout is not chunked (tiny grids only)
+    return (size_t)(imgs * per);
+}
+
+static int chunk_images(const ConvGeom& g, size_t ws_bytes) {
+    const long per = col_floats_per_image(g) * 4;
+    long imgs = (long)(ws_bytes / (size_t)(per > 0 ? per : 1));
+    if (imgs > g.N) imgs = g.N;
+    return (int)imgs;
+}
+
+int jvae_fold_fwd(const ConvGeom& g, const float* xb, const float* w, const float* bias, float* ys,
+                  float* ws, size_t ws_bytes, hipStream_t st) {
+    const int Kd = g.Cb * g.KH * g.KW, Ps = g.Hs * g.Ws;
+    if (pixel_batched(g)) {
+        if (ws_bytes < (size_t)col_floats_per_image(g) * 4 * g.N) return JVAE_EWORKSPACE;
+        // col[q][n][k];  Y_q[n][cs] = col_q[n][:] . W[cs][:]
+        hipLaunchKernelGGL(unfold_kernel, dim3(grid_for((long)g.N * Kd * Ps)), dim3(256), 0, st, xb, ws, g, 0, g.N,
+                           (long)Kd, 1L, (long)g.N * Kd, 1);
+        JVAE_LAUNCH_CHECK();
+        return jvae_gemm_launch(g.N, g.Cs, Kd, Ps, ws, Kd, 1, (long)g.N * Kd, w, 1, Kd, 0,
+                                ys, (long)g.Cs * Ps, Ps, 1, bias, bias ? 1 : 0, 0, 1, st);
+    }
+    const int chunk = chunk_images(g, ws_bytes);
+    if (chunk < 1) return JVAE_EWORKSPACE;
+    for (int n0 = 0; n0 < g.N; n0 += chunk) {
+        const int ni = (g.N - n0 < chunk) ? g.N - n0 : chunk;
+        hipLaunchKernelGGL(unfold_kernel, dim3(grid_for((long)ni * Kd * Ps)), dim3(256), 0, st, xb, ws, g, n0, ni,
+                           (long)Kd * Ps, (long)Ps, 1L, 0);
+        JVAE_LAUNCH_CHECK();
+        int rc = jvae_gemm_launch(g.Cs, Ps, Kd, ni, w, Kd, 1, 0, ws, Ps, 1, (long)Kd * Ps,
+                                  ys + (long)n0 * g.Cs * Ps, Ps, 1, (long)g.Cs * Ps, bias, bias ? 2 : 0, 0, 1, st);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+int jvae_fold_bwd(const ConvGeom& g, const float* ys, const float* w, const float* bias, float* xb,
+                  float* ws, size_t ws_bytes, hipStream_t st) {
+    const int Kd = g.Cb * g.KH * g.KW, Ps = g.Hs * g.Ws;
+    if (pixel_batched(g)) {
+        if (ws_bytes < (size_t)col_floats_per_image(g) * 4 * g.N) return JVAE_EWORKSPACE;
+        // dcol_q[n][k] = sum_cs Ys[n][cs][q] W[cs][k]
+        int rc = jvae_gemm_launch(g.N, Kd, g.Cs, Ps, ys, (long)g.Cs * Ps, Ps, 1, w, Kd, 1, 0,
+                                  ws, Kd, 1, (long)g.N * Kd, nullptr, 0, 0, 1, st);
+        if (rc) return rc;
+        hipLaunchKernelGGL(fold_kernel, dim3(grid_for((long)g.N * g.Cb * g.Hb * g.Wb)), dim3(256), 0, st, ws, xb, bias,
+                           g, 0, g.N, (long)Kd, 1L, (long)g.N * Kd);
+        JVAE_LAUNCH_CHECK();
+        return 0;
+    }
+    const int chunk = chunk_images(g, ws_bytes);
+    if (chunk < 1) return JVAE_EWORKSPACE;
+    for (int n0 = 0; n0 < g.N; n0 += chunk) {
+        const int ni = (g.N - n0 < chunk) ? g.N - n0 : chunk;
+        // dcol_n[k][q] = sum_cs W[cs][k] Ys_n[cs][q]
+        int rc = jvae_gemm_launch(Kd, Ps, g.Cs, ni, w, 1, Kd, 0, ys + (long)n0 * g.Cs * Ps, Ps, 1, (long)g.Cs * Ps,
+                                  ws, Ps, 1, (long)Kd * Ps, nullptr, 0, 0, 1, st);
+        if (rc) return rc;
+        hipLaunchKernelGGL(fold_kernel, dim3(grid_for((long)ni * g.Cb * g.Hb * g.Wb)), dim3(256), 0, st, ws, xb, bias,
+                           g, n0, ni, (long)Kd * Ps, (long)Ps, 1L);
+        JVAE_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+// dW[Cs][Kd] (+)= sum_n Ys_n . unfold(Xb)_n^T.  dW must already hold the value to accumulate onto
+// (the caller zeroes it for a plain gradient): partial products are added with float atomics.
+int jvae_fold_wgrad(const ConvGeom& g, const float* xb, const float* ys, float* dw,
+                    float* ws, size_t ws_bytes, hipStream_t st) {
+    const int Kd = g.Cb * g.KH * g.KW, Ps = g.Hs * g.Ws;
+    if (pixel_batched(g)) {
+        if (ws_bytes < (size_t)col_floats_per_image(g) * 4 * g.N) return JVAE_EWORKSPACE;
+        hipLaunchKernelGGL(unfold_kernel, dim3(grid_for((long)g.N * Kd * Ps)), dim3(256), 0, st, xb, ws, g, 0, g.N,
+                           (long)Kd, 1L, (long)g.N * Kd, 1);
+        JVAE_LAUNCH_CHECK();
+        // dW[cs][k] += sum_q sum_n Ys[n][cs][q] col_q[n][k]
+        int splitk = g.N >= 512 ? 4 : 1;
+        return jvae_gemm_launch(g.Cs, Kd, g.N, Ps, ys, Ps, (long)g.Cs * Ps, 1, ws, Kd, 1, (long)g.N * Kd,
+                                dw, Kd, 1, 0, nullptr, 0, 4, splitk, st);
+    }
+    const int chunk = chunk_images(g, ws_bytes);
+    if (chunk < 1) return JVAE_EWORKSPACE;
+    for (int n0 = 0; n0 < g.N; n0 += chunk) {
+        const int ni = (g.N - n0 < chunk) ? g.N - n0 : chunk;
+        hipLaunchKernelGGL(unfold_kernel, dim3(grid_for((long)ni * Kd * Ps)), dim3(256), 0, st, xb, ws, g, n0, ni,
+                           (long)Kd * Ps, (long)Ps, 1L, 0);
+        JVAE_LAUNCH_CHECK();
+        int rc = jvae_gemm_launch(g.Cs, Kd, Ps, ni, ys + (long)n0 * g.Cs * Ps, Ps, 1, (long)g.Cs * Ps,
+                                  ws, 1, Ps, (long)Kd * Ps, dw, Kd, 1, 0, nullptr, 0, 4, 1, st);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+int jvae_channel_sum(const float* t, float* out, int N, int C, int P, int accumulate, hipStream_t st) {
+    if (C <= 0) return 0;
+    hipLaunchKernelGGL(channel_sum_kernel, dim3(C), dim3(256), 0, st, t, out, N, C, P, accumulate);
+    JVAE_LAUNCH_CHECK();
+    return 0;
+}

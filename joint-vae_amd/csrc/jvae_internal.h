@@ -1,0 +1,21 @@
+// Internal (non-ABI) declarations shared between the translation units of libjvae_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+// C[b](m,n) (+)= sum_k A[b](m,k) B[b](k,n); element strides in floats.  flags: 1 accumulate, 2 ReLU.
+// splitk > 1 adds partial products with float atomics: C must then hold the value to accumulate onto
+// (zeros for a plain product).  bias_mode: 0 none, 1 per-n, 2 per-m.
+int jvae_gemm_launch(int M, int N, int K, int batch,
+                     const float* A, long sAm, long sAk, long sAb,
+                     const float* B, long sBk, long sBn, long sBb,
+                     float* C, long sCm, long sCn, long sCb,
+                     const float* bias, int bias_mode, int flags, int splitk, hipStream_t st);
+
+// Geometry of one (transposed) convolution.  "big" side = the tensor that is unfolded (conv input /
+// transposed-conv output), "small" side = the tensor on the folded grid (conv output / transposed-conv input).
+struct ConvGeom {
+    int N;            // images
+    int Cb, Hb, Wb;   // big side:   channels, height, width
+    int Cs, Hs, Ws;   // small side: channels, height, width
+    int KH, KW, S, P; // kernel, stride, padding (as in nn.Conv2d / nn.ConvTranspose2d)
+};

@@ -1,0 +1,476 @@
+"""MI355X-native joint / class-conditional VAE: drop-in for the reference's `cvae.ClassificationVariationalNetwork`.
+
+Scope: the per-batch training step of the reference (cvae.py:2424-2479) —
+features -> encoder -> (mu, log sigma^2) -> reparameterised z -> decoder / imager -> ELBO terms -> backward ->
+clip -> Adam — executed by hand-written gfx950 HIP kernels (libjvae_hip.so) behind the same Python API:
+
+    ClassificationVariationalNetwork(input_shape, num_labels, type, ..., sigma, optimizer, ...)   cvae.py:135-167
+    .forward(x, y=None, x_features=None, z_output=True, sampling_epsilon_norm_out=False, sigma_out=False)  :426-521
+    .evaluate(x, y, batch, current_measures, with_beta, kl_var_weighting, gamma_weighting, z_output)       :523-917
+    .train_model(...)   (hot loop :2424-2479; test / OOD phases are out of scope)                            :2081-2547
+    .train() / .to() / .save() / .load() / .latent_sampling / .device / .nparams
+
+What is NOT rebuilt here (raises NotImplementedError when asked for): types other than 'cvae'; pooling /
+up-sampling / resnet feature stacks; dropout; coded, per-dimension or rmse sigma; categorical output;
+accuracy / OOD / misclassification evaluation (`y=None` all-class evaluate lives in SURVEY §8f-1).
+There is no CPU path: calling forward/evaluate with CPU tensors raises.
+"""
+import json
+import logging
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+from torch import nn
+
+from jvae_hip import ops
+from module.optimizers import Optimizer
+from module.losses import x_loss, mse_loss, categorical_loss  # noqa: F401  (import surface of the reference)
+from module.vae_layers import Encoder, Classifier, Sigma, build_de_conv_layers, find_input_shape
+from module.vae_layers import onehot_encoding, activation_layers
+from module.vae_layers.layers import HipLinear, DenseStack
+
+DEFAULT_ACTIVATION = 'relu'
+DEFAULT_OUTPUT_ACTIVATION = 'linear'
+DEFAULT_LATENT_SAMPLING = 100
+VERSION = 2.
+LOG2PI = math.log(2 * math.pi)
+
+
+class ClassificationVariationalNetwork(nn.Module):
+    r"""X -- features -- encoder -- Z -- decoder -- imager -- X^   with a class-conditional prior p(z|y)
+    (and a classifier head on z when gamma > 0)."""
+
+    loss_components_per_type = {'cvae': ('cross_x', 'kl', 'total', 'zdist', 'var_kl', 'dzdist', 'iws',
+                                         'sigma', 'wmse', 'z_logdet', 'z_tr_inv_cov')}
+    predict_methods_per_type = {'cvae': ['iws', 'closest']}
+    metrics_per_type = {'cvae': ['rmse', 'dB', 'd-mind', 'ld-norm', 'sigma']}
+    ood_methods_per_type = {'cvae': ['iws-2s', 'iws-a-1-1', 'iws-a-4-1', 'iws', 'mse', 'elbo', 'soft',
+                                     'elbo-2s', 'elbo-a-1-1', 'elbo-a-4-1', 'zdist']}
+    misclass_methods_per_type = {'cvae': ['softkl*', 'iws', 'softiws*', 'kl', 'max', 'zdist', 'softzdist*',
+                                          'baseline*', 'hyz']}
+
+    def __init__(self, input_shape, num_labels, type='cvae', y_is_coded=False, output_distribution='gaussian',
+                 job_number=0, features=None, pretrained_features=None, batch_norm=False, dropout=False,
+                 encoder=[36], latent_dim=32, prior={}, beta=1., gamma=0., decoder=[36], upsampler=None,
+                 pretrained_upsampler=None, classifier=[36], name='joint-vae', activation=DEFAULT_ACTIVATION,
+                 latent_sampling=DEFAULT_LATENT_SAMPLING, test_latent_sampling=None,
+                 encoder_forced_variance=False, output_activation=DEFAULT_OUTPUT_ACTIVATION, sigma={'value': 1},
+                 optimizer={}, shadow=False, representation='rgb', version=VERSION, *args, **kw):
+        super().__init__(*args, **kw)
+        if type != 'cvae':
+            raise NotImplementedError("only type='cvae' is built on the native kernels (got {!r})".format(type))
+        if output_distribution != 'gaussian':
+            raise NotImplementedError('categorical output is outside the native-kernel contract')
+        if dropout:
+            raise NotImplementedError('dropout is outside the native-kernel contract')
+        assert not upsampler or features, 'no upsampler without features'
+
+        self.name = name
+        self.job_number = job_number
+        self.type = type
+        self.is_cvae, self.is_jvae, self.is_vib, self.is_vae, self.is_xvae = True, False, False, False, False
+        self.loss_components = self.loss_components_per_type[type]
+        self.metrics = self.metrics_per_type[type]
+        self.predict_methods = list(self.predict_methods_per_type[type])
+        self.ood_methods = list(self.ood_methods_per_type[type])
+        self.misclass_methods = list(self.misclass_methods_per_type[type])
+        self.y_is_coded = y_is_coded
+        self.y_is_decoded = gamma                 # cvae: the classifier enters the loss iff gamma
+        self.x_is_generated = True
+        self.output_distribution = output_distribution
+        self.losses_might_be_computed_for_each_class = True
+
+        if self.y_is_decoded:
+            self.classifier_type = 'linear'
+            if classifier and isinstance(classifier[0], str):
+                assert classifier[0] in ('softmax',)
+                self.classifier_type = classifier[0]
+            if 'esty' not in self.predict_methods:
+                self.predict_methods.append('esty')
+            if 'cross_y' not in self.loss_components:
+                self.loss_components += ('cross_y',)
+        else:
+            self.classifier_type = None
+            classifier = []
+
+        bn_enc = bool(features) and batch_norm in ('encoder', 'both')
+        bn_dec = bool(features) and batch_norm == 'both'
+        if not features:
+            batch_norm = False
+
+        if features:
+            self.features = build_de_conv_layers(input_shape, features, activation=activation, batch_norm=bn_enc,
+                                                 pretrained_dict=pretrained_features)
+            enc_in = self.features.output_shape
+        else:
+            self.features = None
+            enc_in = input_shape
+
+        self.trained = 0
+        if isinstance(sigma, Sigma):
+            self.sigma = sigma
+        elif isinstance(sigma, dict):
+            self.sigma = Sigma(**sigma)
+        else:
+            self.sigma = Sigma(value=sigma)
+        if self.sigma.coded or self.sigma.per_dim or self.sigma.is_rmse:
+            raise NotImplementedError('coded / per-dimension / rmse sigma are outside the native-kernel contract '
+                                      '(fixed, decayed and learned scalar sigma are built)')
+
+        test_latent_sampling = test_latent_sampling or latent_sampling
+        self.beta = beta
+        self.gamma = gamma if self.y_is_decoded else None
+        prior = dict(prior)
+        prior['num_priors'] = num_labels
+        self.encoder = Encoder(enc_in, num_labels, intermediate_dims=encoder, latent_dim=latent_dim,
+                               y_is_coded=self.y_is_coded, dropout=dropout, sigma_output_dim=0,
+                               forced_variance=encoder_forced_variance, sampling_size=latent_sampling, prior=prior,
+                               activation=activation, sampling=latent_sampling > 1 or beta > 0)
+
+        dense, width = [], latent_dim
+        shared_act = activation_layers[activation]()
+        for d in decoder:
+            dense += [HipLinear(width, d), shared_act]
+            width = d
+        self.decoder = DenseStack(*dense)
+        if upsampler:
+            hw = find_input_shape(upsampler, input_shape[1:])
+            cells = hw[0] * hw[1]
+            assert not width % cells, 'Could not go from {} to *, {} {}'.format(width, *hw)
+            self.imager = build_de_conv_layers((width // cells, *hw), upsampler, batch_norm=bn_dec,
+                                               activation=activation, output_activation=output_activation,
+                                               output_distribution=self.output_distribution,
+                                               pretrained_dict=pretrained_upsampler, where='output')
+        else:
+            upsampler = None
+            self.imager = DenseStack(HipLinear(width, int(np.prod(input_shape))),
+                                     activation_layers[output_activation]())
+            self.imager.input_shape = (width,)
+
+        if self.classifier_type in ('linear', None):
+            self.classifier = Classifier(latent_dim, num_labels, classifier, activation=activation)
+
+        self.input_shape = tuple(input_shape)
+        self.num_labels = num_labels
+        self.input_dim = len(input_shape)
+        self.batch_norm = batch_norm
+        self.dropout = dropout
+        self._sizes_of_layers = [input_shape, num_labels, encoder, latent_dim, decoder, upsampler, classifier]
+        self.architecture = {'input_shape': input_shape, 'num_labels': num_labels,
+                             'output_distribution': self.output_distribution, 'type': type,
+                             'representation': representation, 'encoder': encoder, 'batch_norm': batch_norm,
+                             'dropout': dropout, 'activation': activation,
+                             'encoder_forced_variance': self.encoder.forced_variance, 'latent_dim': latent_dim,
+                             'test_latent_sampling': test_latent_sampling, 'prior': self.encoder.prior.params,
+                             'decoder': decoder, 'upsampler': upsampler, 'classifier': classifier,
+                             'output_activation': output_activation, 'version': VERSION}
+        if features:
+            self.architecture['features'] = self.features.name
+        linear_clf = self.classifier_type == 'linear'
+        self.depth = (len(encoder) + len(decoder) + len(classifier)) if linear_clf else 0
+        self.width = (sum(encoder) + sum(decoder) + sum(classifier)) if linear_clf else 0
+
+        self.training_parameters = {'sigma': self.sigma.params, 'beta': self.beta, 'gamma': self.gamma,
+                                    'latent_sampling': latent_sampling, 'set': None, 'data_augmentation': [],
+                                    'pretrained_features': getattr(pretrained_features, 'name', None),
+                                    'pretrained_upsampler': getattr(pretrained_upsampler, 'name', None),
+                                    'epochs': 0, 'batch_size': None, 'fine_tuning': []}
+        self.testing = {0: {m: {'n': 0, 'epochs': 0, 'accuracy': 0} for m in self.predict_methods}}
+        self.ood_results = {}
+        self.optimizer = Optimizer(self.parameters(), **optimizer)
+        self.training_parameters['optimizer'] = self.optimizer.params
+        self.train_history = {'epochs': 0}
+
+        self.latent_dim = latent_dim
+        self._latent_samplings = {'train': latent_sampling, 'eval': test_latent_sampling}
+        self.latent_sampling = latent_sampling
+        self.encoder_layer_sizes, self.decoder_layer_sizes, self.classifier_layer_sizes = encoder, decoder, classifier
+        self.upsampler = upsampler
+        self.activation = activation
+        self.output_activation = output_activation
+        self.z_output = False
+        self._host_cache = {}
+        self.eval()
+
+    # ------------------------------------------------------------------------------------ module state
+    def train(self, *a, **k):
+        super().train(*a, **k)
+        self.latent_sampling = self._latent_samplings['train' if self.training else 'eval']
+        return self
+
+    @property
+    def latent_sampling(self):
+        return self._latent_sampling
+
+    @latent_sampling.setter
+    def latent_sampling(self, v):
+        self._latent_sampling = v
+        self.encoder.sampling_size = v
+
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    @device.setter
+    def device(self, d):
+        self.to(d)
+
+    def to(self, d):
+        super().to(d)
+        self.optimizer.to(d)
+        return self
+
+    @property
+    def nparams(self):
+        return sum(p.nelement() for p in self.parameters())
+
+    @property
+    def max_batch_sizes(self):
+        """The reference hard-wires {'train': 32, 'test': 32} (cvae.py:1145-1147); with 288 GB of
+        HBM the honest bound is far beyond any batch this model is trained with."""
+        return {'train': 1 << 16, 'test': 1 << 16}
+
+    # ------------------------------------------------------------------------------------ forward
+    def _features_of(self, x):
+        if not self.features:
+            return x
+        lead = (1,) if x.dim() == self.input_dim else x.shape[:-self.input_dim]
+        t = self.features(x.reshape(-1, *self.input_shape))
+        return t.view(*lead, *self.encoder.input_shape)
+
+    def forward(self, x, y=None, x_features=None, **kw):
+        """x (N1..Ng, D1..Dt), y (N1..Ng) -> (x_reco (L+1, N.., D..), logits (L+1, N.., C)[, mu, log_var, z]...)."""
+        if y is None and self.y_is_coded:
+            raise ValueError('y is supposed to be an input of the net')
+        lead = (1,) if x.dim() == self.input_dim else x.shape[:-self.input_dim]
+        if x_features is None:
+            x_features = self._features_of(x)
+        return self.forward_from_features(x_features, None if y is None else y.view(*lead), x, **kw)
+
+    def _decode(self, z):
+        u = self.decoder(z)
+        x_ = self.imager(u.reshape(-1, *self.imager.input_shape))
+        if self.classifier_type in ('linear', None):
+            logits = self.classifier(z)
+        else:                                   # 'softmax': logits from the dictionary itself (cvae.py:498-499)
+            m = self.encoder.prior.mean
+            logits = ops.linear(z, m, m.pow(2).sum(-1) / 2)
+        return x_, logits
+
+    def forward_from_features(self, x_features, y, x, z_output=True, sampling_epsilon_norm_out=False,
+                              sigma_out=False, epsilon=None):
+        lead = x_features.shape[:x_features.dim() - len(self.encoder.input_shape)]
+        flat = x_features.reshape(*lead, -1)
+        y1h = None if (y is None or not self.y_is_coded) else onehot_encoding(y, self.num_labels).float()
+        mu, log_var, z, eps, sigma = self.encoder(flat, y1h, epsilon=epsilon)
+        x_, logits = self._decode(z)
+        out = (x_.view(self.latent_sampling + 1, *lead, *self.input_shape), logits)
+        if z_output:
+            out += (mu, log_var, z)
+        if sampling_epsilon_norm_out:
+            out += ((eps ** 2).sum(-1),)
+        if sigma_out:
+            out += (sigma,)
+        return out
+
+    # ------------------------------------------------------------------------------------ evaluate
+    def evaluate(self, x, y=None, batch=0, current_measures=None, with_beta=False, kl_var_weighting=1.,
+                 gamma_weighting=1, z_output=False, epsilon=None, **kw):
+        """Forward + every per-sample loss term of one batch (training branch of cvae.py:523-917).
+
+        Returns (x_reco (L+1,N,..), y_est (N,C), batch_losses {name: (N,) tensor}, total_measures {name: float}
+        [, mu, log_var, z]).  `epsilon` (L+1,N,K) optionally injects the reparameterisation noise.
+        All Python floats of `total_measures` come from ONE packed device read-back.
+        """
+        if y is None:
+            raise NotImplementedError('all-class evaluation (y=None: accuracy / OOD scoring, SURVEY.md §8f-1) is not '
+                                      'part of this build; the training step always provides y')
+        if x.dim() != self.input_dim + 1:
+            x = x.reshape(-1, *self.input_shape)
+            y = y.reshape(-1)
+        N = x.shape[0]
+        L = self.latent_sampling
+        D = int(np.prod(self.input_shape))
+        cross_y_weight = (gamma_weighting * self.gamma if self.training else False) if self.y_is_decoded else False
+
+        feats = self._features_of(x).reshape(N, -1)
+        y1h = onehot_encoding(y, self.num_labels).float() if self.y_is_coded else None
+        mu, log_var, z, eps, _, terms = self.encoder.encode(feats, y1h, y, kl_var_weighting, epsilon)
+        x_, logits = self._decode(z)
+        x_reco = x_.view(L + 1, N, *self.input_shape)
+
+        s = self.sigma
+        wmse_s = ops.recon_wmse(x_reco, x, s, s.is_log)                     # (L, N)
+        wmse = wmse_s.mean(0)
+        log_sigma = s.squeeze() if s.is_log else s.log().squeeze()
+        sigma2 = (2 * s).exp() if s.is_log else s ** 2
+        mse = wmse * sigma2
+
+        losses = {'kl': terms['kl'], 'zdist': terms['distance'], 'var_kl': terms['var_kl']}
+        dictionary = self.encoder.prior.mean if self.encoder.prior.conditional else None
+        if dictionary is not None:
+            losses['dzdist'] = terms['dzdist']
+        losses['wmse'] = wmse
+        losses['cross_x'] = D * (2 * log_sigma + wmse + LOG2PI) / 2          # sigma_dims = 1 (scalar sigma)
+        total = losses['cross_x']
+        if self.y_is_decoded:
+            losses['cross_y'] = x_loss(y, logits, batch_mean=False)          # all L+1 rows, as cvae.py:738 does
+            if cross_y_weight:
+                total = total + cross_y_weight * losses['cross_y']
+        total = total + (self.beta if with_beta else 1.) * losses['kl']
+        losses['total'] = total
+        if self.training:
+            self.sigma.update(rmse=mse.detach().mean().sqrt())
+
+        measures = self._measures(x, mse, terms, dictionary, batch, current_measures)
+        if self.training:
+            self.training_parameters['sigma'] = self.sigma.host_params(measures['sigma'])
+        out = (x_reco, logits[1:].mean(0), losses, measures)
+        if z_output:
+            out += (mu, log_var, z)
+        return out
+
+    def _measures(self, x, mse, terms, dictionary, batch, current):
+        """Running means as Python floats (cvae.py:619-624,689-724,755-762) from one device->host copy."""
+        if not current:
+            current = {k: 0. for k in ('xpow', 'mse', 'dB', 'imut-zy', 'd-mind', 'ld-norm', 'var_kl', 'zdist')}
+        with torch.no_grad():
+            s = self.sigma.detach()
+            vals = [((2 * s).exp() if self.sigma.is_log else s.pow(2)).mean().sqrt(),
+                    x.pow(2).mean(), mse.mean(), terms['distance'].mean(), terms['var_kl'].mean()]
+            if dictionary is not None:
+                vals += [dictionary.pow(2).mean(), self.encoder.capacity(), self.encoder.dict_min_distance()]
+            flag = self.optimizer.nonfinite_flag()
+            if flag is not None:
+                vals.append(flag.float().squeeze())
+            host = torch.stack([v.reshape(()) for v in vals]).tolist()
+        if flag is not None and host[-1] != 0:
+            print('GRAD NAN')                       # cvae.py:2454-2457 (reported one step later: no extra sync)
+            sys.exit(1)
+        m = {'sigma': host[0]}
+
+        def run(key, v):
+            return (current[key] * batch + v) / (batch + 1)
+        m['xpow'] = run('xpow', host[1])
+        m['mse'] = run('mse', host[2])
+        m['rmse'] = math.sqrt(m['mse'])
+        m['dB'] = 10 * math.log10(m['xpow'] / m['mse'])
+        m['zdist'] = run('zdist', host[3])
+        m['var_kl'] = run('var_kl', host[4])
+        if dictionary is not None:
+            m['ld-norm'], m['imut-zy'], m['d-mind'] = host[5], host[6], host[7]
+        return m
+
+    # ------------------------------------------------------------------------------------ training loop
+    def train_step(self, x, y, batch=0, current_measures=None, kl_var_weighting=1., gamma_weighting=1., epsilon=None):
+        """One iteration of the reference's hot loop (cvae.py:2429-2461): zero_grad, evaluate, backward, clip, step."""
+        self.optimizer.zero_grad()
+        _, y_est, losses, measures = self.evaluate(x, y, batch=batch, with_beta=True,
+                                                   kl_var_weighting=kl_var_weighting,
+                                                   gamma_weighting=gamma_weighting,
+                                                   current_measures=current_measures, epsilon=epsilon)
+        losses['total'].mean().backward()
+        self.optimizer.clip(self.parameters())
+        self.optimizer.step()
+        return losses, measures
+
+    def train_model(self, trainset=None, transformer='default', data_augmentation=[], optimizer=None, epochs=50,
+                    batch_size=100, test_batch_size=100, validation=4096, device=None, testset=None, oodsets=None,
+                    acc_methods=None, fine_tuning=False, warmup=[0, 0], warmup_gamma=[0, 0], latent_sampling=None,
+                    validation_sample_size=1024, full_test_every=10, ood_detection_every=10, train_accuracy=False,
+                    save_dir=None, outputs=None, signal_handler=None):
+        """Training loop with the reference's signature (cvae.py:2081-2104).  `trainset` is any map-style dataset of
+        (x in [0,1] float tensor, int label); the periodic accuracy / OOD phases of the reference are out of
+        scope and skipped."""
+        if isinstance(trainset, str):
+            raise NotImplementedError('named torchvision datasets are host-side plumbing outside this build: '
+                                      'pass a torch.utils.data.Dataset')
+        optimizer = optimizer or self.optimizer
+        if latent_sampling:
+            self._latent_samplings['train'] = latent_sampling
+        device = device or self.device
+        self.training_parameters.update({'batch_size': batch_size, 'warmup': list(warmup),
+                                         'warmup_gamma': list(warmup_gamma), 'full_test_every': full_test_every})
+        loader = torch.utils.data.DataLoader(trainset, batch_size=batch_size, shuffle=True, num_workers=0)
+        done = self.trained
+        sig = signal_handler
+        for epoch in range(done, epochs):
+            if sig is not None and getattr(sig, 'sig', 0) > 2:
+                logging.warning('Breaking training loop bc of signal %s after %d epochs', sig, epoch)
+                break
+            self.encoder.prior.thaw_means(epoch)
+            self.train()
+            w_kl = max(0., min(1., (epoch + 1 - warmup[0]) / (warmup[1] + 1)))
+            w_gamma = max(0., min(1., (epoch + 1 - warmup_gamma[0]) / (warmup_gamma[1] + 1)))
+            t0 = time.time()
+            measures, sums, nb = None, {}, 0
+            for i, (x, y) in enumerate(loader):
+                x, y = x.to(device), y.to(device)
+                losses, measures = self.train_step(x, y, batch=i, current_measures=measures,
+                                                   kl_var_weighting=w_kl, gamma_weighting=w_gamma)
+                for k, v in losses.items():
+                    sums[k] = v.detach().mean() + sums.get(k, 0.)
+                nb = i + 1
+                if outputs is not None and hasattr(outputs, 'results'):
+                    outputs.results(i, len(loader), epoch + 1, epochs, preambule='train',
+                                    losses={k: float('nan') for k in self.loss_components},
+                                    metrics={k: measures[k] for k in self.metrics},
+                                    accuracy={k: np.nan for k in self.predict_methods},
+                                    time_per_i=(time.time() - t0) / (i + 1), batch_size=batch_size, end_of_epoch='\n')
+            self.eval()
+            mean_loss = {k: (v / max(nb, 1)).item() for k, v in sums.items()}
+            self.train_history[epoch] = {'train_loss': mean_loss, 'train_measures': dict(measures or {}),
+                                         'lr': self.optimizer.lr}
+            self.train_history['epochs'] += 1
+            self.trained += 1
+            if fine_tuning:
+                self.training_parameters['fine_tuning'].append(epoch)
+            optimizer.update_lr()
+            if save_dir:
+                self.save(save_dir)
+        return self.train_history
+
+    # ------------------------------------------------------------------------------------ persistence
+    def save(self, dir_name=None):
+        """params.json / train_params.json / history.json + state.pth + optimizer.pth (cvae.py:2650-2675)."""
+        dir_name = dir_name or getattr(self, 'saved_dir', None)
+        os.makedirs(dir_name, exist_ok=True)
+        tp = dict(self.training_parameters)
+        tp['sigma'] = self.sigma.params
+
+        def dump(obj, name):
+            with open(os.path.join(dir_name, name), 'w') as f:
+                json.dump(obj, f, default=str)
+        dump(self.architecture, 'params.json')
+        dump(tp, 'train_params.json')
+        dump(self.train_history, 'history.json')
+        torch.save(self.state_dict(), os.path.join(dir_name, 'state.pth'))
+        torch.save(self.optimizer.state_dict(), os.path.join(dir_name, 'optimizer.pth'))
+        self.saved_dir = dir_name
+        return dir_name
+
+    def load_weights(self, dir_name, strict=True, with_optimizer=True):
+        """Load state.pth (+ optimizer.pth) written by save() of this class or of the reference."""
+        state = torch.load(os.path.join(dir_name, 'state.pth'), map_location=self.device)
+        with torch.no_grad():
+            mine = self.state_dict()
+            for k, v in state.items():
+                if k in mine:
+                    mine[k].copy_(v)
+                elif strict:
+                    raise KeyError(k)
+        opt = os.path.join(dir_name, 'optimizer.pth')
+        if with_optimizer and os.path.exists(opt):
+            self.optimizer.load_state_dict(torch.load(opt, map_location=self.device))
+        return self
+
+    def print_architecture(self, *a, **kw):
+        arch = self.architecture
+        return '{type} K={latent_dim} features={f} upsampler={upsampler}'.format(f=arch.get('features'), **arch)
+
+    def print_training(self, *a, **kw):
+        return 'sigma={} optimizer={}'.format(self.sigma, self.optimizer)

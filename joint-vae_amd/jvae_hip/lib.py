@@ -1,0 +1,104 @@
+"""ctypes binding of libjvae_hip.so (C ABI: include/jvae_hip.h).
+
+There is NO fallback: if the shared library is missing or a tensor is not resident on an AMD GPU every
+op raises.  The library is built in-tree by `__graft_entry__.build()` / `make -C joint-vae_amd/csrc`.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_long, c_size_t, c_void_p, POINTER
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libjvae_hip.so')
+
+_lib = None
+
+P = c_void_p
+_SIGS = {
+    'jvae_version': (c_char_p, []),
+    'jvae_gemm_f32': (c_int, [c_int] * 4 + [P, c_long, c_long, c_long] * 3 + [P, c_int, c_int, c_int, P]),
+    'jvae_conv2d_workspace_bytes': (c_size_t, [c_int] * 11),
+    'jvae_conv2d_out_shape': (c_int, [c_int] * 8 + [POINTER(c_int), POINTER(c_int)]),
+    'jvae_conv2d_fwd_f32': (c_int, [P, P, P, P] + [c_int] * 11 + [P, c_size_t, P]),
+    'jvae_conv2d_dgrad_f32': (c_int, [P, P, P] + [c_int] * 11 + [P, c_size_t, P]),
+    'jvae_conv2d_wgrad_f32': (c_int, [P, P, P, P, c_int] + [c_int] * 11 + [P, c_size_t, P]),
+    'jvae_channel_sum_f32': (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    'jvae_bn_workspace_bytes': (c_size_t, [c_int]),
+    'jvae_bn_fwd_f32': (c_int, [P] * 9 + [c_int, c_int, c_int, c_float, c_float, c_int, c_int, P, c_size_t, P]),
+    'jvae_bn_bwd_f32': (c_int, [P] * 9 + [c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),
+    'jvae_act_fwd_f32': (c_int, [P, P, c_long, c_int, P]),
+    'jvae_act_bwd_f32': (c_int, [P, P, P, c_long, c_int, P]),
+    'jvae_dict_stats_f32': (c_int, [P, P, c_int, c_int, P]),
+    'jvae_latent_fwd_f32': (c_int, [P] * 13 + [c_int] * 6 + [c_float] * 3 + [c_int, c_int, c_float, P]),
+    'jvae_latent_bwd_f32': (c_int, [P] * 17 + [c_int] * 6 + [c_float] * 3 + [c_int, c_int, P, c_size_t, P]),
+    'jvae_recon_fwd_f32': (c_int, [P, P, P, c_int, P, c_int, c_int, c_int, P]),
+    'jvae_recon_bwd_f32': (c_int, [P, P, P, c_int, P, P, P, P, c_int, c_int, c_int, c_int, P, c_size_t, P]),
+    'jvae_xent_fwd_f32': (c_int, [P, P, P, c_int, c_int, c_int, P]),
+    'jvae_xent_bwd_f32': (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
+    'jvae_sqnorm_accum_f32': (c_int, [P, c_long, P, c_int, P]),
+    'jvae_clip_scale_f32': (c_int, [P, c_long, P, c_float, P]),
+    'jvae_adam_step_f32': (c_int, [P, P, P, P, c_long] + [c_float] * 5 + [c_long, c_float, P, P, P]),
+}
+
+
+class JvaeHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and return the ctypes handle; raises JvaeHipError when the library is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise JvaeHipError(f'{LIB_PATH} is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                           'or `make -C joint-vae_amd/csrc` (there is no CPU/PyTorch fallback)')
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)            # AttributeError here = header / library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def exported_symbols():
+    return list(_SIGS)
+
+
+_ERR = {-1: 'invalid argument', -2: 'unsupported configuration', -3: 'workspace too small'}
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = _ERR.get(rc, f'hipError_t {rc}')
+        raise JvaeHipError(f'{what} failed: {msg}')
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    """Device pointer of a dense fp32/int64 CUDA tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise JvaeHipError('jvae_hip ops need tensors resident on the GPU (no CPU fallback); got device '
+                           + str(t.device))
+    if not t.is_contiguous():
+        raise JvaeHipError('jvae_hip ops need contiguous tensors')
+    return t.data_ptr()
+
+
+_workspaces = {}
+
+
+def workspace(nbytes, device):
+    """Stream-ordered scratch shared by all ops of one device (grown on demand, never shrunk)."""
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        _workspaces[key] = ws = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+    return ws

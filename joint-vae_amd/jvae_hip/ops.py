@@ -1,0 +1,415 @@
+"""Autograd-aware wrappers around the HIP kernels of libjvae_hip.so.
+
+PyTorch is plumbing here (device memory, streams, the autograd tape); every FLOP of the training step is
+executed by the hand-written gfx950 kernels.  Every function raises if its tensors are not on the GPU.
+"""
+import math
+from ctypes import byref, c_int
+
+import torch
+
+from . import lib as L
+
+RELU, SIGMOID, IDENT = 1, 2, 0
+ACT_KIND = {'relu': RELU, 'sigmoid': SIGMOID, 'linear': IDENT, None: IDENT}
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _f32(t, what):
+    if t.dtype != torch.float32:
+        raise L.JvaeHipError(f'{what}: fp32 expected, got {t.dtype}')
+    return t
+
+
+# ------------------------------------------------------------------------------------------- gemm
+def gemm(M, N, K, A, sA, B, sB, C, sC, bias=None, bias_mode=0, flags=0, splitk=1, batch=1):
+    """Raw strided product on the current stream.  sA = (sAm, sAk, sAb) etc. (elements)."""
+    lib = L.load()
+    rc = lib.jvae_gemm_f32(M, N, K, batch, L.ptr(A), *sA, L.ptr(B), *sB, L.ptr(C), *sC,
+                           L.ptr(bias), bias_mode, flags, splitk, L.stream_ptr())
+    L.check(rc, 'jvae_gemm_f32')
+
+
+def channel_sum(t, N, C, P, out=None, accumulate=False):
+    lib = L.load()
+    if out is None:
+        out = torch.empty(C, device=t.device, dtype=torch.float32)
+    L.check(lib.jvae_channel_sum_f32(L.ptr(t), L.ptr(out), N, C, P, int(accumulate), L.stream_ptr()), 'channel_sum')
+    return out
+
+
+class _Linear(torch.autograd.Function):
+    """y = x W^T + b (+ReLU / sigmoid).  nn.Linear + activation, layers.py:283-296, cvae.py:291-301."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, act):
+        x2 = _c(_f32(x, 'linear').reshape(-1, x.shape[-1]))
+        w = _c(w)
+        R, I = x2.shape
+        O = w.shape[0]
+        y = torch.empty((R, O), device=x.device, dtype=torch.float32)
+        gemm(R, O, I, x2, (I, 1, 0), w, (1, I, 0), y, (O, 1, 0), bias=b, bias_mode=1 if b is not None else 0,
+             flags=2 if act == RELU else 0)
+        if act == SIGMOID:
+            L.check(L.load().jvae_act_fwd_f32(L.ptr(y), L.ptr(y), y.numel(), SIGMOID, L.stream_ptr()), 'act_fwd')
+        ctx.save_for_backward(x2, w, y if act != IDENT else None)
+        ctx.act = act
+        ctx.has_bias = b is not None
+        ctx.xshape = x.shape
+        return y.reshape(*x.shape[:-1], O)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, w, y = ctx.saved_tensors
+        lib = L.load()
+        R, I = x2.shape
+        O = w.shape[0]
+        gy = _c(gy.reshape(R, O))
+        if ctx.act != IDENT:
+            g = torch.empty_like(gy)
+            L.check(lib.jvae_act_bwd_f32(L.ptr(gy), L.ptr(y), L.ptr(g), gy.numel(), ctx.act, L.stream_ptr()), 'act_bwd')
+            gy = g
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty((R, I), device=gy.device, dtype=torch.float32)
+            gemm(R, I, O, gy, (O, 1, 0), w, (I, 1, 0), gx, (I, 1, 0))
+            gx = gx.reshape(ctx.xshape)
+        if ctx.needs_input_grad[1]:
+            gw = torch.zeros((O, I), device=gy.device, dtype=torch.float32)
+            tiles = ((O + 63) // 64) * ((I + 63) // 64)
+            splitk = max(1, min(R // 64, 256 // max(tiles, 1)))
+            gemm(O, I, R, gy, (1, O, 0), x2, (I, 1, 0), gw, (I, 1, 0), splitk=splitk)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = channel_sum(gy, R, O, 1)
+        return gx, gw, gb, None
+
+
+def linear(x, w, b=None, act=IDENT):
+    return _Linear.apply(x, w, b, act)
+
+
+# ------------------------------------------------------------------------------------------- conv
+class ConvSpec:
+    __slots__ = ('cin', 'cout', 'k', 's', 'p', 'op', 'transposed')
+
+    def __init__(self, cin, cout, k, s, p, op=0, transposed=False):
+        self.cin, self.cout, self.k, self.s, self.p, self.op, self.transposed = cin, cout, k, s, p, op, bool(transposed)
+
+    def out_hw(self, H, W):
+        oh, ow = c_int(), c_int()
+        rc = L.load().jvae_conv2d_out_shape(H, W, self.k, self.k, self.s, self.p, self.op, int(self.transposed),
+                                            byref(oh), byref(ow))
+        L.check(rc, 'jvae_conv2d_out_shape')
+        return oh.value, ow.value
+
+    def geom(self, N, H, W):
+        return (N, self.cin, H, W, self.cout, self.k, self.k, self.s, self.p, self.op, int(self.transposed))
+
+
+def _conv_ws(geom, device):
+    nbytes = L.load().jvae_conv2d_workspace_bytes(*geom)
+    ws = L.workspace(nbytes, device)
+    return ws, ws.numel()
+
+
+def conv_fwd_raw(x, w, b, spec):
+    N, _, H, W = x.shape
+    oh, ow = spec.out_hw(H, W)
+    y = torch.empty((N, spec.cout, oh, ow), device=x.device, dtype=torch.float32)
+    geom = spec.geom(N, H, W)
+    ws, nb = _conv_ws(geom, x.device)
+    rc = L.load().jvae_conv2d_fwd_f32(L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(y), *geom, L.ptr(ws), nb, L.stream_ptr())
+    L.check(rc, 'jvae_conv2d_fwd_f32')
+    return y
+
+
+def conv_dgrad_raw(gy, w, spec, xshape):
+    N, _, H, W = xshape
+    gx = torch.empty(xshape, device=gy.device, dtype=torch.float32)
+    geom = spec.geom(N, H, W)
+    ws, nb = _conv_ws(geom, gy.device)
+    rc = L.load().jvae_conv2d_dgrad_f32(L.ptr(gy), L.ptr(w), L.ptr(gx), *geom, L.ptr(ws), nb, L.stream_ptr())
+    L.check(rc, 'jvae_conv2d_dgrad_f32')
+    return gx
+
+
+def conv_wgrad_raw(x, gy, spec, wshape, want_bias):
+    N, _, H, W = x.shape
+    gw = torch.empty(wshape, device=x.device, dtype=torch.float32)
+    gb = torch.empty(spec.cout, device=x.device, dtype=torch.float32) if want_bias else None
+    geom = spec.geom(N, H, W)
+    ws, nb = _conv_ws(geom, x.device)
+    rc = L.load().jvae_conv2d_wgrad_f32(L.ptr(x), L.ptr(gy), L.ptr(gw), L.ptr(gb), 0, *geom, L.ptr(ws), nb,
+                                        L.stream_ptr())
+    L.check(rc, 'jvae_conv2d_wgrad_f32')
+    return gw, gb
+
+
+class _Conv(torch.autograd.Function):
+    """nn.Conv2d / nn.ConvTranspose2d (conv.py:186-196)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, spec):
+        x = _c(_f32(x, 'conv'))
+        w = _c(w)
+        y = conv_fwd_raw(x, w, b, spec)
+        ctx.save_for_backward(x, w)
+        ctx.spec = spec
+        ctx.has_bias = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gy = _c(gy)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = conv_dgrad_raw(gy, w, ctx.spec, x.shape)
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            gw, gb = conv_wgrad_raw(x, gy, ctx.spec, w.shape, ctx.has_bias and ctx.needs_input_grad[2])
+        return gx, gw, gb, None
+
+
+def conv2d(x, w, b, spec):
+    return _Conv.apply(x, w, b, spec)
+
+
+# ------------------------------------------------------------------------------------------- batch norm
+class _BatchNormAct(torch.autograd.Function):
+    """nn.BatchNorm2d (train or eval) + optional ReLU (conv.py:214-220)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, rm, rv, nbt, training, relu, momentum, eps):
+        x = _c(_f32(x, 'batchnorm'))
+        N, C = x.shape[0], x.shape[1]
+        P = x.numel() // max(N * C, 1)
+        lib = L.load()
+        y = torch.empty_like(x)
+        mean = torch.empty(C, device=x.device, dtype=torch.float32)
+        invstd = torch.empty(C, device=x.device, dtype=torch.float32)
+        nb = lib.jvae_bn_workspace_bytes(C)
+        ws = L.workspace(nb, x.device)
+        rc = lib.jvae_bn_fwd_f32(L.ptr(x), L.ptr(gamma), L.ptr(beta), L.ptr(rm), L.ptr(rv), L.ptr(nbt), L.ptr(y),
+                                 L.ptr(mean), L.ptr(invstd), N, C, P, momentum, eps, int(training), int(relu),
+                                 L.ptr(ws), ws.numel(), L.stream_ptr())
+        L.check(rc, 'jvae_bn_fwd_f32')
+        if training:
+            ctx.save_for_backward(x, gamma, beta, mean, invstd)
+            ctx.relu = relu
+            ctx.dims = (N, C, P)
+        else:
+            ctx.dims = None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        if ctx.dims is None:
+            raise L.JvaeHipError('backward through eval-mode BatchNorm is not part of the training step')
+        x, gamma, beta, mean, invstd = ctx.saved_tensors
+        N, C, P = ctx.dims
+        gy = _c(gy)
+        lib = L.load()
+        gx = torch.empty_like(x)
+        gg = torch.empty(C, device=x.device, dtype=torch.float32)
+        gb = torch.empty(C, device=x.device, dtype=torch.float32)
+        nb = lib.jvae_bn_workspace_bytes(C)
+        ws = L.workspace(nb, x.device)
+        rc = lib.jvae_bn_bwd_f32(L.ptr(gy), L.ptr(x), L.ptr(gamma), L.ptr(beta), L.ptr(mean), L.ptr(invstd), L.ptr(gx),
+                                 L.ptr(gg), L.ptr(gb), 0, N, C, P, int(ctx.relu), L.ptr(ws), ws.numel(), L.stream_ptr())
+        L.check(rc, 'jvae_bn_bwd_f32')
+        return gx, gg, gb, None, None, None, None, None, None, None
+
+
+def batchnorm_act(x, gamma, beta, running_mean, running_var, num_batches_tracked, training, relu,
+                  momentum=0.1, eps=1e-5):
+    return _BatchNormAct.apply(x, gamma, beta, running_mean, running_var, num_batches_tracked, training, relu,
+                               momentum, eps)
+
+
+class _Act(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, kind):
+        x = _c(_f32(x, 'act'))
+        y = torch.empty_like(x)
+        L.check(L.load().jvae_act_fwd_f32(L.ptr(x), L.ptr(y), x.numel(), kind, L.stream_ptr()), 'act_fwd')
+        ctx.save_for_backward(y)
+        ctx.kind = kind
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        y, = ctx.saved_tensors
+        gy = _c(gy)
+        gx = torch.empty_like(gy)
+        L.check(L.load().jvae_act_bwd_f32(L.ptr(gy), L.ptr(y), L.ptr(gx), gy.numel(), ctx.kind, L.stream_ptr()), 'act_bwd')
+        return gx, None
+
+
+def act(x, kind):
+    if kind == IDENT:
+        if not x.is_cuda:
+            raise L.JvaeHipError('jvae_hip ops need tensors resident on the GPU (no CPU fallback)')
+        return x
+    return _Act.apply(x, kind)
+
+
+# ------------------------------------------------------------------------------------------- latent
+PRIOR_KIND = {'gaussian': 0, 'tilted': 1, 'uniform': 2}
+VAR_KIND = {'scalar': 0, 'diag': 1, 'full': 2}
+
+
+class _Latent(torch.autograd.Function):
+    """clip + reparameterise + KL terms; see csrc/latent.hip for the reference anchors."""
+
+    @staticmethod
+    def forward(ctx, mu, lv_raw, eps, y, means, T, cfg):
+        lib = L.load()
+        mu = _c(_f32(mu, 'latent'))
+        lv_raw = _c(lv_raw)
+        eps = _c(eps)
+        means = _c(means)
+        T = _c(T)
+        y = _c(y)
+        if y.dtype != torch.int64:
+            raise L.JvaeHipError('class labels must be int64')
+        N, K = mu.shape
+        Ls = eps.shape[0] - 1
+        C = means.shape[0]
+        dev = mu.device
+        dict_ = torch.empty(K + 1, device=dev, dtype=torch.float32)
+        L.check(lib.jvae_dict_stats_f32(L.ptr(means), L.ptr(dict_), C, K, L.stream_ptr()), 'dict_stats')
+        lv = torch.empty_like(mu)
+        z = torch.empty((Ls + 1, N, K), device=dev, dtype=torch.float32)
+        kl, zd, vkl, dzd = (torch.empty(N, device=dev, dtype=torch.float32) for _ in range(4))
+        forced = cfg.get('forced_lv')
+        args = (N, K, Ls, C, cfg['prior'], cfg['var_dim'], cfg['tau'], cfg['alpha'], cfg['w'], int(cfg['sampled']),
+                int(forced is not None))
+        rc = lib.jvae_latent_fwd_f32(L.ptr(mu), L.ptr(lv_raw), L.ptr(eps), L.ptr(y), L.ptr(means), L.ptr(T), L.ptr(dict_),
+                                     L.ptr(lv), L.ptr(z), L.ptr(kl), L.ptr(zd), L.ptr(vkl), L.ptr(dzd),
+                                     *args, float(forced or 0.), L.stream_ptr())
+        L.check(rc, 'jvae_latent_fwd_f32')
+        ctx.save_for_backward(mu, lv_raw, lv, eps, y, means, T)
+        ctx.args = args
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(dzd)
+        return lv, z, kl, zd, vkl, dzd
+
+    @staticmethod
+    def backward(ctx, g_lv, g_z, g_kl, g_zd, g_vkl, _g_dzd):
+        mu, lv_raw, lv, eps, y, means, T = ctx.saved_tensors
+        lib = L.load()
+        N, K, Ls, C, prior, var_dim = ctx.args[:6]
+        dev = mu.device
+        gmu = torch.empty_like(mu)
+        glv = torch.empty_like(mu)
+        need_means = ctx.needs_input_grad[4]
+        need_T = ctx.needs_input_grad[5] and var_dim != 0
+        gmeans = torch.zeros_like(means) if need_means else None
+        gT = torch.zeros_like(T) if need_T else None
+        nb = 8 * N
+        ws = L.workspace(nb, dev)
+
+        def opt(t):
+            return None if t is None else _c(t)
+        rc = lib.jvae_latent_bwd_f32(L.ptr(mu), L.ptr(lv_raw), L.ptr(lv), L.ptr(eps), L.ptr(y), L.ptr(means), L.ptr(T),
+                                     L.ptr(opt(g_z)), L.ptr(opt(g_kl)), L.ptr(opt(g_zd)), L.ptr(opt(g_vkl)),
+                                     None, L.ptr(opt(g_lv)),
+                                     L.ptr(gmu), L.ptr(glv), L.ptr(gmeans), L.ptr(gT),
+                                     *ctx.args, L.ptr(ws), ws.numel(), L.stream_ptr())
+        L.check(rc, 'jvae_latent_bwd_f32')
+        return gmu, glv, None, None, gmeans, gT, None
+
+
+def latent(mu, lv_raw, eps, y, means, T, *, prior='gaussian', var_dim='scalar', tau=0., alpha=0., w=1.,
+           sampled=True, forced_lv=None):
+    """-> (log_var (N,K), z (L+1,N,K), kl, zdist, var_kl, dzdist (N,))"""
+    cfg = dict(prior=PRIOR_KIND[prior], var_dim=VAR_KIND[var_dim], tau=float(tau), alpha=float(alpha), w=float(w),
+               sampled=bool(sampled), forced_lv=forced_lv)
+    return _Latent.apply(mu, lv_raw, eps, y, means, T, cfg)
+
+
+# ------------------------------------------------------------------------------------------- losses
+class _Recon(torch.autograd.Function):
+    """wmse (L,N) of x_reco[1:] against x with a scalar sigma (losses.py:8-27; cvae.py:649-652)."""
+
+    @staticmethod
+    def forward(ctx, x_reco, x, sigma, sigma_is_log):
+        x_reco = _c(_f32(x_reco, 'recon'))
+        x = _c(x)
+        sigma = _c(sigma)
+        if sigma.numel() != 1:
+            raise L.JvaeHipError('per-dimension sigma is outside the native-kernel contract')
+        Lp1, N = x_reco.shape[0], x_reco.shape[1]
+        D = x.numel() // max(N, 1)
+        wmse = torch.empty((Lp1 - 1, N), device=x.device, dtype=torch.float32)
+        rc = L.load().jvae_recon_fwd_f32(L.ptr(x_reco), L.ptr(x), L.ptr(sigma), int(sigma_is_log), L.ptr(wmse),
+                                         Lp1 - 1, N, D, L.stream_ptr())
+        L.check(rc, 'jvae_recon_fwd_f32')
+        ctx.save_for_backward(x_reco, x, sigma, wmse)
+        ctx.is_log = sigma_is_log
+        ctx.dims = (Lp1 - 1, N, D)
+        return wmse
+
+    @staticmethod
+    def backward(ctx, g):
+        x_reco, x, sigma, wmse = ctx.saved_tensors
+        Ls, N, D = ctx.dims
+        g = _c(g)
+        gxr = torch.empty_like(x_reco)
+        gs = torch.empty_like(sigma) if ctx.needs_input_grad[2] else None
+        ws = L.workspace(4 * Ls * N + 16, x.device)
+        rc = L.load().jvae_recon_bwd_f32(L.ptr(x_reco), L.ptr(x), L.ptr(sigma), int(ctx.is_log), L.ptr(g), L.ptr(wmse),
+                                         L.ptr(gxr), L.ptr(gs), 0, Ls, N, D, L.ptr(ws), ws.numel(), L.stream_ptr())
+        L.check(rc, 'jvae_recon_bwd_f32')
+        return gxr, None, gs, None
+
+
+def recon_wmse(x_reco, x, sigma, sigma_is_log):
+    return _Recon.apply(x_reco, x, sigma, sigma_is_log)
+
+
+class _Xent(torch.autograd.Function):
+    """Row-wise cross entropy, target y[r % N] (F.cross_entropy(reduction='none'), losses.py:76-86)."""
+
+    @staticmethod
+    def forward(ctx, logits, y):
+        lg = _c(_f32(logits, 'xent').reshape(-1, logits.shape[-1]))
+        y = _c(y)
+        R, C = lg.shape
+        ce = torch.empty(R, device=lg.device, dtype=torch.float32)
+        L.check(L.load().jvae_xent_fwd_f32(L.ptr(lg), L.ptr(y), L.ptr(ce), R, y.numel(), C, L.stream_ptr()), 'xent_fwd')
+        ctx.save_for_backward(lg, y)
+        ctx.shape = logits.shape
+        return ce.reshape(logits.shape[:-1])
+
+    @staticmethod
+    def backward(ctx, g):
+        lg, y = ctx.saved_tensors
+        R, C = lg.shape
+        g = _c(g.reshape(-1))
+        gl = torch.empty_like(lg)
+        L.check(L.load().jvae_xent_bwd_f32(L.ptr(lg), L.ptr(y), L.ptr(g), L.ptr(gl), R, y.numel(), C, L.stream_ptr()),
+                'xent_bwd')
+        return gl.reshape(ctx.shape), None
+
+
+def cross_entropy_rows(logits, y):
+    return _Xent.apply(logits, y)
+
+
+# ------------------------------------------------------------------------------------------- optimiser
+def sqnorm_accum(g, acc, reset):
+    L.check(L.load().jvae_sqnorm_accum_f32(L.ptr(g), g.numel(), L.ptr(acc), int(reset), L.stream_ptr()), 'sqnorm')
+
+
+def clip_scale(g, sqnorm, max_norm):
+    L.check(L.load().jvae_clip_scale_f32(L.ptr(g), g.numel(), L.ptr(sqnorm), float(max_norm), L.stream_ptr()), 'clip_scale')
+
+
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, max_norm=0., sqnorm=None, flag=None):
+    rc = L.load().jvae_adam_step_f32(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), p.numel(), lr, beta1, beta2, eps,
+                                     weight_decay, step, float(max_norm or 0.), L.ptr(sqnorm), L.ptr(flag), L.stream_ptr())
+    L.check(rc, 'jvae_adam_step_f32')

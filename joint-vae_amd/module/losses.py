@@ -1,0 +1,49 @@
+"""Per-sample loss terms on HIP kernels (public surface of the reference's module/losses.py:8-86).
+
+    mse_loss(x_output, x_target, ndim, batch_mean)        reconstruction mean-square over the image dims
+    x_loss(y_target, logits, batch_mean)                  cross entropy of the L(+1) sampled logits
+    categorical_loss(...)                                  256-way pixel cross entropy (not in the native contract)
+"""
+import torch
+
+from jvae_hip import ops
+
+
+def mse_loss(x_output, x_target, ndim=3, batch_mean=True):
+    """x_target (N1..Ng, D1..Dt); x_output (L, N1..Ng, D1..Dt) -> (L, N1..Ng) mean squares (or their mean).
+
+    Runs the reconstruction kernel with sigma = 1; that kernel compares rows 1..L of a (L+1, N, D) tensor
+    with x, so a leading dummy row is passed.
+    """
+    lead = x_output.shape[:x_output.dim() - x_target.dim()]
+    L_ = 1
+    for s in lead:
+        L_ *= s
+    batch = x_target.shape[:x_target.dim() - ndim]
+    n = 1
+    for s in batch:
+        n *= s
+    D = x_target.numel() // max(n, 1)
+    xo = x_output.reshape(L_, n, D)
+    padded = torch.cat([xo[:1], xo], 0)                     # row 0 is ignored by the kernel
+    one = torch.ones(1, device=x_target.device)
+    wmse = ops.recon_wmse(padded, x_target.reshape(n, D), one, False).reshape(*lead, *batch)
+    return wmse.mean() if batch_mean else wmse
+
+
+def x_loss(y_target, logits, batch_mean=True):
+    """Cross entropy between labels y (N1..Ng) and logits (L, N1..Ng, C), averaged over L.
+
+    y_target None: all-class evaluation -> -log(softmax + 1e-6) averaged over the sampled rows, class-major
+    (evaluation path)."""
+    if y_target is None:
+        log_p = (logits.softmax(dim=-1) + 1e-6).log()
+        perm = [-1] + list(range(log_p.dim() - 2))
+        rows = log_p[1:].mean(0) if log_p.shape[0] > 1 else log_p[0]
+        return -rows.permute(perm)
+    ce = ops.cross_entropy_rows(logits, y_target.reshape(-1))        # (L, N1..Ng)
+    return ce.mean() if batch_mean else ce.mean(0)
+
+
+def categorical_loss(x_output, x_target, ndim=3, batch_mean=True):
+    raise NotImplementedError('categorical (256-way) output distribution is outside the native-kernel contract')

@@ -1,0 +1,324 @@
+"""Optimiser of the joint CVAE: global-norm clipping + Adam on flat fp32 buffers, on HIP kernels.
+
+Public surface of the reference's module/optimizers.py:14-134 (`Optimizer(parameters, optim_type, lr,
+lr_decay, weight_decay, grad_clipping, **kw)` with `.params .lr .kind .zero_grad() .clip() .step()
+.update_lr() .update_scheduler_from_epoch() .state_dict() .load_state_dict() .to() .__format__`), where the
+reference wraps torch.optim.Adam + clip_grad_norm_ + ExponentialLR.
+
+MI355X design: every parameter that receives gradient is re-pointed (`.data`, `.grad`) into ONE flat,
+16-byte aligned device buffer, so that
+  * zero_grad is one memset,
+  * clip_grad_norm_ is one squared-norm reduction whose scalar stays on the device,
+  * Adam (+ L2 weight decay + the clip coefficient + the NaN/Inf scan of cvae.py:2454-2457) is ONE kernel,
+  * the data-parallel gradient exchange is ONE RCCL all-reduce of that buffer (latency-bound at ~6 MB).
+Parameters that never receive gradient (e.g. the classifier when gamma = 0, the scalar prior variance) are
+left untouched exactly as torch.optim.Adam skips `grad is None` parameters; they join (as a new group with
+its own step count) the first time a gradient shows up.
+"""
+import logging
+
+import torch
+
+from jvae_hip import ops
+from jvae_compat import texify_str
+
+default_lr = {'sgd': 0.01, 'adam': 0.001}
+params_by_type = {'sgd': ('momentum', 'nesterov', 'weight_decay'),
+                  'adam': ('betas', 'weight_decay', 'amsgrad')}
+
+_ALIGN = 4        # floats: every tensor starts on a 16-byte boundary inside the flat buffer
+
+
+class _FlatGroup:
+    """Parameters that joined at the same time: contiguous p / g / m / v buffers and one step count."""
+
+    def __init__(self, params, device, step=0):
+        self.params = list(params)
+        self.offsets = []
+        n = 0
+        for p in self.params:
+            self.offsets.append(n)
+            n += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        self.numel = n
+        self.step = step
+        self.p = torch.zeros(n, device=device, dtype=torch.float32)
+        self.g = torch.zeros(n, device=device, dtype=torch.float32)
+        self.m = torch.zeros(n, device=device, dtype=torch.float32)
+        self.v = torch.zeros(n, device=device, dtype=torch.float32)
+        with torch.no_grad():
+            for p, o in zip(self.params, self.offsets):
+                k = p.numel()
+                self.p[o:o + k].copy_(p.data.reshape(-1))
+                if p.grad is not None:
+                    self.g[o:o + k].copy_(p.grad.reshape(-1))
+                p.data = self.p[o:o + k].view(p.shape)
+                p.grad = self.g[o:o + k].view(p.shape)
+
+    def view(self, buf, i):
+        p, o = self.params[i], self.offsets[i]
+        return buf[o:o + p.numel()].view(p.shape)
+
+    def intact(self):
+        """Do the parameters still live in this group's buffers and still want gradients?"""
+        base_p, base_g = self.p.data_ptr(), self.g.data_ptr()
+        for p, o in zip(self.params, self.offsets):
+            if not p.requires_grad or p.grad is None:
+                return False
+            if p.data_ptr() != base_p + 4 * o or p.grad.data_ptr() != base_g + 4 * o:
+                return False
+        return True
+
+
+class Optimizer:
+
+    def __init__(self, parameters, optim_type='adam', lr=0, lr_decay=0, weight_decay=0, grad_clipping=None,
+                 epoch=0, **kw):
+        if optim_type != 'adam':
+            raise NotImplementedError("only optim_type='adam' is built on the native kernels (got {!r})".format(optim_type))
+        if kw.get('amsgrad'):
+            raise NotImplementedError('amsgrad is outside the native-kernel contract')
+        self.kind = optim_type
+        lr = lr or default_lr[optim_type]
+        self.params = {'optim_type': optim_type, 'lr': lr, 'lr_decay': lr_decay, 'weight_decay': weight_decay,
+                       'grad_clipping': grad_clipping}
+        self.params.update(kw)
+        self.grad_clipping = grad_clipping
+        self.init_lr = lr
+        self.lr_decay = lr_decay
+        self.weight_decay = weight_decay
+        self.betas = tuple(kw.get('betas', (0.9, 0.999)))
+        self.eps = kw.get('eps', 1e-8)
+        self._lr = lr
+        self._epochs_decayed = 0
+        self._all = [p for p in parameters]
+        self._groups = []
+        self._clip_pending = False
+        self._sqnorm = None          # device scalar: squared global gradient norm of the last clip()
+        self._flag = None            # device int: set by the Adam kernel when a parameter became NaN/Inf
+        self._world = 1
+        self._pg = None
+        self._reduced = False
+        logging.debug('Creating optimizer with params %s', ' ; '.join(f'{k}:{v}' for k, v in self.params.items()))
+
+    # ---- learning rate -----------------------------------------------------------------------------
+    @property
+    def lr(self):
+        return self._lr
+
+    def update_lr(self):
+        if self.lr_decay:
+            old = self._lr
+            self._epochs_decayed += 1
+            self._lr = self.init_lr * (1 - self.lr_decay) ** self._epochs_decayed
+            logging.debug(f'lr updated from {old:.4e} to {self._lr:.4e}')
+
+    def update_scheduler_from_epoch(self, n):
+        if self.lr_decay:
+            for _ in range(n):
+                self.update_lr()
+
+    # ---- data-parallel hook (no equivalent in the single-process reference) ----------
+    def set_distributed(self, world_size, process_group=None):
+        """Average gradients over `world_size` ranks (one RCCL all-reduce per flat group) before clip/step."""
+        self._world = int(world_size)
+        self._pg = process_group
+
+    def reduce_gradients(self):
+        if self._world > 1 and not self._reduced:
+            import torch.distributed as dist
+            self._adopt_new()
+            for g in self._groups:
+                dist.all_reduce(g.g, op=dist.ReduceOp.AVG, group=self._pg)
+            self._reduced = True
+
+    # ---- flat-buffer management -------------------------------------------------------------------
+    def _device(self):
+        for p in self._all:
+            return p.device
+        return torch.device('cpu')
+
+    def _flat_ids(self):
+        return {id(p) for g in self._groups for p in g.params}
+
+    def _adopt_new(self):
+        """Parameters with a gradient that are not in a flat group yet join a new one."""
+        if self._groups and not all(g.intact() for g in self._groups):
+            self._rebuild()
+        known = self._flat_ids()
+        fresh = [p for p in self._all if id(p) not in known and p.requires_grad and p.grad is not None]
+        if fresh:
+            dev = fresh[0].device
+            if dev.type != 'cuda':
+                raise RuntimeError('module.optimizers.Optimizer runs on the GPU only (parameters are on {}); '
+                                   'there is no CPU fallback'.format(dev))
+            self._groups.append(_FlatGroup(fresh, dev))
+
+    def _rebuild(self):
+        """Something moved the parameters (.to(), load_state_dict, requires_grad flip): re-flatten, keep state."""
+        old = self._groups
+        self._groups = []
+        for g in old:
+            keep = [i for i, p in enumerate(g.params) if p.requires_grad]
+            if not keep:
+                continue
+            ps = [g.params[i] for i in keep]
+            dev = ps[0].device
+            if dev.type != 'cuda':
+                self._cpu_state = getattr(self, '_cpu_state', [])      # state parked until we are back on a GPU
+                self._cpu_state.append((ps, [g.view(g.m, i).detach().cpu().clone() for i in keep],
+                                        [g.view(g.v, i).detach().cpu().clone() for i in keep], g.step))
+                continue
+            ng = _FlatGroup(ps, dev, g.step)
+            with torch.no_grad():
+                for j, i in enumerate(keep):
+                    ng.view(ng.m, j).copy_(g.view(g.m, i).to(dev))
+                    ng.view(ng.v, j).copy_(g.view(g.v, i).to(dev))
+            self._groups.append(ng)
+
+    def _restore_parked(self):
+        parked = getattr(self, '_cpu_state', None)
+        if not parked:
+            return
+        rest = []
+        for ps, ms, vs, step in parked:
+            dev = ps[0].device
+            if dev.type != 'cuda':
+                rest.append((ps, ms, vs, step))
+                continue
+            ng = _FlatGroup(ps, dev, step)
+            with torch.no_grad():
+                for j in range(len(ps)):
+                    ng.view(ng.m, j).copy_(ms[j].to(dev))
+                    ng.view(ng.v, j).copy_(vs[j].to(dev))
+            self._groups.append(ng)
+        self._cpu_state = rest
+
+    def to(self, device):
+        """Called by the model's .to(): parameters have just been moved, so re-flatten on their new device."""
+        logging.debug(f'Sending optimizer to {device}')
+        if self._groups:
+            self._rebuild()
+        self._restore_parked()
+        self._sqnorm = None
+        self._flag = None
+
+    # ---- the step ------------------------------------------------------------------------------------
+    def zero_grad(self, *a, **kw):
+        flat = self._flat_ids()
+        for g in self._groups:
+            g.g.zero_()
+        for p in self._all:
+            if id(p) not in flat:
+                p.grad = None
+        self._clip_pending = False
+        self._reduced = False
+
+    def clip(self, parameters=None):
+        """clip_grad_norm_(all parameters, grad_clipping): the norm is reduced here, the coefficient is
+        applied inside the Adam kernel of the following step() (and to .grad too if step() does not follow)."""
+        self.reduce_gradients()
+        if not self.grad_clipping:
+            return
+        self._adopt_new()
+        if not self._groups:
+            return
+        dev = self._groups[0].g.device
+        if self._sqnorm is None or self._sqnorm.device != dev:
+            self._sqnorm = torch.zeros(1, device=dev, dtype=torch.float32)
+        for i, g in enumerate(self._groups):
+            ops.sqnorm_accum(g.g, self._sqnorm, reset=(i == 0))
+        self._clip_pending = True
+
+    def grad_norm(self):
+        """Global gradient norm measured by the last clip() (device scalar tensor)."""
+        return None if self._sqnorm is None else self._sqnorm.sqrt()
+
+    def apply_clip_to_grads(self):
+        """Materialise the clipped gradients in .grad (what clip_grad_norm_ leaves behind)."""
+        if self._clip_pending:
+            for g in self._groups:
+                ops.clip_scale(g.g, self._sqnorm, self.grad_clipping)
+            self._clip_pending = False
+
+    def step(self):
+        self.reduce_gradients()
+        self._adopt_new()
+        if not self._groups:
+            return
+        dev = self._groups[0].g.device
+        if self._flag is None or self._flag.device != dev:
+            self._flag = torch.zeros(1, device=dev, dtype=torch.int32)
+        clip = self.grad_clipping if self._clip_pending else 0.
+        for g in self._groups:
+            g.step += 1
+            ops.adam_step(g.p, g.g, g.m, g.v, self._lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
+                          g.step, max_norm=clip, sqnorm=self._sqnorm if clip else None, flag=self._flag)
+        self._clip_pending = False
+
+    def nonfinite_flag(self):
+        """Device int32 tensor, non-zero once any updated parameter was NaN/Inf (None before the first step)."""
+        return self._flag
+
+    # ---- persistence (torch.optim.Adam state_dict layout, so optimizer.pth round-trips) ---------------
+    def state_dict(self, *a, **k):
+        index = {id(p): i for i, p in enumerate(self._all)}
+        state = {}
+        for g in self._groups:
+            for j, p in enumerate(g.params):
+                state[index[id(p)]] = {'step': torch.tensor(float(g.step)),
+                                       'exp_avg': g.view(g.m, j).detach().clone(),
+                                       'exp_avg_sq': g.view(g.v, j).detach().clone()}
+        group = {'lr': self._lr, 'betas': self.betas, 'eps': self.eps, 'weight_decay': self.weight_decay,
+                 'amsgrad': False, 'maximize': False, 'foreach': None, 'capturable': False, 'differentiable': False,
+                 'fused': None, 'decoupled_weight_decay': False, 'initial_lr': self.init_lr,
+                 'params': list(range(len(self._all)))}
+        return {'state': state, 'param_groups': [group]}
+
+    def load_state_dict(self, sd, *a, **k):
+        pg = sd['param_groups'][0]
+        self._lr = pg['lr']
+        self.betas = tuple(pg.get('betas', self.betas))
+        self.eps = pg.get('eps', self.eps)
+        self.weight_decay = pg.get('weight_decay', self.weight_decay)
+        by_step = {}
+        for idx, st in sd['state'].items():
+            by_step.setdefault(int(float(st['step'])), []).append(int(idx))
+        self._groups = []
+        for step, idxs in sorted(by_step.items(), reverse=True):
+            ps = [self._all[i] for i in sorted(idxs)]
+            dev = ps[0].device
+            if dev.type != 'cuda':
+                self._cpu_state = getattr(self, '_cpu_state', [])
+                self._cpu_state.append((ps, [sd['state'][i]['exp_avg'].clone() for i in sorted(idxs)],
+                                        [sd['state'][i]['exp_avg_sq'].clone() for i in sorted(idxs)], step))
+                continue
+            g = _FlatGroup(ps, dev, step)
+            with torch.no_grad():
+                for j, i in enumerate(sorted(idxs)):
+                    g.view(g.m, j).copy_(sd['state'][i]['exp_avg'].to(dev))
+                    g.view(g.v, j).copy_(sd['state'][i]['exp_avg_sq'].to(dev))
+            self._groups.append(g)
+
+    # ---- printing --------------------------------------------------------------------------------------
+    def __str__(self):
+        return self.__format__('10')
+
+    def __format__(self, format_spec):
+        if format_spec.endswith('x'):
+            return texify_str(self.__format__(format_spec[:-1]), num=True)
+        try:
+            level = int(format_spec)
+        except ValueError:
+            level = 0
+        if not level:
+            return self.__str__()
+        parts = [self.kind, f'lr={self.init_lr}']
+        if self.lr_decay:
+            parts.append(f'decay={self.lr_decay}')
+        else:
+            level -= 1
+        shown = {'betas': self.betas, 'weight_decay': self.weight_decay, 'amsgrad': False}
+        extra = [f'{k}={shown[k]}' for k in params_by_type[self.kind] if shown[k] and not isinstance(shown[k], bool)]
+        if extra:
+            parts.append('--'.join(extra))
+        return '--'.join(parts[:level])

@@ -1,0 +1,246 @@
+"""Layer-string DSL -> (de)convolution stacks that run on the gfx950 HIP kernels.
+
+Same public surface as the reference's module/vae_layers/conv.py (`build_de_conv_layers`,
+`find_input_shape`, `parse_conv_layer_name`, `conv_layer_name`, `features_dict`, `upsampler_dict`; reference
+lines 20-86, 89-105, 108-125, 128-244) and the same `state_dict` layout (conv at index 3i, BatchNorm2d at
+3i+1, activation at 3i+2), but the returned container executes conv -> BatchNorm(batch stats) -> ReLU through
+libjvae_hip.so instead of ATen/MIOpen.
+
+DSL recap (conv-models.ini): `[defaults]tok-tok-...`; a token is `C x K + P : S` (channels, kernel,
+padding, stride), upsamplers add `++OP` (output padding) and `!C...` (a plain convolution inside a
+transposed stack).  Pooling (`M`/`A`) and nearest up-sampling (`U`) tokens parse, but building them raises:
+they are outside this build's native-kernel contract.
+"""
+import configparser
+import logging
+import os
+import re
+
+from torch import nn
+
+from jvae_hip import ops
+from .misc import activation_layers, Reshape, ACT_OF_MODULE
+
+_ini = configparser.ConfigParser()
+_ini.read(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'conv-models.ini'))
+features_dict = dict(_ini['features'])
+upsampler_dict = dict(_ini['upsampler'])
+
+_FIELD_RE = {'out_channels': r'^(\d+)', 'kernel_size': r'x(\d+)', 'output_padding': r'\+\+(\d+)',
+             'padding': r'(?<!\+)\+(\d+)(?!\d*\+)', 'stride': r':(\d+)'}
+
+
+def parse_conv_layer_name(s, ltype='conv', out_channels=32, kernel_size=5, padding='*', stride=None,
+                          output_padding=0, activation='relu', output_activation='linear', where='input'):
+    """One DSL token -> dict(ltype, out_channels, kernel_size, padding, stride[, output_padding]).
+
+    Keyword arguments are the defaults for fields the token leaves out (the `[...]` prefix of a layer
+    string is parsed with this same function and fed back in).  padding '*' = k // 2 for input-side
+    convolutions, 0 otherwise.
+    """
+    upsampling_side = where == 'output'
+    if upsampling_side:
+        ltype = 'deconv'
+    head = s[:1].lower()
+    body = s
+    if head in ('a', 'm'):
+        ltype, body = head + 'pooling', s[1:]
+    elif head == 'u':
+        ltype, body = 'upsampler', s[1:]
+    conv_inside_deconv = upsampling_side and body.startswith('!')
+    if conv_inside_deconv:
+        body = body[1:]
+
+    found = {}
+    for field, pattern in _FIELD_RE.items():
+        m = re.search(pattern, body)
+        if m:
+            found[field] = int(m.group(1))
+
+    p = {'ltype': ltype, 'kernel_size': found.get('kernel_size', kernel_size),
+         'padding': found.get('padding', padding), 'stride': found.get('stride', stride)}
+    if ltype in ('conv', 'deconv'):
+        p['out_channels'] = found.get('out_channels', out_channels)
+    if ltype == 'deconv' and not conv_inside_deconv:
+        p['output_padding'] = found.get('output_padding', output_padding)
+    if conv_inside_deconv:
+        p['ltype'] = 'conv'
+    if p['padding'] == '*':
+        # the reference resolves '*' against the side-wide layer type, so a `!` conv on the
+        # upsampling side gets 0 as well
+        p['padding'] = p['kernel_size'] // 2 if (ltype == 'conv') else 0
+    if p['stride'] is None and p['ltype'].endswith('conv'):
+        p['stride'] = 1
+    return p
+
+
+def conv_layer_name(conv_layer):
+    """Canonical token of a built layer (used for the stack's `.name` when it is not a named net)."""
+    if isinstance(conv_layer, (nn.Conv2d, nn.ConvTranspose2d)):
+        k, p, s = conv_layer.kernel_size[0], conv_layer.padding[0], conv_layer.stride[0]
+        tok = f'{conv_layer.out_channels}x{k}'
+        if p != k // 2:
+            tok += f'+{p}'
+        if s != 1:
+            tok += f':{s}'
+        return tok
+    raise NotImplementedError(type(conv_layer).__name__)
+
+
+class HipConv2d(nn.Conv2d):
+    """nn.Conv2d parameters (same init / state_dict), forward on the HIP implicit-GEMM kernels."""
+
+    def _spec(self):
+        return ops.ConvSpec(self.in_channels, self.out_channels, self.kernel_size[0], self.stride[0], self.padding[0])
+
+    def forward(self, x):
+        return ops.conv2d(x, self.weight, self.bias, self._spec())
+
+
+class HipConvTranspose2d(nn.ConvTranspose2d):
+    def _spec(self):
+        return ops.ConvSpec(self.in_channels, self.out_channels, self.kernel_size[0], self.stride[0], self.padding[0],
+                            self.output_padding[0], transposed=True)
+
+    def forward(self, x, output_size=None):
+        return ops.conv2d(x, self.weight, self.bias, self._spec())
+
+
+class HipBatchNorm2d(nn.BatchNorm2d):
+    """nn.BatchNorm2d state; forward = batch-statistics kernel (+ the following ReLU when fused by the stack)."""
+
+    def forward(self, x, relu=False):
+        return ops.batchnorm_act(x, self.weight, self.bias, self.running_mean, self.running_var,
+                                 self.num_batches_tracked, self.training, relu, self.momentum, self.eps)
+
+
+class HipConvStack(nn.Sequential):
+    """nn.Sequential whose forward fuses BatchNorm2d with the activation that follows it."""
+
+    def forward(self, x):
+        mods = list(self)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, HipBatchNorm2d) and i + 1 < len(mods) and type(mods[i + 1]) in ACT_OF_MODULE \
+                    and ACT_OF_MODULE[type(mods[i + 1])] in (ops.RELU, ops.IDENT):
+                x = m(x, relu=ACT_OF_MODULE[type(mods[i + 1])] == ops.RELU)
+                i += 2
+                continue
+            x = m(x)
+            i += 1
+        return x
+
+
+def build_de_conv_layers(input_shape, layers_name, batch_norm=False, where='input', activation='relu',
+                         output_activation='linear', output_distribution='gaussian', pretrained_dict=None):
+    """Build the encoder-side (`where='input'`) or decoder-side (`where='output'`) convolution stack.
+
+    Returns an nn.Sequential-compatible module with `.name .output_shape .input_shape .shapes`.
+    """
+    if where == 'input' and layers_name.startswith('resnet'):
+        raise NotImplementedError('torchvision resnet/densenet features are outside the native-kernel contract')
+
+    table = features_dict if where == 'input' else upsampler_dict
+    net_name = layers_name if layers_name in table else None
+    spec = table.get(layers_name, layers_name)
+    if isinstance(input_shape, int):
+        input_shape = (input_shape, 1, 1)
+
+    defaults = {}
+    if spec.startswith('['):
+        close = spec.index(']')
+        for tok in spec[1:close].split('-'):
+            d = parse_conv_layer_name(tok, where=where)
+            defaults[d.pop('ltype')] = d
+        spec = spec[close + 1:]
+
+    channels, h, w = input_shape
+    modules, tokens, shapes = [], [], [tuple(input_shape)]
+    last_act = None
+    toks = spec.split('-')
+    for n, tok in enumerate(toks):
+        kind = parse_conv_layer_name(tok, where=where)['ltype']
+        p = parse_conv_layer_name(tok, **defaults.get(kind, {}), where=where)
+        kind = p.pop('ltype')
+        if kind not in ('conv', 'deconv'):
+            raise NotImplementedError(f'layer token {tok!r} ({kind}) is outside the native-kernel contract '
+                                      '(only convolutions and transposed convolutions are built)')
+        if where == 'output' and n == len(toks) - 1 and output_distribution == 'categorical':
+            p['out_channels'] *= 256
+        k, pad, s = p['kernel_size'], p['padding'], p['stride']
+        if kind == 'conv':
+            layer = HipConv2d(channels, **p)
+            h, w = (h + 2 * pad - k) // s + 1, (w + 2 * pad - k) // s + 1
+        else:
+            layer = HipConvTranspose2d(channels, **p)
+            op = p['output_padding']
+            h, w = (h - 1) * s - 2 * pad + k + op, (w - 1) * s - 2 * pad + k + op
+        channels = p['out_channels']
+        modules.append(layer)
+        if batch_norm:
+            modules.append(HipBatchNorm2d(channels))
+        modules.append(activation_layers[activation]())
+        last_act = len(modules) - 1
+        tokens.append(conv_layer_name(layer))
+        shapes.append((channels, h, w))
+
+    out_channels = (channels,)
+    if where == 'output':
+        modules[last_act] = activation_layers[output_activation]()
+        if output_distribution == 'categorical':
+            modules.append(Reshape((256, channels // 256, h, w)))
+            out_channels = (256, channels // 256)
+    stack = HipConvStack(*modules)
+    stack.name = net_name or '-'.join(tokens)
+    stack.output_shape = (*out_channels, h, w)
+    stack.input_shape = input_shape
+    stack.shapes = shapes
+
+    if pretrained_dict:
+        stack.load_state_dict(pretrained_dict)
+        logging.debug('Pretrained conv layers for %s', where)
+        for prm in stack.parameters():
+            prm.requires_grad_(False)
+    return stack
+
+
+def find_input_shape(layers_name, wanted_output_shape, input_shape=(1, 1)):
+    """Smallest spatial input (h, w) an upsampler maps onto `wanted_output_shape` (grown one step at a time)."""
+    h, w = input_shape
+    wanted = tuple(wanted_output_shape)
+    while True:
+        got = tuple(_upsampler_out_hw(layers_name, h, w))
+        if got == wanted:
+            logging.debug('Found input_shape for %s: %s, %s', layers_name, h, w)
+            return (h, w)
+        if got[0] > wanted[0] or got[1] > wanted[1]:
+            raise ValueError('Did not find an input shape yielding output size ({}, {}) for {}'.format(*wanted, layers_name))
+        h += int(got[0] < wanted[0])
+        w += int(got[1] < wanted[1])
+
+
+def _upsampler_out_hw(layers_name, h, w):
+    """Shape inference only (no parameters are allocated)."""
+    spec = upsampler_dict.get(layers_name, layers_name)
+    defaults = {}
+    if spec.startswith('['):
+        close = spec.index(']')
+        for tok in spec[1:close].split('-'):
+            d = parse_conv_layer_name(tok, where='output')
+            defaults[d.pop('ltype')] = d
+        spec = spec[close + 1:]
+    for tok in spec.split('-'):
+        kind = parse_conv_layer_name(tok, where='output')['ltype']
+        p = parse_conv_layer_name(tok, **defaults.get(kind, {}), where='output')
+        k, pad, s = p['kernel_size'], p['padding'], p['stride']
+        if p['ltype'] == 'conv':
+            h, w = (h + 2 * pad - k) // s + 1, (w + 2 * pad - k) // s + 1
+        elif p['ltype'] == 'deconv':
+            op = p['output_padding']
+            h, w = (h - 1) * s - 2 * pad + k + op, (w - 1) * s - 2 * pad + k + op
+        elif p['ltype'] == 'upsampler':
+            h, w = int(h * s), int(w * s)
+        else:
+            raise NotImplementedError(tok)
+    return h, w

@@ -1,0 +1,339 @@
+"""Dense blocks of the joint CVAE on HIP kernels: Sigma, Sampling, Encoder, Classifier.
+
+Same public surface as the reference's module/vae_layers/layers.py — `Sigma` (:73-213), `Sampling`
+(:216-250), `Encoder` (:253-403), `Classifier` (:456-483) — and the same `state_dict` keys
+(`encoder.dense_projs.{0,2,..}`, `encoder.dense_mean`, `encoder.dense_log_var`, `encoder.prior.*`,
+`classifier.{0,2,..}`).  The unused colour-space / Decoder helpers of that file are not rebuilt.
+"""
+import logging
+import math
+
+import numpy as np
+import torch
+from torch import nn
+from torch.nn import Parameter
+
+from jvae_hip import ops
+from jvae_compat import texify_str
+from module.priors import build_prior
+from .misc import activation_layers, ACT_OF_MODULE
+
+
+class Sigma(Parameter):
+    """Standard deviation of p(x|z): a Parameter that is fixed, learned (stored as log sigma), tied to
+    the running RMSE with a decay rule, or coded by the encoder.  Constructor as in the reference:
+    Sigma(value, sdim, input_dim, reach, decay, max_step, learned, is_rmse, sigma0, is_log)."""
+
+    @staticmethod
+    def __new__(cls, value=None, sdim=1, input_dim=False, learned=False, is_rmse=False, is_log=False, **kw):
+        assert value is not None or is_rmse or input_dim
+        if is_rmse or (input_dim and value is None):
+            value = 0
+        log_stored = bool(is_log or learned or input_dim)
+        fill = math.log(value) if log_stored else value
+        data = torch.full((sdim,) if isinstance(sdim, int) else tuple(sdim), float(fill))
+        return super().__new__(cls, data, requires_grad=bool(learned or input_dim))
+
+    def __init__(self, value=None, learned=False, is_rmse=False, sdim=1, input_dim=False, reach=1, decay=0,
+                 max_step=None, sigma0=None, is_log=False):
+        assert not learned or not is_rmse
+        assert not decay or not learned
+        self._rmse = np.nan
+        self.is_rmse = is_rmse
+        self.sigma0 = value if (sigma0 is None and not is_rmse) else sigma0
+        self.learned = learned
+        self.input_dim = input_dim
+        self.is_log = bool(learned or is_log or input_dim)
+        self.decay = 1 if is_rmse else decay
+        self.reach = reach if (decay or is_rmse) else None
+        self.max_step = max_step
+        self.sdim = sdim
+        if self.coded:
+            self._output_dim = input_dim if self.per_dim else (1,) * len(input_dim)
+        else:
+            self._output_dim = None
+
+    def __deepcopy__(self, memo):
+        new = Sigma.__new__(Sigma, value=1.0, sdim=self.sdim, learned=self.requires_grad)
+        new.__dict__.update(self.__dict__)
+        new.data = self.data.clone()
+        memo[id(self)] = new
+        return new
+
+    # -- views ------------------------------------------------------------------------------------
+    @property
+    def value(self):
+        """RMS value of sigma as a Python float (host read-back: not used inside the training step)."""
+        with torch.no_grad():
+            d = self.data
+            return ((2 * d).exp() if self.is_log else d.pow(2)).mean().sqrt().item()
+
+    @property
+    def coded(self):
+        return bool(self.input_dim)
+
+    @property
+    def per_dim(self):
+        return self.sdim != 1
+
+    @property
+    def output_dim(self):
+        return self._output_dim
+
+    @property
+    def params(self):
+        d = {k: v for k, v in self.__dict__.items() if not k.startswith('_')}
+        d['value'] = self.value
+        return d
+
+    def host_params(self, value):
+        """`params` with an already known RMS value (avoids the device read-back of `.value`)."""
+        d = {k: v for k, v in self.__dict__.items() if not k.startswith('_')}
+        d['value'] = value
+        return d
+
+    # -- updates -------------------------------------------------------------------------------------
+    def update(self, rmse=None, v=None):
+        assert rmse is None or v is None
+        if v is not None:
+            lead = tuple(range(v.dim() - self.dim()))
+            v = v.mean(lead) if lead else v
+            assert v.dim() == self.dim()
+            self.data = v
+            return
+        if rmse is None:
+            return
+        self._rmse = rmse
+        if self.learned or not self.decay:
+            return
+        delta = self.decay * (self.reach * rmse - self.data)
+        if self.max_step and abs(delta) > self.max_step:
+            delta = self.max_step if delta > 0 else -self.max_step
+        self.data += delta
+
+    # -- printing ------------------------------------------------------------------------------------
+    def __format__(self, spec):
+        if spec.endswith(('f', 'g', 'e')):
+            return self.value.__format__(spec)
+        if spec.endswith('x'):
+            return texify_str(str(self), num=True)
+        if spec.endswith('i'):
+            if self.is_rmse:
+                return 'e'
+            if self.coded:
+                return 'C' if self.per_dim else 'c'
+            if self.learned:
+                return 'l'
+        return str(self)
+
+    def __str__(self):
+        if self.is_rmse:
+            return 'rmse' if self._rmse is np.nan else f'rmse ({self._rmse:g})'
+        if self.coded:
+            return 'coded {}'.format('mask' if self.per_dim else 'scalar')
+        if self.learned:
+            return f'{self.sigma0:g}->rmse[l] ({self.value:g})'
+        if not self.decay:
+            with torch.no_grad():
+                return f'{self.data.item():g}'
+        mult = '' if self.reach == 1 else f'{self.reach:g}*'
+        cap = f'<{self.max_step:g}' if self.max_step else ''
+        return f'{self.sigma0:g}->{mult}rmse[-{self.decay:g}*{cap}]'
+
+    def __repr__(self):
+        if self.is_rmse:
+            return 'Sigma will be RMSE'
+        s = super().__repr__()
+        if self.decay:
+            return s[:-1] + f', decaying to {self.reach}*mse with rate {self.decay})'
+        return s
+
+
+def draw_epsilon(sampling_size, shape, device, distribution='gaussian'):
+    """(L+1, *shape) noise from the device's default generator, row 0 zeroed (layers.py:233-238)."""
+    size = (sampling_size + 1,) + tuple(shape)
+    if distribution == 'gaussian':
+        eps = torch.randn(size, device=device)
+    else:
+        eps = (torch.rand(size, device=device) - 0.5) * math.sqrt(12)
+    eps[0] = 0
+    return eps
+
+
+class Sampling(nn.Module):
+    """z[l] = mu + exp(log_var / 2) * eps[l] * is_sampled for l = 0..L with eps[0] = 0.
+
+    forward(z_mean, z_log_var[, epsilon]) -> (z (L+1, ..., K), eps[1:]).  Runs the fused latent kernel with a
+    standard normal prior (its KL outputs are discarded); Encoder uses the kernel directly to get both.
+    """
+
+    def __init__(self, latent_dim, sampling_size=1, sampling=True, distribution='gaussian', **kwargs):
+        assert distribution in ('gaussian', 'uniform'), '{} for sampling unknown'.format(distribution)
+        super().__init__(**kwargs)
+        self.distribution = distribution
+        self.sampling_size = sampling_size
+        self.is_sampled = sampling
+
+    def forward(self, z_mean, z_log_var, epsilon=None):
+        K = z_mean.shape[-1]
+        if epsilon is None:
+            epsilon = draw_epsilon(self.sampling_size, z_log_var.shape, z_mean.device, self.distribution)
+        mu2 = z_mean.reshape(-1, K)
+        n = mu2.shape[0]
+        labels = torch.zeros(n, dtype=torch.int64, device=z_mean.device)
+        means = torch.zeros((1, K), device=z_mean.device)
+        T = torch.ones(1, device=z_mean.device)
+        _, z, _, _, _, _ = ops.latent(mu2, z_log_var.reshape(-1, K), epsilon.reshape(epsilon.shape[0], n, K), labels,
+                                      means, T, sampled=bool(self.is_sampled))
+        return z.reshape(epsilon.shape), epsilon[1:]
+
+    def __repr__(self):
+        if not self.is_sampled:
+            return 'Deactivated, returns mean'
+        return 'Sampling({}, L={})'.format(self.distribution, self.sampling_size)
+
+
+class HipLinear(nn.Linear):
+    """nn.Linear parameters; forward = MFMA GEMM with the bias (and a following activation) in the epilogue."""
+
+    def forward(self, x, act=ops.IDENT):
+        return ops.linear(x, self.weight, self.bias, act)
+
+
+class DenseStack(nn.Sequential):
+    """Linear / activation chain; fuses each activation into the producing GEMM's epilogue."""
+
+    def forward(self, x):
+        mods = list(self)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            nxt = mods[i + 1] if i + 1 < len(mods) else None
+            if isinstance(m, HipLinear) and type(nxt) in ACT_OF_MODULE:
+                x = m(x, ACT_OF_MODULE[type(nxt)])
+                i += 2
+            else:
+                x = m(x)
+                i += 1
+        return x
+
+
+def _dropout_not_supported(p):
+    raise NotImplementedError('dropout={} is outside the native-kernel contract of this build'.format(p))
+
+
+class Encoder(nn.Module):
+    """Dense trunk -> (mu, log sigma^2) heads -> reparameterised samples; owns the latent prior."""
+
+    def __init__(self, input_shape, num_labels, representation='rgb', y_is_coded=False, latent_dim=32,
+                 intermediate_dims=[64], name='encoder', dropout=False, activation='relu', sampling_size=10,
+                 sampling=True, sigma_output_dim=0, forced_variance=False, prior={}, **kwargs):
+        super().__init__(**kwargs)
+        self.name = name
+        self.y_is_coded = y_is_coded
+        self.input_shape = input_shape
+        self.num_labels = num_labels
+        self.forced_variance = forced_variance
+        self._sampling_size = sampling_size
+        if dropout:
+            _dropout_not_supported(dropout)
+
+        width = int(np.prod(input_shape)) + num_labels * bool(y_is_coded)
+        trunk = []
+        for d in intermediate_dims:
+            trunk += [HipLinear(width, d), activation_layers[activation]()]
+            width = d
+        self.dense_projs = DenseStack(*trunk)
+        self.dense_mean = HipLinear(width, latent_dim)
+        self.dense_log_var = HipLinear(width, latent_dim)
+        self.sigma_output_dim = sigma_output_dim
+        if sigma_output_dim:
+            self.sigma = HipLinear(width, int(np.prod(sigma_output_dim)))
+
+        noise = 'uniform' if prior.get('distribution', 'gaussian') == 'uniform' else 'gaussian'
+        self.sampling = Sampling(latent_dim, sampling_size, sampling, distribution=noise)
+        prior['dim'] = latent_dim
+        self.prior = build_prior(**prior)
+        logging.debug('Built %s', self.prior)
+
+    def eval(self, *a):
+        print('eval', *a)
+
+    @property
+    def sampling_size(self):
+        return self._sampling_size
+
+    @sampling_size.setter
+    def sampling_size(self, v):
+        self._sampling_size = v
+        self.sampling.sampling_size = v
+
+    # -- dictionary diagnostics (evaluation / logging only) -----------------------------------------
+    def capacity(self):
+        """Upper bound of I(Z;Y) from the pairwise distances of the class means (layers.py:323-336)."""
+        m = self.prior.mean
+        C = self.num_labels
+        d2 = torch.cdist(m, m).pow(2)
+        return math.log(C) - torch.exp(-d2 / 4).sum(0).log().sum() / C
+
+    def dict_min_distance(self):
+        m = self.prior.mean
+        C = self.num_labels
+        guard = 2 * m.norm(dim=1).max() * torch.eye(C, device=m.device)
+        return (torch.cdist(m, m) + guard).min()
+
+    # -- forward -------------------------------------------------------------------------------------
+    def heads(self, x, y=None):
+        """Trunk + the two heads: (u, mu, raw log-variance) — raw = before the +-20 clip."""
+        u = x if y is None else torch.cat((x, y), dim=-1)
+        u = self.dense_projs(u)
+        return u, self.dense_mean(u), (None if self.forced_variance else self.dense_log_var(u))
+
+    def encode(self, x, y_onehot, labels, kl_var_weighting=1., epsilon=None):
+        """Fused path used by the training step: heads, then ONE latent kernel for clip + samples + KL.
+
+        labels: int64 class of every row (prior component), or None for a non-conditional prior.
+        Returns (mu, log_var, z, eps[1:], sigma_coded, kl_terms dict with kl / distance / var_kl / dzdist).
+        """
+        u, mu, lv_raw = self.heads(x, y_onehot)
+        K = mu.shape[-1]
+        batch = mu.shape[:-1]
+        mu2 = mu.reshape(-1, K)
+        n = mu2.shape[0]
+        pr = self.prior
+        if epsilon is None:
+            epsilon = draw_epsilon(self._sampling_size, mu.shape, mu.device, self.sampling.distribution)
+        lab, means, T = pr._kernel_operands(labels if pr.conditional else None, n, mu.device)
+        forced = math.log(self.forced_variance) if self.forced_variance else None
+        raw2 = mu2 if lv_raw is None else lv_raw.reshape(-1, K)
+        lv, z, kl, dist, vkl, dzd = ops.latent(mu2, raw2, epsilon.reshape(epsilon.shape[0], n, K), lab, means, T,
+                                               prior=pr.distribution, var_dim=pr.var_dim, tau=pr._tau,
+                                               alpha=pr._alpha_k, w=kl_var_weighting,
+                                               sampled=bool(self.sampling.is_sampled), forced_lv=forced)
+        sigma = self.sigma(u) if self.sigma_output_dim else None
+        terms = {'kl': kl.reshape(batch), 'distance': dist.reshape(batch), 'var_kl': vkl.reshape(batch),
+                 'dzdist': dzd.reshape(batch)}
+        return mu, lv.reshape(mu.shape), z.reshape(epsilon.shape), epsilon[1:], sigma, terms
+
+    def forward(self, x, y=None, epsilon=None):
+        """x (..., D) [, y one-hot (..., C)] -> (z_mean, z_log_var, z (L+1, ..., K), eps[1:], sigma)."""
+        labels = None
+        if self.prior.conditional:      # KL terms are discarded here: any component will do
+            labels = torch.zeros(x.shape[:-1], dtype=torch.int64, device=x.device)
+        mu, log_var, z, e, sigma, _ = self.encode(x, y, labels, epsilon=epsilon)
+        return mu, log_var, z, e, sigma
+
+
+class Classifier(DenseStack):
+    """Latent (..., K) -> logits (..., C): Linear(+activation) chain ending in Linear(num_labels)."""
+
+    def __init__(self, latent_dim, num_labels, intermediate_dims=[], name='classifier', activation='relu', **kwargs):
+        layers = []
+        width = latent_dim
+        act = activation_layers[activation]()          # one shared activation module, as in the reference
+        for d in intermediate_dims:
+            layers += [HipLinear(width, d), act]
+            width = d
+        layers.append(HipLinear(width, num_labels))
+        super().__init__(*layers, **kwargs)
+        self.name = name

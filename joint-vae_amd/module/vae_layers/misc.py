@@ -1,0 +1,50 @@
+"""Small layer helpers (API of the reference's module/vae_layers/misc.py:6-39), executing on HIP kernels."""
+import torch
+from torch import nn
+
+from jvae_hip import ops
+
+
+def onehot_encoding(y, C):
+    """Integer labels (...,) -> float one-hot (..., C).  Pure indexing (no arithmetic): a scatter of ones."""
+    out = torch.zeros(*y.shape, C, device=y.device)
+    return out.scatter_(-1, y.unsqueeze(-1), 1)
+
+
+class HipReLU(nn.ReLU):
+    def forward(self, x):
+        return ops.act(x, ops.RELU)
+
+
+class HipSigmoid(nn.Sigmoid):
+    def forward(self, x):
+        return ops.act(x, ops.SIGMOID)
+
+
+class HipIdentity(nn.Identity):
+    def forward(self, x):
+        return ops.act(x, ops.IDENT)
+
+
+class _Unsupported(nn.Module):
+    def __init__(self, *a, **k):
+        raise NotImplementedError('leaky ReLU is outside the native-kernel contract of this build '
+                                  '(relu / sigmoid / linear are supported)')
+
+
+activation_layers = {'linear': HipIdentity, 'sigmoid': HipSigmoid, 'relu': HipReLU, 'leaky': _Unsupported}
+
+ACT_OF_MODULE = {HipReLU: ops.RELU, HipSigmoid: ops.SIGMOID, HipIdentity: ops.IDENT}
+
+
+def _no_activation(a):
+    return a
+
+
+class Reshape(nn.Module):
+    def __init__(self, output_shape):
+        super().__init__()
+        self.shape = output_shape
+
+    def forward(self, x):
+        return x.view(-1, *self.shape)

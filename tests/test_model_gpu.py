@@ -1,0 +1,153 @@
+"""End-to-end GPU parity of the drop-in model (cvae.ClassificationVariationalNetwork on HIP kernels):
+  * against the reference's own outputs (tests/golden/*.npz, produced by oracle/gen_golden.py) on every case,
+  * against the CPU oracle on larger seeded batches,
+  * size-independent properties at BASELINE.json's full batch (N=512).
+Tolerance (north_star): per-sample ELBO / KL / reconstruction within 1e-4 relative fp32."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import jvae_oracle as O
+from oracle.cases import CASES, get_case, full_config
+from oracle.det_init import det_inputs, load_det_state
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+RTOL = 1e-4
+
+
+def rel(a, b, floor=1e-30):
+    a = np.asarray(a.detach().double().cpu() if torch.is_tensor(a) else a, dtype=np.float64)
+    b = np.asarray(b.detach().double().cpu() if torch.is_tensor(b) else b, dtype=np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), floor))
+
+
+def dead_bias(key, state_keys):
+    parts = key.split('.')
+    if parts[-1] != 'bias' or not parts[-2].isdigit():
+        return False
+    return '.'.join(parts[:-2] + [str(int(parts[-2]) + 1), 'running_mean']) in set(state_keys)
+
+
+def build(case):
+    from cvae import ClassificationVariationalNetwork as Net
+    net = Net(**case['net'])
+    load_det_state(net, seed=0)
+    net.to(DEV)
+    net.train()
+    return net
+
+
+@pytest.mark.parametrize('name', list(CASES))
+def test_train_step_matches_reference_golden(name, golden_dir):
+    g = np.load(os.path.join(golden_dir, name + '.npz'))
+    case = get_case(name)
+    net = build(case)
+    kw = case['net']
+    uniform = kw['prior'].get('distribution') == 'uniform'
+    x, y, eps = det_inputs(case['N'], kw['input_shape'], kw['num_labels'], net.latent_sampling, kw['latent_dim'],
+                           uniform_eps=uniform)
+    x, y, eps = x.to(DEV), y.to(DEV), eps.to(DEV)
+    net.optimizer.zero_grad()
+    x_reco, y_est, losses, meas, mu, log_var, z = net.evaluate(
+        x, y, batch=0, with_beta=True, kl_var_weighting=case['kl_var_weighting'],
+        gamma_weighting=case['gamma_weighting'], z_output=True, epsilon=eps)
+    assert bool((y.cpu() == det_inputs(case['N'], kw['input_shape'], kw['num_labels'], 1, 1)[1]).all())   # labels bit-exact
+    assert rel(mu, g['mu']) < RTOL and rel(log_var, g['log_var']) < RTOL and rel(z, g['z']) < RTOL
+    assert rel(x_reco, g['x_reco']) < RTOL
+    assert rel(y_est, g['y_est']) < 5e-4
+    for k in [f[5:] for f in g.files if f.startswith('loss.')]:
+        if np.abs(g['loss.' + k]).max() == 0:
+            assert float(losses[k].abs().max()) == 0.
+            continue
+        assert rel(losses[k], g['loss.' + k]) < RTOL, k
+    for k in [f[8:] for f in g.files if f.startswith('measure.')]:
+        ref = float(g['measure.' + k])
+        assert abs(meas[k] - ref) <= 2e-4 * max(1.0, abs(ref)), (k, meas[k], ref)
+    losses['total'].mean().backward()
+    tot = float(g['total_grad_norm'])
+    got = {n: p.grad for n, p in net.named_parameters() if p.grad is not None}
+    assert set(g['grad_names']) <= set(got)
+    for k in g['grad_names']:
+        ref = float(g['gnorm.' + k])
+        assert abs(float(got[k].double().norm()) - ref) <= 3e-4 * max(ref, 1e-3 * tot), k
+        if 'grad.' + k in g.files and not dead_bias(k, g['state_keys']):
+            assert rel(got[k], g['grad.' + k], floor=1e-6 * tot) < 1e-3, k
+    net.optimizer.clip(net.parameters())
+    assert abs(float(net.optimizer.grad_norm()) - tot) <= 1e-4 * tot
+    net.optimizer.step()
+    params = dict(net.named_parameters())
+    for k in g['param_names']:
+        if 'param_after.' + k in g.files and not dead_bias(k, g['state_keys']):
+            assert rel(params[k], g['param_after.' + k]) < 2e-5, k
+    bufs = dict(net.named_buffers())
+    for f in g.files:
+        if f.startswith('buffer_after.'):
+            assert rel(bufs[f[13:]].double(), g[f]) < 2e-5, f
+
+
+@pytest.mark.parametrize('which,N', [(2, 64), (3, 48)])
+def test_three_steps_against_oracle(which, N):
+    """Three consecutive optimiser steps on a larger batch: losses track the CPU oracle step by step."""
+    case = full_config(which, N)
+    kw = case['net']
+    net = build(case)
+    sp = O.make_spec(**kw)
+    P = O.init_state(sp, seed=0)
+    opt = O.AdamState(sp)
+    meas = None
+    for step in range(3):
+        x, y, eps = det_inputs(N, kw['input_shape'], kw['num_labels'], 1, kw['latent_dim'], seed=100 + 10 * step)
+        out, grads, gn = O.train_step(sp, P, opt, x, y, eps)
+        losses, meas = net.train_step(x.to(DEV), y.to(DEV), batch=step, current_measures=meas, epsilon=eps.to(DEV))
+        for k in ('total', 'cross_x', 'kl', 'zdist', 'var_kl', 'wmse', 'dzdist'):
+            assert rel(losses[k], out[2][k]) < (RTOL if step == 0 else 5e-4), (step, k)
+        assert abs(float(net.optimizer.grad_norm()) - gn) < 2e-4 * gn
+
+
+def test_full_batch_properties():
+    """BASELINE config 2 at N=512: properties that do not need the oracle at full size."""
+    case = full_config(2, 512)
+    kw = case['net']
+    net = build(case)
+    x, y, eps = det_inputs(512, kw['input_shape'], 10, 1, 64, seed=7)
+    x, y, eps = x.to(DEV), y.to(DEV), eps.to(DEV)
+    _, _, l1, _ = net.evaluate(x, y, with_beta=True, epsilon=eps)
+    # (1) the ELBO decomposes exactly: total = cross_x + beta * kl, kl = (zdist + var_kl) / 2
+    assert rel(l1['total'], l1['cross_x'] + l1['kl']) < 1e-6
+    assert rel(l1['kl'], 0.5 * (l1['zdist'] + l1['var_kl'])) < 1e-5
+    # (2) a permutation of the batch permutes the per-sample losses (BatchNorm statistics are symmetric)
+    perm = torch.randperm(512, device=DEV)
+    _, _, l2, _ = net.evaluate(x[perm], y[perm], with_beta=True, epsilon=eps[:, perm])
+    assert rel(l2['total'], l1['total'][perm]) < 2e-5
+    assert rel(l2['kl'], l1['kl'][perm]) < 2e-5
+    # (3) eps = 0 makes both decoded rows identical (row 0 is the mean path)
+    xr, _, _, _ = net.evaluate(x, y, with_beta=True, epsilon=torch.zeros_like(eps))
+    assert rel(xr[1], xr[0]) < 1e-6
+    # (4) a step lowers the loss on the same batch (lr 1e-3, clip 100)
+    before = float(l1['total'].mean())
+    for _ in range(5):
+        net.train_step(x, y, epsilon=eps)
+    _, _, l3, _ = net.evaluate(x, y, with_beta=True, epsilon=eps)
+    assert float(l3['total'].mean()) < before
+    assert all(bool(torch.isfinite(p).all()) for p in net.parameters())
+
+
+def test_checkpoint_roundtrip(tmp_path):
+    case = get_case('c2_n8')
+    kw = case['net']
+    net = build(case)
+    x, y, eps = det_inputs(8, kw['input_shape'], 10, 1, 64)
+    x, y, eps = x.to(DEV), y.to(DEV), eps.to(DEV)
+    net.train_step(x, y, epsilon=eps)
+    net.save(str(tmp_path))
+    assert sorted(os.listdir(tmp_path)) == ['history.json', 'optimizer.pth', 'params.json', 'state.pth', 'train_params.json']
+    other = build(case)
+    other.load_weights(str(tmp_path))
+    la, _ = net.train_step(x, y, epsilon=eps)
+    lb, _ = other.train_step(x, y, epsilon=eps)
+    assert rel(la['total'], lb['total']) < 1e-6
+    for (n1, p1), (n2, p2) in zip(net.named_parameters(), other.named_parameters()):
+        assert rel(p1, p2, floor=1e-12) < 1e-5, n1

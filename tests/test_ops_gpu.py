@@ -1,0 +1,249 @@
+"""GPU parity of every HIP op (through the C ABI) against a plain PyTorch-CPU fp32 reference of the same op.
+Tolerances are stated per test; fp32 MFMA accumulates in k order, so 1e-4 relative to the output scale is
+the bar (north_star: 1e-4 relative fp32)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = 'cuda'
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / max(float(b.abs().max()), 1e-30))
+
+
+def test_library_loaded_on_gpu():
+    from jvae_hip import lib
+    assert lib.load().jvae_version()
+    assert torch.cuda.is_available()
+
+
+@pytest.mark.parametrize('M,N,K', [(512, 128, 800), (1024, 4096, 64), (37, 75, 33), (200, 3136, 2048), (64, 64, 1)])
+@pytest.mark.parametrize('layout', ['nn', 'nt', 'tn', 'tt'])
+def test_gemm_layouts(M, N, K, layout):
+    from jvae_hip import ops
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    A = torch.randn(M, K, generator=g)
+    B = torch.randn(K, N, generator=g)
+    bias = torch.randn(N, generator=g)
+    ref = A @ B + bias
+    Ad = (A if layout[0] == 'n' else A.t().contiguous()).to(DEV)
+    Bd = (B if layout[1] == 'n' else B.t().contiguous()).to(DEV)
+    sA = (K, 1, 0) if layout[0] == 'n' else (1, M, 0)
+    sB = (N, 1, 0) if layout[1] == 'n' else (1, K, 0)
+    C = torch.empty(M, N, device=DEV)
+    ops.gemm(M, N, K, Ad, sA, Bd, sB, C, (N, 1, 0), bias=bias.to(DEV), bias_mode=1)
+    assert rel(C, ref) < 2e-5
+    # split-K with atomics on a pre-zeroed C
+    C2 = torch.zeros(M, N, device=DEV)
+    ops.gemm(M, N, K, Ad, sA, Bd, sB, C2, (N, 1, 0), bias=bias.to(DEV), bias_mode=1, splitk=4)
+    assert rel(C2, ref) < 2e-5
+
+
+CONVS = [  # (cin, cout, k, s, p, op, transposed, H)   every layer geometry of conv32 / deconv32 / conv32+ / deconv32+
+    (3, 32, 5, 1, 2, 0, False, 32), (32, 32, 5, 2, 2, 0, False, 32), (32, 64, 5, 1, 2, 0, False, 16),
+    (64, 64, 5, 2, 2, 0, False, 16), (64, 200, 7, 1, 0, 0, False, 8), (128, 200, 3, 1, 0, 0, False, 8),
+    (64, 64, 8, 1, 0, 0, True, 1), (64, 64, 5, 1, 2, 0, True, 8), (64, 64, 5, 2, 2, 1, True, 8),
+    (64, 32, 5, 1, 2, 0, True, 16), (32, 32, 5, 2, 2, 1, True, 16), (32, 32, 5, 1, 2, 0, True, 32),
+    (32, 3, 5, 1, 2, 0, False, 32), (8, 128, 4, 1, 0, 0, True, 5), (5, 7, 3, 1, 1, 0, False, 9),
+]
+
+
+@pytest.mark.parametrize('cin,cout,k,s,p,op,tr,H', CONVS)
+@pytest.mark.parametrize('N', [3, 8])
+def test_conv_all_directions(cin, cout, k, s, p, op, tr, H, N):
+    from jvae_hip import ops
+    g = torch.Generator().manual_seed(cin * 131 + cout * 17 + k + H)
+    x = torch.randn(N, cin, H, H, generator=g)
+    wshape = (cin, cout, k, k) if tr else (cout, cin, k, k)
+    w = torch.randn(wshape, generator=g) / math.sqrt(cin * k * k)
+    b = torch.randn(cout, generator=g)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    if tr:
+        yr = F.conv_transpose2d(xr, wr, br, stride=s, padding=p, output_padding=op)
+    else:
+        yr = F.conv2d(xr, wr, br, stride=s, padding=p)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    spec = ops.ConvSpec(cin, cout, k, s, p, op, tr)
+    xd, wd, bd = (t.to(DEV).requires_grad_(True) for t in (x, w, b))
+    yd = ops.conv2d(xd, wd, bd, spec)
+    assert yd.shape == yr.shape
+    assert rel(yd, yr) < 2e-5
+    yd.backward(gy.to(DEV))
+    assert rel(xd.grad, xr.grad) < 2e-5
+    assert rel(wd.grad, wr.grad) < 5e-5
+    assert rel(bd.grad, br.grad) < 2e-5
+
+
+@pytest.mark.parametrize('N,C,P,relu', [(8, 32, 1024, True), (5, 3, 1024, False), (16, 200, 4, True), (2, 64, 63, True)])
+def test_batchnorm_train(N, C, P, relu):
+    from jvae_hip import ops
+    g = torch.Generator().manual_seed(N + C + P)
+    x = torch.randn(N, C, P, 1, generator=g) * 2 + 3
+    gamma = torch.rand(C, generator=g) + 0.5
+    beta = torch.randn(C, generator=g)
+    rm, rv = torch.randn(C, generator=g), torch.rand(C, generator=g) + 0.5
+    xr, gr, br = (t.clone().requires_grad_(True) for t in (x, gamma, beta))
+    rmr, rvr = rm.clone(), rv.clone()
+    yr = F.batch_norm(xr, rmr, rvr, gr, br, True, 0.1, 1e-5)
+    if relu:
+        yr = torch.relu(yr)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    xd, gd, bd = (t.to(DEV).requires_grad_(True) for t in (x, gamma, beta))
+    rmd, rvd = rm.to(DEV), rv.to(DEV)
+    nbt = torch.zeros((), dtype=torch.int64, device=DEV)
+    yd = ops.batchnorm_act(xd, gd, bd, rmd, rvd, nbt, True, relu)
+    assert rel(yd, yr) < 1e-5
+    assert rel(rmd, rmr) < 1e-6 and rel(rvd, rvr) < 1e-5 and int(nbt) == 1
+    yd.backward(gy.to(DEV))
+    assert rel(xd.grad, xr.grad) < 1e-4
+    assert rel(gd.grad, gr.grad) < 1e-4 and rel(bd.grad, br.grad) < 1e-4
+    # eval mode uses the running statistics
+    ye = ops.batchnorm_act(xd.detach(), gd.detach(), bd.detach(), rmd, rvd, nbt, False, relu)
+    yer = F.batch_norm(x, rmr, rvr, gamma, beta, False, 0.1, 1e-5)
+    assert rel(ye, torch.relu(yer) if relu else yer) < 1e-5
+
+
+@pytest.mark.parametrize('act', [0, 1, 2])
+def test_linear(act):
+    from jvae_hip import ops
+    g = torch.Generator().manual_seed(act)
+    x = torch.randn(2, 48, 800, generator=g)
+    w = torch.randn(64, 800, generator=g) / 28
+    b = torch.randn(64, generator=g)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    yr = F.linear(xr, wr, br)
+    yr = [lambda t: t, torch.relu, torch.sigmoid][act](yr)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    xd, wd, bd = (t.to(DEV).requires_grad_(True) for t in (x, w, b))
+    yd = ops.linear(xd, wd, bd, act)
+    assert rel(yd, yr) < 2e-5
+    yd.backward(gy.to(DEV))
+    assert rel(xd.grad, xr.grad) < 2e-5 and rel(wd.grad, wr.grad) < 2e-5 and rel(bd.grad, br.grad) < 2e-5
+
+
+@pytest.mark.parametrize('prior,var_dim', [('gaussian', 'scalar'), ('gaussian', 'diag'), ('gaussian', 'full'),
+                                           ('tilted', 'scalar'), ('uniform', 'scalar')])
+@pytest.mark.parametrize('K,L', [(64, 1), (200, 2), (16, 1)])
+def test_latent_against_oracle(prior, var_dim, K, L):
+    """clip + reparameterise + KL, forward and backward, vs the CPU oracle's prior_kl (oracle/jvae_oracle.py)."""
+    from jvae_hip import ops
+    from oracle import jvae_oracle as O
+    from oracle.det_init import det_tensor
+    N, C = 12, 7
+    g = torch.Generator().manual_seed(K + L)
+    mu = torch.randn(N, K, generator=g)
+    lv_raw = torch.randn(N, K, generator=g) * 2
+    lv_raw[0, 0], lv_raw[1, 1] = 25., -30.           # exercise the +-20 clip and its zero sub-gradient
+    eps = torch.randn(L + 1, N, K, generator=g)
+    eps[0] = 0
+    y = torch.randint(0, C, (N,), generator=g)
+    means = det_tensor('encoder.prior.mean', (C, K))
+    T = det_tensor('encoder.prior._var_parameter', {'scalar': (C,), 'diag': (C, K), 'full': (C, K, K)}[var_dim])
+    w = 0.3
+    tau = {'tilted': 5., 'uniform': 1.5}.get(prior, 0.)
+    sp = dict(K=K, prior=dict(distribution=prior, tau=tau, var_dim=var_dim))
+    mr, lr_, er, meansr, Tr = (t.clone().requires_grad_(True) for t in (mu, lv_raw, eps, means, T))
+    P = {'encoder.prior.mean': meansr, 'encoder.prior._var_parameter': Tr}
+    lvc = torch.clip(lr_, -20, 20)
+    zr = mr + torch.exp(0.5 * lvc) * er
+    kd = O.prior_kl(sp, P, mr, lvc, y, w)
+    gz = torch.randn(zr.shape, generator=g)
+    gk, gd, gv = (torch.randn(N, generator=g) for _ in range(3))
+    obj = (zr * gz).sum() + (kd['kl'] * gk).sum() + (kd['distance'] * gd).sum() + (kd['var_kl'] * gv).sum()
+    obj.backward()
+    alpha = 0.
+    if prior == 'uniform':
+        phi = 0.5 * (1 + math.erf(tau / math.sqrt(2)))
+        alpha = math.log(2 * tau) - math.log(2 * phi - 1)
+    md, ld, meansd, Td = (t.to(DEV).requires_grad_(True) for t in (mu, lv_raw, means, T))
+    lv, z, kl, zd, vkl, dzd = ops.latent(md, ld, eps.to(DEV), y.to(DEV), meansd, Td, prior=prior, var_dim=var_dim,
+                                         tau=tau, alpha=alpha, w=w)
+    assert rel(lv, lvc) < 1e-6 and rel(z, zr) < 1e-5
+    assert rel(kl, kd['kl']) < 2e-5 and rel(zd, kd['distance']) < 2e-5
+    if prior != 'tilted':
+        assert rel(vkl, kd['var_kl']) < 2e-5
+    dm = means.mean(0)
+    dz_ref = (mu - dm).pow(2).sum(1) + (means.pow(2).sum(1).mean(0) - dm.pow(2).sum())
+    assert rel(dzd, dz_ref) < 2e-5
+    objd = (z * gz.to(DEV)).sum() + (kl * gk.to(DEV)).sum() + (zd * gd.to(DEV)).sum() + (vkl * gv.to(DEV)).sum()
+    objd.backward()
+    assert rel(md.grad, mr.grad) < 5e-5
+    assert rel(ld.grad, lr_.grad) < 5e-5
+    assert float(ld.grad[0, 0]) == 0. and float(ld.grad[1, 1]) == 0.
+    assert rel(meansd.grad, meansr.grad) < 5e-5
+    if var_dim != 'scalar':
+        assert rel(Td.grad, Tr.grad) < 5e-5
+
+
+@pytest.mark.parametrize('is_log', [True, False])
+def test_recon(is_log):
+    from jvae_hip import ops
+    g = torch.Generator().manual_seed(5)
+    L, N, D = 2, 6, 3072
+    xr_ = torch.randn(L + 1, N, 3, 32, 32, generator=g)
+    x = torch.rand(N, 3, 32, 32, generator=g)
+    s = torch.tensor([0.3 if is_log else 0.7])
+    a, sr = xr_.clone().requires_grad_(True), s.clone().requires_grad_(True)
+    sig = sr.exp() if is_log else sr
+    ref = ((a[1:] / sig - x / sig) ** 2).reshape(L, N, -1).mean(-1)
+    gw = torch.randn(L, N, generator=g)
+    (ref * gw).sum().backward()
+    ad, sd = xr_.to(DEV).requires_grad_(True), s.to(DEV).requires_grad_(True)
+    out = ops.recon_wmse(ad, x.to(DEV), sd, is_log)
+    assert rel(out, ref) < 1e-5
+    (out * gw.to(DEV)).sum().backward()
+    assert rel(ad.grad, a.grad) < 1e-5 and float(ad.grad[0].abs().max()) == 0.
+    assert rel(sd.grad, sr.grad) < 1e-5
+
+
+def test_cross_entropy():
+    from jvae_hip import ops
+    g = torch.Generator().manual_seed(9)
+    L, N, C = 3, 10, 100
+    lg = torch.randn(L, N, C, generator=g) * 3
+    y = torch.randint(0, C, (N,), generator=g)
+    a = lg.clone().requires_grad_(True)
+    ref = F.cross_entropy(a.reshape(-1, C), y.repeat(L), reduction='none').reshape(L, N)
+    gw = torch.randn(L, N, generator=g)
+    (ref * gw).sum().backward()
+    d = lg.to(DEV).requires_grad_(True)
+    out = ops.cross_entropy_rows(d, y.to(DEV))
+    assert rel(out, ref) < 1e-5
+    (out * gw.to(DEV)).sum().backward()
+    assert rel(d.grad, a.grad) < 1e-5
+
+
+def test_clip_and_adam_against_torch():
+    from jvae_hip import ops
+    g = torch.Generator().manual_seed(3)
+    n = 100003
+    p0 = torch.randn(n, generator=g)
+    pr = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([pr], lr=1e-3, weight_decay=3e-5)
+    pd = torch.zeros(n + 1, device=DEV)[:n]      # deliberately a 16-byte aligned base
+    pd.copy_(p0)
+    m, v = torch.zeros_like(pd), torch.zeros_like(pd)
+    acc = torch.zeros(1, device=DEV)
+    for step in range(1, 4):
+        gr = torch.randn(n, generator=g) * (50 if step == 1 else 0.01)     # step 1 clips, later ones do not
+        pr.grad = gr.clone()
+        tn = torch.nn.utils.clip_grad_norm_([pr], 100.)
+        opt.step()
+        gd = gr.to(DEV)
+        ops.sqnorm_accum(gd, acc, reset=True)
+        assert abs(float(acc.sqrt()) - float(tn)) < 1e-4 * float(tn)
+        flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+        ops.adam_step(pd, gd, m, v, 1e-3, 0.9, 0.999, 1e-8, 3e-5, step, max_norm=100., sqnorm=acc, flag=flag)
+        assert rel(pd, pr) < 1e-6 and int(flag) == 0
+    gd = torch.full((n,), float('nan'), device=DEV)
+    ops.adam_step(pd, gd, m, v, 1e-3, 0.9, 0.999, 1e-8, 3e-5, 4, flag=flag)
+    assert int(flag) == 1
