@@ -1,0 +1,158 @@
+#!/usr/bin/env python3
+"""Benchmark of the per-batch joint-CVAE training step on MI355X (BASELINE.json metric: training images/s).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = cvae.py:2429-2461 of the reference on one synthetic batch already resident in HBM:
+zero_grad -> evaluate(x, y, with_beta=True) -> total.mean().backward() -> clip_grad_norm_(100) -> Adam, with the
+reparameterisation noise drawn on the device.  Workload = BASELINE.json configs[1] (CIFAR-10 conv CVAE, bs=512
+per GPU, fp32).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+for p in (REPO, os.path.join(REPO, 'joint-vae_amd')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+FLOP_PER_IMAGE = 923.2e6          # conv/linear MACs*2, fwd + bwd, L=1 (decoder runs on 2N latents)
+MFMA_F32_PEAK = 157.3e12          # MI355X dense fp32 MFMA, MI355X_MICROARCH.md
+BATCH_PER_GPU = 512
+
+
+def build_model(device):
+    from cvae import ClassificationVariationalNetwork as Net
+    from oracle.cases import full_config       # constructor kwargs only (data, not the oracle's arithmetic)
+    torch.manual_seed(0)
+    net = Net(**full_config(2, BATCH_PER_GPU)['net'])
+    net.to(device)
+    net.train()
+    return net
+
+
+def dominant_kernel_roofline(device, reps=20):
+    """Largest layer of the step (imager.15: ConvTranspose2d 32->32 5x5 on 1024x32x32x32, 53.69 GFLOP fwd) timed
+    with HIP events on the launch stream."""
+    from jvae_hip import ops
+    N, C, H = 2 * BATCH_PER_GPU, 32, 32
+    spec = ops.ConvSpec(C, C, 5, 1, 2, 0, transposed=True)
+    x = torch.randn(N, C, H, H, device=device)
+    w = torch.randn(C, C, 5, 5, device=device) * 0.03
+    b = torch.zeros(C, device=device)
+    for _ in range(3):
+        ops.conv_fwd_raw(x, w, b, spec)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        ops.conv_fwd_raw(x, w, b, spec)
+    e1.record()
+    torch.cuda.synchronize()
+    sec = e0.elapsed_time(e1) * 1e-3 / reps
+    flops = 2.0 * N * H * H * C * C * 25
+    return {'bound': 'mfma', 'kernel': 'conv2d_fwd imager.15 (ConvT 32->32 5x5 s1, 1024x32x32x32)',
+            'achieved': flops / sec / 1e12, 'peak': MFMA_F32_PEAK / 1e12, 'unit': 'TFLOP/s',
+            'frac': flops / sec / MFMA_F32_PEAK, 'traffic': None, 'launch_ms': sec * 1e3}
+
+
+def cpu_baseline(max_seconds=25.0):
+    """The CPU oracle (PyTorch-CPU restatement of the reference step, pinned to the reference's goldens) on the
+    host cores, bounded sample of the same workload."""
+    from oracle import jvae_oracle as O
+    from oracle.cases import full_config
+    from oracle.det_init import det_inputs
+    kw = full_config(2, BATCH_PER_GPU)['net']
+    sp = O.make_spec(**kw)
+    P = O.init_state(sp, seed=0)
+    opt = O.AdamState(sp)
+    x, y, eps = det_inputs(BATCH_PER_GPU, kw['input_shape'], 10, 1, 64, seed=1234)
+    O.train_step(sp, P, opt, x, y, eps)                       # warm-up
+    t0 = time.time()
+    n = 0
+    while n < 12 and time.time() - t0 < max_seconds:
+        O.train_step(sp, P, opt, x, y, eps)
+        n += 1
+    dt = time.time() - t0
+    return {'value': n * BATCH_PER_GPU / dt, 'unit': 'images/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': f'{n} train steps of bs={BATCH_PER_GPU} (config 2) with the PyTorch-CPU oracle, '
+                      f'{os.cpu_count()} logical CPUs visible'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    a = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        torch.cuda.set_device(local)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+    device = torch.device('cuda', local)
+    torch.cuda.set_device(device)
+
+    net = build_model(device)
+    if world > 1:
+        net.optimizer.set_distributed(world)
+    g = torch.Generator(device=device).manual_seed(1234 + rank)
+    x = torch.rand(BATCH_PER_GPU, 3, 32, 32, device=device, generator=g)
+    y = torch.randint(0, 10, (BATCH_PER_GPU,), device=device, generator=g)
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    meas = None
+    for i in range(a.warmup):
+        _, meas = net.train_step(x, y, batch=i, current_measures=meas)
+    sync()
+    t0 = time.time()
+    for i in range(a.steps):
+        losses, meas = net.train_step(x, y, batch=i, current_measures=meas)
+    sync()
+    dt = time.time() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    value = world * BATCH_PER_GPU * a.steps / dt
+
+    if rank == 0:
+        out = {'metric': 'training_images_per_sec', 'value': value, 'unit': 'images/s', 'n_gpus': world,
+               'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': dt / a.steps * 1e3, 'higher_is_better': True,
+               'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+               'config': {'workload': 'BASELINE configs[1]: CIFAR-10 3x32x32 conv CVAE (conv32/deconv32, latent_dim=64, '
+                                      'C=10, batch_norm=both, learned sigma, L=1), bs=512 per GPU, fp32, '
+                                      'fwd+bwd+clip+Adam',
+                          'global_batch': world * BATCH_PER_GPU, 'parallelism': f'dp{world}',
+                          'bn_statistics': 'per-rank (local)'},
+               'step_mfma_frac': value / world * FLOP_PER_IMAGE / MFMA_F32_PEAK,
+               'final_loss': float(losses['total'].mean())}
+        out['roofline'] = dominant_kernel_roofline(device)
+        if world == 1 and not a.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -229,6 +229,17 @@ def init_state(sp, seed=0):
 
 
 # ----------------------------------------------------------------------------------------------- forward
+TAPE = None        # debugging aid: set to a list to record (name, tensor) of every stack intermediate
+
+
+def _tape(name, t):
+    if TAPE is not None:
+        if t.requires_grad:
+            t.retain_grad()
+        TAPE.append((name, t))
+    return t
+
+
 def run_stack(P, prefix, layers, bn, x, last_act, training=True, momentum=0.1, eps=1e-5):
     """conv.py:186-230: (de)conv -> [BatchNorm2d] -> ReLU; the LAST activation is `last_act` for upsamplers."""
     i = 0
@@ -238,6 +249,7 @@ def run_stack(P, prefix, layers, bn, x, last_act, training=True, momentum=0.1, e
             x = F.conv2d(x, w, b, stride=d['s'], padding=d['p'])
         else:
             x = F.conv_transpose2d(x, w, b, stride=d['s'], padding=d['p'], output_padding=d['op'])
+        _tape(f'{prefix}.{i}', x)
         i += 1
         if bn:
             x = F.batch_norm(x, P[f'{prefix}.{i}.running_mean'], P[f'{prefix}.{i}.running_var'],
@@ -246,7 +258,7 @@ def run_stack(P, prefix, layers, bn, x, last_act, training=True, momentum=0.1, e
                 P[f'{prefix}.{i}.num_batches_tracked'] += 1
             i += 1
         act = 'relu' if (last_act is None or li < len(layers) - 1) else last_act
-        x = _act(x, act)
+        x = _tape(f'{prefix}.{i}', _act(x, act))
         i += 1
     return x
 
