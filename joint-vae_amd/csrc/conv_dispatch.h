@@ -14,6 +14,25 @@ int jvae_fold_wgrad(const ConvGeom& g, const float* xb, const float* ys, float* 
                     float* ws, size_t ws_bytes, hipStream_t st);
 int jvae_channel_sum(const float* t, float* out, int N, int C, int P, int accumulate, hipStream_t st);
 
+// conv_mfma.hip: implicit-GEMM 5x5 kernels (forward-type)
+bool jvae_conv5_fwd_ok(int Cin, int H, int W, int Cout, int OH, int OW, int S, int P);
+size_t jvae_conv5_pack_floats(int Cin, int Cout);
+int jvae_conv5_fwd(const float* in, const float* w, int swap, int flip, const float* bias, float* out,
+                   int N, int Cin, int H, int W, int Cout, int OW, int S, int P, float* ws, hipStream_t st);
+
+int jvae_conv5_pack(const float* w, float* wp, int C, int O, int swap, int flip, hipStream_t st);
+
+// conv_t2_mfma.hip: stride-2 transposed 5x5 (4-phase): small (C,HS,WS) -> big (O,2HS,2WS), wpacked = (C,25,O)
+bool jvae_convt2_ok(int C, int HS, int WS, int O, int HB, int WB, int KH, int KW, int S, int P);
+int jvae_convt2(const float* in, const float* wpacked, const float* bias, float* out, int N, int C, int WS, int O,
+                hipStream_t st);
+
+// conv_wgrad_mfma.hip: dW[a][b][tap] = sum Ps[n][a][u][v] Q[n][b][u*S+kh-P][v*S+kw-P]
+bool jvae_conv5_wgrad_ok(int Ca, int HS, int WS, int Cb, int HB, int WB, int S, int P);
+size_t jvae_conv5_wgrad_ws_floats(int N, int Ca, int Cb, int S, int WS);
+int jvae_conv5_wgrad(const float* ps, const float* q, float* dw, int accumulate, int swapflip,
+                     int N, int Ca, int WS, int Cb, int S, int P, float* ws, hipStream_t st);
+
 // conv_dispatch.hip
 size_t jvae_conv_ws(const ConvGeom& g, int transposed);
 int jvae_conv_fwd(const ConvGeom& g, int transposed, const float* x, const float* w, const float* bias, float* y,

@@ -1,26 +1,93 @@
 // Direction -> primitive mapping (see conv_generic.hip header) and fast-path selection.
+//
+// Fast paths (conv_mfma.hip) exist for the 5x5 "same-size / half-size" layers that carry >95 % of the FLOPs of
+// conv32 / deconv32; everything else (7x7, 8x8, 3x3, 4x4 heads, odd sizes) takes the unfold + GEMM path.
 #include "common.h"
 #include "conv_dispatch.h"
 
+namespace {
+
+inline bool is5(const ConvGeom& g) { return g.KH == 5 && g.KW == 5; }
+
+// conv forward / transposed dgrad:  big (Cb,Hb,Wb) --conv S,P--> small (Cs,Hs,Ws)
+inline bool fold_fwd_fast(const ConvGeom& g) {
+    return is5(g) && jvae_conv5_fwd_ok(g.Cb, g.Hb, g.Wb, g.Cs, g.Hs, g.Ws, g.S, g.P);
+}
+// stride-1 conv dgrad / stride-1 transposed forward: small --conv 1, 4-P, flipped--> big
+inline bool fold_bwd_fast_s1(const ConvGeom& g) {
+    return is5(g) && g.S == 1 && g.P <= 4 && jvae_conv5_fwd_ok(g.Cs, g.Hs, g.Ws, g.Cb, g.Hb, g.Wb, 1, 4 - g.P);
+}
+
+// stride-2 transposed forward / stride-2 conv dgrad: small -> big by the 4-phase kernel
+inline bool fold_bwd_fast_s2(const ConvGeom& g) {
+    return jvae_convt2_ok(g.Cs, g.Hs, g.Ws, g.Cb, g.Hb, g.Wb, g.KH, g.KW, g.S, g.P);
+}
+inline int run_t2(const ConvGeom& g, const float* small, const float* w, const float* bias, float* big, float* ws,
+                  hipStream_t st) {
+    int rc = jvae_conv5_pack(w, ws, g.Cs, g.Cb, 1, 0, st);
+    if (rc) return rc;
+    return jvae_convt2(small, ws, bias, big, g.N, g.Cs, g.Ws, g.Cb, st);
+}
+
+// wgrad: role swap when the folded side has very few channels (Conv 32->3): see conv_wgrad_mfma.hip
+inline bool wgrad_swap(const ConvGeom& g) { return g.S == 1 && g.Cs < 16 && g.Cb >= 16 && g.Hs == g.Hb; }
+inline bool wgrad_fast(const ConvGeom& g) {
+    if (!is5(g)) return false;
+    if (wgrad_swap(g)) return jvae_conv5_wgrad_ok(g.Cb, g.Hb, g.Wb, g.Cs, g.Hs, g.Ws, 1, 4 - g.P);
+    return jvae_conv5_wgrad_ok(g.Cs, g.Hs, g.Ws, g.Cb, g.Hb, g.Wb, g.S, g.P);
+}
+inline size_t wgrad_ws_floats(const ConvGeom& g) {
+    if (wgrad_swap(g)) return jvae_conv5_wgrad_ws_floats(g.N, g.Cb, g.Cs, 1, g.Wb);
+    return jvae_conv5_wgrad_ws_floats(g.N, g.Cs, g.Cb, g.S, g.Ws);
+}
+
+}  // namespace
+
 size_t jvae_conv_ws(const ConvGeom& g, int transposed) {
     (void)transposed;
-    return jvae_conv_generic_ws(g);
+    size_t a = jvae_conv_generic_ws(g);
+    size_t b = is5(g) ? 4 * jvae_conv5_pack_floats(g.Cb, g.Cs) : 0;
+    size_t c = wgrad_fast(g) ? 4 * wgrad_ws_floats(g) : 0;
+    if (b > a) a = b;
+    return a > c ? a : c;
 }
 
 int jvae_conv_fwd(const ConvGeom& g, int transposed, const float* x, const float* w, const float* bias, float* y,
                   float* ws, size_t ws_bytes, hipStream_t st) {
-    if (!transposed) return jvae_fold_fwd(g, x, w, bias, y, ws, ws_bytes, st);
+    if (!transposed) {
+        if (fold_fwd_fast(g) && ws_bytes >= 4 * jvae_conv5_pack_floats(g.Cb, g.Cs))
+            return jvae_conv5_fwd(x, w, 0, 0, bias, y, g.N, g.Cb, g.Hb, g.Wb, g.Cs, g.Ws, g.S, g.P, ws, st);
+        return jvae_fold_fwd(g, x, w, bias, y, ws, ws_bytes, st);
+    }
+    if (fold_bwd_fast_s1(g) && ws_bytes >= 4 * jvae_conv5_pack_floats(g.Cs, g.Cb))
+        return jvae_conv5_fwd(x, w, 1, 1, bias, y, g.N, g.Cs, g.Hs, g.Ws, g.Cb, g.Wb, 1, 4 - g.P, ws, st);
+    if (fold_bwd_fast_s2(g) && ws_bytes >= 4 * jvae_conv5_pack_floats(g.Cs, g.Cb)) return run_t2(g, x, w, bias, y, ws, st);
     return jvae_fold_bwd(g, x, w, bias, y, ws, ws_bytes, st);
 }
 
 int jvae_conv_dgrad(const ConvGeom& g, int transposed, const float* dy, const float* w, float* dx,
                     float* ws, size_t ws_bytes, hipStream_t st) {
-    if (!transposed) return jvae_fold_bwd(g, dy, w, nullptr, dx, ws, ws_bytes, st);
+    if (!transposed) {
+        if (fold_bwd_fast_s1(g) && ws_bytes >= 4 * jvae_conv5_pack_floats(g.Cs, g.Cb))
+            return jvae_conv5_fwd(dy, w, 1, 1, nullptr, dx, g.N, g.Cs, g.Hs, g.Ws, g.Cb, g.Wb, 1, 4 - g.P, ws, st);
+        if (fold_bwd_fast_s2(g) && ws_bytes >= 4 * jvae_conv5_pack_floats(g.Cs, g.Cb))
+            return run_t2(g, dy, w, nullptr, dx, ws, st);
+        return jvae_fold_bwd(g, dy, w, nullptr, dx, ws, ws_bytes, st);
+    }
+    if (fold_fwd_fast(g) && ws_bytes >= 4 * jvae_conv5_pack_floats(g.Cb, g.Cs))
+        return jvae_conv5_fwd(dy, w, 0, 0, nullptr, dx, g.N, g.Cb, g.Hb, g.Wb, g.Cs, g.Ws, g.S, g.P, ws, st);
     return jvae_fold_fwd(g, dy, w, nullptr, dx, ws, ws_bytes, st);
 }
 
 int jvae_conv_wgrad(const ConvGeom& g, int transposed, const float* x, const float* dy, float* dw,
                     float* ws, size_t ws_bytes, hipStream_t st) {
-    if (!transposed) return jvae_fold_wgrad(g, x, dy, dw, ws, ws_bytes, st);
-    return jvae_fold_wgrad(g, dy, x, dw, ws, ws_bytes, st);
+    const float* big = transposed ? dy : x;       // unfolded side
+    const float* small = transposed ? x : dy;     // folded side
+    if (wgrad_fast(g) && ws_bytes >= 4 * wgrad_ws_floats(g)) {
+        // the generic entry point zeroed dw (or holds the value to accumulate onto): always accumulate here
+        if (wgrad_swap(g))
+            return jvae_conv5_wgrad(big, small, dw, 1, 1, g.N, g.Cb, g.Wb, g.Cs, 1, 4 - g.P, ws, st);
+        return jvae_conv5_wgrad(small, big, dw, 1, 0, g.N, g.Cs, g.Ws, g.Cb, g.S, g.P, ws, st);
+    }
+    return jvae_fold_wgrad(g, big, small, dw, ws, ws_bytes, st);
 }

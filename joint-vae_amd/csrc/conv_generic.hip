@@ -70,19 +70,32 @@ __global__ __launch_bounds__(256) void fold_kernel(const float* __restrict__ col
     }
 }
 
-// out[c] (+)= sum_{n,q} t[n][c][q]      (bias gradients; reference: autograd of the conv bias add)
+// out[c] += sum_{n in split, q} t[n][c][q]   (bias gradients; reference: autograd of the conv bias add).
+// grid (C, nsplit): each block reduces a slice of images with 16-byte loads, one float atomic per block.
 __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ t, float* __restrict__ out,
-                                                          int N, int C, int P, int accumulate) {
+                                                          int N, int C, int P, int nsplit) {
     __shared__ float red[17];
-    const int c = blockIdx.x;
+    const int c = blockIdx.x, sp = blockIdx.y;
+    const int per = (N + nsplit - 1) / nsplit;
+    const int nb = sp * per, ne = min(N, nb + per);
     float s = 0.f;
-    const long per = (long)N * P;
-    for (long i = threadIdx.x; i < per; i += blockDim.x) {
-        const long n = i / P, q = i % P;
-        s += t[(n * C + c) * P + q];
+    if ((P & 3) == 0) {
+        const int P4 = P >> 2;
+        const long cnt = (long)(ne - nb) * P4;
+        for (long i = threadIdx.x; i < cnt; i += blockDim.x) {
+            const long n = nb + i / P4, q = i % P4;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(t + (n * C + c) * (long)P + q * 4);
+            s += (v[0] + v[1]) + (v[2] + v[3]);
+        }
+    } else {
+        const long cnt = (long)(ne - nb) * P;
+        for (long i = threadIdx.x; i < cnt; i += blockDim.x) {
+            const long n = nb + i / P, q = i % P;
+            s += t[(n * C + c) * (long)P + q];
+        }
     }
     s = block_sum(s, red);
-    if (threadIdx.x == 0) out[c] = accumulate ? out[c] + s : s;
+    if (threadIdx.x == 0 && ne > nb) atomicAdd(&out[c], s);
 }
 
 inline int grid_for(long total) {
@@ -200,7 +213,18 @@ int jvae_fold_wgrad(const ConvGeom& g, const float* xb, const float* ys, float* 
 
 int jvae_channel_sum(const float* t, float* out, int N, int C, int P, int accumulate, hipStream_t st) {
     if (C <= 0) return 0;
-    hipLaunchKernelGGL(channel_sum_kernel, dim3(C), dim3(256), 0, st, t, out, N, C, P, accumulate);
+    if (!accumulate) {
+        hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)C, st);
+        if (e != hipSuccess) return (int)e;
+    }
+    if (N <= 0) return 0;
+    long work = (long)N * P;
+    int ns = (int)(work / 4096);
+    const int cap = (1024 + C - 1) / C;
+    if (ns > cap) ns = cap;
+    if (ns > N) ns = N;
+    if (ns < 1) ns = 1;
+    hipLaunchKernelGGL(channel_sum_kernel, dim3(C, ns), dim3(256), 0, st, t, out, N, C, P, ns);
     JVAE_LAUNCH_CHECK();
     return 0;
 }

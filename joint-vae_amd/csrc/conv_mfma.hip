@@ -1,0 +1,233 @@
+// Implicit-GEMM 5x5 convolution on the fp32 matrix cores (v_mfma_f32_32x32x2_f32) for NCHW tensors.
+//
+//   out[n][o][y][x] = bias[o] + sum_{c,kh,kw} in[n][c][y*S + kh - P][x*S + kw - P] * Wp[c][kh*5+kw][o]
+//
+// One kernel family ("forward-type") serves, through a weight re-pack (pack_kernel below):
+//   Conv2d forward (S = 1, 2), ConvTranspose2d stride-1 forward (flipped taps, P' = 4 - P),
+//   Conv2d stride-1 dgrad (swapped + flipped), ConvTranspose2d dgrad (a plain convolution of dy, S = 1, 2).
+// Reference ops: nn.Conv2d / nn.ConvTranspose2d 5x5 layers of conv32 / deconv32 (conv-models.ini:19,25).
+//
+// Mapping to CDNA4:
+//  * A workgroup (256 threads = 4 waves) owns PIX = MT*128 consecutive output pixels (full image rows, one or
+//    several images) x NT*32 output channels.  The input patch of those pixels (with halo) for CC input
+//    channels and the CC*25*(NT*32) weight slice live in LDS; the halo / out-of-image cells are zeroed ONCE,
+//    per channel chunk only the interior is re-staged with aligned 16-byte global loads (NCHW rows).
+//  * MFMA operands: A = weights (rows i = output channel), B = input patch (cols j = pixel), K = 2 input
+//    channels of the same tap per instruction, so both fragment reads are one ds_read_b32 with an
+//    immediate offset; 32 consecutive pixels per half-wave are consecutive LDS dwords (conflict-free for
+//    32-wide rows, 2-way for narrower ones).
+//  * The accumulator tile has the pixel on the lane and the channel in the register index, so every store
+//    instruction writes 128 contiguous bytes of one NCHW plane.
+//  * Each wave: MT x NT tiles of 32x32 (64 accumulator VGPRs); per 4 MFMAs (256 matrix-pipe cycles) it
+//    issues MT + NT LDS reads: the kernel is matrix-pipe bound, co-resident workgroups hide the staging.
+#include "common.h"
+#include "jvae_internal.h"
+#include "conv_dispatch.h"
+
+namespace {
+
+struct FwdP {
+    const float* in;     // (N, Cin, H, W)
+    const float* wp;     // packed (Cin, 25, Cout)
+    const float* bias;   // (Cout) or null
+    float* out;          // (N, Cout, OH, OW)
+    int N, Cin, H, W, Cout, P;
+};
+
+template <int S, int OW, int MT, int NT, int CC>
+struct FwdGeom {
+    static constexpr int OH = OW;
+    static constexpr int PIX = MT * 128;                       // output pixels per workgroup
+    static constexpr int OHW = OH * OW;
+    static constexpr int NIMG = PIX >= OHW ? PIX / OHW : 1;    // images per workgroup
+    static constexpr int TH = PIX >= OHW ? OH : PIX / OW;      // output rows per image in the tile
+    static constexpr int ROWS = (TH - 1) * S + 5;              // input rows in the patch
+    static constexpr int WIN = OW * S;                         // input width
+    static constexpr int WP0 = (OW - 1) * S + 9;               // worst case P = 0 (lds col = x*S + kw - P + 4)
+    static constexpr int WP1 = WIN + 4;
+    static constexpr int WP = (((WP0 > WP1 ? WP0 : WP1) + 3) / 4) * 4;
+    static constexpr int CH = ROWS * WP;                       // floats per channel per image
+    static constexpr int XS = NIMG * CC * CH;                  // input patch floats
+    static constexpr int WCOLS = NT * 32;
+    static constexpr int WS = CC * 25 * WCOLS;
+};
+
+template <int S, int OW, int MT, int NT, int CC>
+__global__ __launch_bounds__(256) void conv5_fwd_kernel(FwdP p) {
+    using G = FwdGeom<S, OW, MT, NT, CC>;
+    __shared__ __attribute__((aligned(16))) float lds[G::XS + G::WS];
+    float* Xs = lds;
+    float* Ws = lds + G::XS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    constexpr int TILES_PER_IMG = G::OHW >= G::PIX ? G::OHW / G::PIX : 1;
+    const int img0 = (G::OHW >= G::PIX) ? (int)(blockIdx.x / TILES_PER_IMG) : (int)blockIdx.x * G::NIMG;
+    const int row0 = (G::OHW >= G::PIX) ? (int)(blockIdx.x % TILES_PER_IMG) * G::TH : 0;
+    const int o0 = blockIdx.y * G::WCOLS;
+
+    // ---- zero the whole patch once: halo columns / out-of-image rows / missing images stay zero for all chunks
+    for (int i = tid; i < G::XS / 4; i += 256) reinterpret_cast<f32x4*>(Xs)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- this lane's pixels (B operand): LDS offset of tap (0,0), channel 0
+    int pixoff[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int pix = (wave * MT + mt) * 32 + l31;          // pixel inside the workgroup tile
+        const int im = pix / (G::TH * OW), rem = pix % (G::TH * OW);
+        const int r = rem / OW, c = rem % OW;
+        pixoff[mt] = im * (CC * G::CH) + (r * S) * G::WP + c * S + 4 - p.P + half * G::CH;
+    }
+
+    f32x16 acc[NT][MT];
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < MT; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int in_row0 = row0 * S - p.P;                       // input row of patch row 0
+    constexpr int W4 = G::WIN / 4;
+    constexpr int XUNITS = G::NIMG * CC * G::ROWS * W4;       // interior float4s per chunk
+    constexpr int WUNITS = G::WS / 4;
+
+    for (int c0 = 0; c0 < p.Cin; c0 += CC) {
+        __syncthreads();                                      // previous chunk fully consumed (and zero fill done)
+        for (int u = tid; u < XUNITS; u += 256) {
+            const int x4 = u % W4;
+            int t = u / W4;
+            const int lr = t % G::ROWS; t /= G::ROWS;
+            const int c = t % CC, im = t / CC;
+            const int ir = in_row0 + lr, n = img0 + im, ch = c0 + c;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (ir >= 0 && ir < p.H && n < p.N && ch < p.Cin)
+                v = *reinterpret_cast<const f32x4*>(p.in + (((long)n * p.Cin + ch) * p.H + ir) * p.W + x4 * 4);
+            *reinterpret_cast<f32x4*>(&Xs[(im * CC + c) * G::CH + lr * G::WP + 4 + x4 * 4]) = v;
+        }
+        for (int u = tid; u < WUNITS; u += 256) {
+            const int col4 = u % (G::WCOLS / 4), kr = u / (G::WCOLS / 4);     // kr = c*25 + tap
+            const int ch = c0 + kr / 25;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (ch < p.Cin)
+                v = *reinterpret_cast<const f32x4*>(p.wp + ((long)(c0 * 25 + kr)) * p.Cout + o0 + col4 * 4);
+            reinterpret_cast<f32x4*>(Ws)[u] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int cp = 0; cp < CC / 2; ++cp) {
+#pragma unroll
+            for (int tap = 0; tap < 25; ++tap) {
+                const int kh = tap / 5, kw = tap % 5;
+                float a[NT], b[MT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) a[nt] = Ws[((cp * 2 + half) * 25 + tap) * G::WCOLS + nt * 32 + l31];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) b[mt] = Xs[pixoff[mt] + (cp * 2) * G::CH + kh * G::WP + kw];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+                        acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[nt], b[mt], acc[nt][mt], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue: D[i = channel][j = pixel]; lane holds pixel j = l31, rows i = (r&3) + 8*(r>>2) + 4*half
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int pix = (wave * MT + mt) * 32 + l31;
+        const int im = pix / (G::TH * OW), rem = pix % (G::TH * OW);
+        const int n = img0 + im;
+        if (n >= p.N) continue;
+        const int oy = row0 + rem / OW, ox = rem % OW;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = o0 + nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                float v = acc[nt][mt][r];
+                if (p.bias) v += p.bias[o];
+                p.out[(((long)n * p.Cout + o) * G::OH + oy) * OW + ox] = v;
+            }
+    }
+}
+
+// Wp[c][tap][o] from a PyTorch-layout weight.  swap: source is [c][o][tap] (else [o][c][tap]); flip: tap -> 24 - tap
+__global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ w, float* __restrict__ wp,
+                                                   int C, int O, int swap, int flip) {
+    const int total = C * 25 * O;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int o = i % O, tap = (i / O) % 25, c = i / (O * 25);
+        const int st = flip ? 24 - tap : tap;
+        wp[i] = swap ? w[((long)c * O + o) * 25 + st] : w[((long)o * C + c) * 25 + st];
+    }
+}
+
+template <int S, int OW, int MT, int NT, int CC>
+int launch_fwd(const FwdP& p, hipStream_t st) {
+    using G = FwdGeom<S, OW, MT, NT, CC>;
+    static_assert((G::XS + G::WS) * 4 <= 160 * 1024, "LDS budget");
+    const long pixels = (long)p.N * G::OHW;
+    dim3 grid((unsigned)((pixels + G::PIX - 1) / G::PIX), (unsigned)(p.Cout / G::WCOLS));
+    if (G::OHW < G::PIX) grid.x = (unsigned)((p.N + G::NIMG - 1) / G::NIMG);
+    hipLaunchKernelGGL((conv5_fwd_kernel<S, OW, MT, NT, CC>), grid, dim3(256), 0, st, p);
+    JVAE_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int S, int OW>
+int launch_fwd_ow(const FwdP& p, hipStream_t st) {
+    if (p.Cout % 64 == 0) return launch_fwd<S, OW, 2, 2, 4>(p, st);
+    return launch_fwd<S, OW, 4, 1, (S == 1 ? 8 : 4)>(p, st);
+}
+
+}  // namespace
+
+// Is the forward-type fast kernel applicable?  in: (N,Cin,H,W) -> out: (N,Cout,OH,OW), 5x5, stride S, padding P.
+bool jvae_conv5_fwd_ok(int Cin, int H, int W, int Cout, int OH, int OW, int S, int P) {
+    if (S != 1 && S != 2) return false;
+    if (OH != OW || H != W) return false;
+    if (OW != 8 && OW != 16 && OW != 32 && OW != 64) return false;
+    if (W != OW * S) return false;                 // "same"-style geometry: 5x5, P = 2 (or its transposed mirror)
+    if (P < 0 || P > 4) return false;
+    if ((OW - 1) * S + 4 - P >= W + 4) return false;   // right-most tap must stay inside the zero halo
+    if (Cout % 32 != 0 || Cin < 1) return false;
+    return true;
+}
+
+size_t jvae_conv5_pack_floats(int Cin, int Cout) { return (size_t)Cin * 25 * Cout; }
+
+int jvae_conv5_pack(const float* w, float* wp, int C, int O, int swap, int flip, hipStream_t st) {
+    const int total = C * 25 * O;
+    hipLaunchKernelGGL(pack_kernel, dim3(cdiv(total, 256) > 512 ? 512 : cdiv(total, 256)), dim3(256), 0, st,
+                       w, wp, C, O, swap, flip);
+    JVAE_LAUNCH_CHECK();
+    return 0;
+}
+
+// ws must hold Cin*25*Cout floats (the packed weights).  swap / flip: see pack_kernel.
+int jvae_conv5_fwd(const float* in, const float* w, int swap, int flip, const float* bias, float* out,
+                   int N, int Cin, int H, int W, int Cout, int OW, int S, int P, float* ws, hipStream_t st) {
+    const int total = Cin * 25 * Cout;
+    hipLaunchKernelGGL(pack_kernel, dim3(cdiv(total, 256) > 512 ? 512 : cdiv(total, 256)), dim3(256), 0, st,
+                       w, ws, Cin, Cout, swap, flip);
+    JVAE_LAUNCH_CHECK();
+    FwdP p{in, ws, bias, out, N, Cin, H, W, Cout, P};
+    if (S == 1) {
+        switch (OW) {
+            case 8: return launch_fwd_ow<1, 8>(p, st);
+            case 16: return launch_fwd_ow<1, 16>(p, st);
+            case 32: return launch_fwd_ow<1, 32>(p, st);
+            case 64: return launch_fwd_ow<1, 64>(p, st);
+        }
+    } else {
+        switch (OW) {
+            case 8: return launch_fwd_ow<2, 8>(p, st);
+            case 16: return launch_fwd_ow<2, 16>(p, st);
+            case 32: return launch_fwd_ow<2, 32>(p, st);
+            case 64: return launch_fwd_ow<2, 64>(p, st);
+        }
+    }
+    return JVAE_ENOTSUP;
+}
