@@ -92,6 +92,7 @@ def main():
     ap.add_argument('--steps', type=int, default=30)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--batch', type=int, default=BATCH_PER_GPU, help='diagnostics only: per-GPU batch (the metric is defined at 512)')
     a = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -110,8 +111,8 @@ def main():
     if world > 1:
         net.optimizer.set_distributed(world)
     g = torch.Generator(device=device).manual_seed(1234 + rank)
-    x = torch.rand(BATCH_PER_GPU, 3, 32, 32, device=device, generator=g)
-    y = torch.randint(0, 10, (BATCH_PER_GPU,), device=device, generator=g)
+    x = torch.rand(a.batch, 3, 32, 32, device=device, generator=g)
+    y = torch.randint(0, 10, (a.batch,), device=device, generator=g)
 
     def sync():
         torch.cuda.synchronize()
@@ -132,7 +133,7 @@ def main():
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
-    value = world * BATCH_PER_GPU * a.steps / dt
+    value = world * a.batch * a.steps / dt
 
     if rank == 0:
         out = {'metric': 'training_images_per_sec', 'value': value, 'unit': 'images/s', 'n_gpus': world,

@@ -27,6 +27,11 @@ bool jvae_convt2_ok(int C, int HS, int WS, int O, int HB, int WB, int KH, int KW
 int jvae_convt2(const float* in, const float* wpacked, const float* bias, float* out, int N, int C, int WS, int O,
                 hipStream_t st);
 
+// conv_smallco.hip: 5x5 stride-1 'same' convolution with <= 4 output channels (vector ALUs)
+bool jvae_conv5_smallco_ok(int Cin, int H, int W, int Cout, int KH, int KW, int S, int P);
+int jvae_conv5_smallco(const float* in, const float* w, const float* bias, float* out, int N, int Cin, int W, int Cout,
+                       hipStream_t st);
+
 // conv_wgrad_mfma.hip: dW[a][b][tap] = sum Ps[n][a][u][v] Q[n][b][u*S+kh-P][v*S+kw-P]
 bool jvae_conv5_wgrad_ok(int Ca, int HS, int WS, int Cb, int HB, int WB, int S, int P);
 size_t jvae_conv5_wgrad_ws_floats(int N, int Ca, int Cb, int S, int WS);

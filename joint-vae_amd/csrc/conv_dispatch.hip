@@ -29,6 +29,12 @@ inline int run_t2(const ConvGeom& g, const float* small, const float* w, const f
     return jvae_convt2(small, ws, bias, big, g.N, g.Cs, g.Ws, g.Cb, st);
 }
 
+// Transposed convolution of a 1x1 input with no padding (imager.0 of deconv32: 64 x 1 x 1 -> 64 x 8 x 8): the
+// output IS the product x[n][ci] . w[ci][(co,kh,kw)] and the dgrad its transpose: plain GEMMs, no fold pass.
+inline bool point_input(const ConvGeom& g) {
+    return g.Hs == 1 && g.Ws == 1 && g.P == 0 && g.S == 1 && g.Hb == g.KH && g.Wb == g.KW;
+}
+
 // wgrad: role swap when the folded side has very few channels (Conv 32->3): see conv_wgrad_mfma.hip
 inline bool wgrad_swap(const ConvGeom& g) { return g.S == 1 && g.Cs < 16 && g.Cb >= 16 && g.Hs == g.Hb; }
 inline bool wgrad_fast(const ConvGeom& g) {
@@ -55,9 +61,16 @@ size_t jvae_conv_ws(const ConvGeom& g, int transposed) {
 int jvae_conv_fwd(const ConvGeom& g, int transposed, const float* x, const float* w, const float* bias, float* y,
                   float* ws, size_t ws_bytes, hipStream_t st) {
     if (!transposed) {
+        if (jvae_conv5_smallco_ok(g.Cb, g.Hb, g.Wb, g.Cs, g.KH, g.KW, g.S, g.P))
+            return jvae_conv5_smallco(x, w, bias, y, g.N, g.Cb, g.Wb, g.Cs, st);
         if (fold_fwd_fast(g) && ws_bytes >= 4 * jvae_conv5_pack_floats(g.Cb, g.Cs))
             return jvae_conv5_fwd(x, w, 0, 0, bias, y, g.N, g.Cb, g.Hb, g.Wb, g.Cs, g.Ws, g.S, g.P, ws, st);
         return jvae_fold_fwd(g, x, w, bias, y, ws, ws_bytes, st);
+    }
+    if (point_input(g)) {
+        const int cols = g.Cb * g.KH * g.KW;
+        return jvae_gemm_launch_ex(g.N, cols, g.Cs, 1, x, g.Cs, 1, 0, w, cols, 1, 0, y, cols, 1, 0,
+                                   bias, bias ? 1 : 0, g.KH * g.KW, 0, 1, st);
     }
     if (fold_bwd_fast_s1(g) && ws_bytes >= 4 * jvae_conv5_pack_floats(g.Cs, g.Cb))
         return jvae_conv5_fwd(x, w, 1, 1, bias, y, g.N, g.Cs, g.Hs, g.Ws, g.Cb, g.Wb, 1, 4 - g.P, ws, st);
@@ -73,6 +86,12 @@ int jvae_conv_dgrad(const ConvGeom& g, int transposed, const float* dy, const fl
         if (fold_bwd_fast_s2(g) && ws_bytes >= 4 * jvae_conv5_pack_floats(g.Cs, g.Cb))
             return run_t2(g, dy, w, nullptr, dx, ws, st);
         return jvae_fold_bwd(g, dy, w, nullptr, dx, ws, ws_bytes, st);
+    }
+    if (point_input(g)) {
+        const int cols = g.Cb * g.KH * g.KW;        // dx[n][ci] = sum_j dy[n][j] w[ci][j]: few tiles, long K -> split-K
+        hipError_t e = hipMemsetAsync(dx, 0, sizeof(float) * (size_t)g.N * g.Cs, st);
+        if (e != hipSuccess) return (int)e;
+        return jvae_gemm_launch(g.N, g.Cs, cols, 1, dy, cols, 1, 0, w, 1, cols, 0, dx, g.Cs, 1, 0, nullptr, 0, 0, 16, st);
     }
     if (fold_fwd_fast(g) && ws_bytes >= 4 * jvae_conv5_pack_floats(g.Cb, g.Cs))
         return jvae_conv5_fwd(dy, w, 0, 0, nullptr, dx, g.N, g.Cb, g.Hb, g.Wb, g.Cs, g.Ws, g.S, g.P, ws, st);

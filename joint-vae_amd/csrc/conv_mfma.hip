@@ -31,7 +31,8 @@ struct FwdP {
     const float* wp;     // packed (Cin, 25, Cout)
     const float* bias;   // (Cout) or null
     float* out;          // (N, Cout, OH, OW)
-    int N, Cin, H, W, Cout, P;
+    int N, Cin, H, W, Cout, P;   // Cout: padded to a multiple of 32 (packed weights), CoutReal: channels of `out`
+    int CoutReal;
 };
 
 template <int S, int OW, int MT, int NT, int CC>
@@ -53,7 +54,7 @@ struct FwdGeom {
 };
 
 template <int S, int OW, int MT, int NT, int CC>
-__global__ __launch_bounds__(256) void conv5_fwd_kernel(FwdP p) {
+__global__ __launch_bounds__(256, 2) void conv5_fwd_kernel(FwdP p) {
     using G = FwdGeom<S, OW, MT, NT, CC>;
     __shared__ __attribute__((aligned(16))) float lds[G::XS + G::WS];
     float* Xs = lds;
@@ -92,28 +93,60 @@ __global__ __launch_bounds__(256) void conv5_fwd_kernel(FwdP p) {
     constexpr int XUNITS = G::NIMG * CC * G::ROWS * W4;       // interior float4s per chunk
     constexpr int WUNITS = G::WS / 4;
 
-    for (int c0 = 0; c0 < p.Cin; c0 += CC) {
-        __syncthreads();                                      // previous chunk fully consumed (and zero fill done)
-        for (int u = tid; u < XUNITS; u += 256) {
+    // Software pipeline: the global loads of chunk c+1 are issued before the MFMAs of chunk c and land in
+    // registers; they are written to LDS after the barrier that retires chunk c's fragment reads.
+    constexpr int XU = (XUNITS + 255) / 256, WU = (WUNITS + 255) / 256;
+    f32x4 rx[XU], rw[WU];
+    auto gload = [&](int c0) {
+#pragma unroll
+        for (int k = 0; k < XU; ++k) {
+            const int u = tid + k * 256;
             const int x4 = u % W4;
             int t = u / W4;
             const int lr = t % G::ROWS; t /= G::ROWS;
             const int c = t % CC, im = t / CC;
             const int ir = in_row0 + lr, n = img0 + im, ch = c0 + c;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ir >= 0 && ir < p.H && n < p.N && ch < p.Cin)
+            if (u < XUNITS && ir >= 0 && ir < p.H && n < p.N && ch < p.Cin)
                 v = *reinterpret_cast<const f32x4*>(p.in + (((long)n * p.Cin + ch) * p.H + ir) * p.W + x4 * 4);
-            *reinterpret_cast<f32x4*>(&Xs[(im * CC + c) * G::CH + lr * G::WP + 4 + x4 * 4]) = v;
+            rx[k] = v;
         }
-        for (int u = tid; u < WUNITS; u += 256) {
+#pragma unroll
+        for (int k = 0; k < WU; ++k) {
+            const int u = tid + k * 256;
             const int col4 = u % (G::WCOLS / 4), kr = u / (G::WCOLS / 4);     // kr = c*25 + tap
             const int ch = c0 + kr / 25;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ch < p.Cin)
+            if (u < WUNITS && ch < p.Cin)
                 v = *reinterpret_cast<const f32x4*>(p.wp + ((long)(c0 * 25 + kr)) * p.Cout + o0 + col4 * 4);
-            reinterpret_cast<f32x4*>(Ws)[u] = v;
+            rw[k] = v;
         }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int k = 0; k < XU; ++k) {
+            const int u = tid + k * 256;
+            if (u < XUNITS) {
+                const int x4 = u % W4;
+                int t = u / W4;
+                const int lr = t % G::ROWS; t /= G::ROWS;
+                const int c = t % CC, im = t / CC;
+                *reinterpret_cast<f32x4*>(&Xs[(im * CC + c) * G::CH + lr * G::WP + 4 + x4 * 4]) = rx[k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < WU; ++k) {
+            const int u = tid + k * 256;
+            if (u < WUNITS) reinterpret_cast<f32x4*>(Ws)[u] = rw[k];
+        }
+    };
+
+    gload(0);
+    for (int c0 = 0; c0 < p.Cin; c0 += CC) {
+        __syncthreads();                                      // previous chunk fully consumed (and zero fill done)
+        lstore();
         __syncthreads();
+        if (c0 + CC < p.Cin) gload(c0 + CC);
 #pragma unroll
         for (int cp = 0; cp < CC / 2; ++cp) {
 #pragma unroll
@@ -146,21 +179,25 @@ __global__ __launch_bounds__(256) void conv5_fwd_kernel(FwdP p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int o = o0 + nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (o >= p.CoutReal) continue;
                 float v = acc[nt][mt][r];
                 if (p.bias) v += p.bias[o];
-                p.out[(((long)n * p.Cout + o) * G::OH + oy) * OW + ox] = v;
+                p.out[(((long)n * p.CoutReal + o) * G::OH + oy) * OW + ox] = v;
             }
     }
 }
 
-// Wp[c][tap][o] from a PyTorch-layout weight.  swap: source is [c][o][tap] (else [o][c][tap]); flip: tap -> 24 - tap
+// Wp[c][tap][o] (o < OP, zero for o >= O) from a PyTorch-layout weight.
+// swap: source is [c][o][tap] (else [o][c][tap]); flip: tap -> 24 - tap
 __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ w, float* __restrict__ wp,
-                                                   int C, int O, int swap, int flip) {
-    const int total = C * 25 * O;
+                                                   int C, int O, int OP, int swap, int flip) {
+    const int total = C * 25 * OP;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        const int o = i % O, tap = (i / O) % 25, c = i / (O * 25);
+        const int o = i % OP, tap = (i / OP) % 25, c = i / (OP * 25);
         const int st = flip ? 24 - tap : tap;
-        wp[i] = swap ? w[((long)c * O + o) * 25 + st] : w[((long)o * C + c) * 25 + st];
+        float v = 0.f;
+        if (o < O) v = swap ? w[((long)c * O + o) * 25 + st] : w[((long)o * C + c) * 25 + st];
+        wp[i] = v;
     }
 }
 
@@ -179,6 +216,7 @@ int launch_fwd(const FwdP& p, hipStream_t st) {
 template <int S, int OW>
 int launch_fwd_ow(const FwdP& p, hipStream_t st) {
     if (p.Cout % 64 == 0) return launch_fwd<S, OW, 2, 2, 4>(p, st);
+    if (p.Cin <= 4) return launch_fwd<S, OW, 4, 1, 4>(p, st);      // 3-channel inputs: one chunk of 2 channel pairs
     return launch_fwd<S, OW, 4, 1, (S == 1 ? 8 : 4)>(p, st);
 }
 
@@ -192,16 +230,17 @@ bool jvae_conv5_fwd_ok(int Cin, int H, int W, int Cout, int OH, int OW, int S, i
     if (W != OW * S) return false;                 // "same"-style geometry: 5x5, P = 2 (or its transposed mirror)
     if (P < 0 || P > 4) return false;
     if ((OW - 1) * S + 4 - P >= W + 4) return false;   // right-most tap must stay inside the zero halo
-    if (Cout % 32 != 0 || Cin < 1) return false;
+    if (Cout < 1 || Cin < 1) return false;       // Cout is padded to a multiple of 32 inside
     return true;
 }
 
-size_t jvae_conv5_pack_floats(int Cin, int Cout) { return (size_t)Cin * 25 * Cout; }
+size_t jvae_conv5_pack_floats(int Cin, int Cout) { return (size_t)Cin * 25 * ((Cout + 31) / 32 * 32); }
 
 int jvae_conv5_pack(const float* w, float* wp, int C, int O, int swap, int flip, hipStream_t st) {
-    const int total = C * 25 * O;
+    const int OP = (O + 31) / 32 * 32;
+    const int total = C * 25 * OP;
     hipLaunchKernelGGL(pack_kernel, dim3(cdiv(total, 256) > 512 ? 512 : cdiv(total, 256)), dim3(256), 0, st,
-                       w, wp, C, O, swap, flip);
+                       w, wp, C, O, OP, swap, flip);
     JVAE_LAUNCH_CHECK();
     return 0;
 }
@@ -209,11 +248,9 @@ int jvae_conv5_pack(const float* w, float* wp, int C, int O, int swap, int flip,
 // ws must hold Cin*25*Cout floats (the packed weights).  swap / flip: see pack_kernel.
 int jvae_conv5_fwd(const float* in, const float* w, int swap, int flip, const float* bias, float* out,
                    int N, int Cin, int H, int W, int Cout, int OW, int S, int P, float* ws, hipStream_t st) {
-    const int total = Cin * 25 * Cout;
-    hipLaunchKernelGGL(pack_kernel, dim3(cdiv(total, 256) > 512 ? 512 : cdiv(total, 256)), dim3(256), 0, st,
-                       w, ws, Cin, Cout, swap, flip);
-    JVAE_LAUNCH_CHECK();
-    FwdP p{in, ws, bias, out, N, Cin, H, W, Cout, P};
+    int rc = jvae_conv5_pack(w, ws, Cin, Cout, swap, flip, st);
+    if (rc) return rc;
+    FwdP p{in, ws, bias, out, N, Cin, H, W, (Cout + 31) / 32 * 32, P, Cout};
     if (S == 1) {
         switch (OW) {
             case 8: return launch_fwd_ow<1, 8>(p, st);

@@ -43,7 +43,7 @@ struct T2Geom {
 };
 
 template <int WS, int NT, int CC>
-__global__ __launch_bounds__(256) void convt2_kernel(T2P p) {
+__global__ __launch_bounds__(256, 2) void convt2_kernel(T2P p) {
     using G = T2Geom<WS, NT, CC>;
     __shared__ __attribute__((aligned(16))) float lds[G::XS + G::WSZ];
     float* Xs = lds;
@@ -76,28 +76,54 @@ __global__ __launch_bounds__(256) void convt2_kernel(T2P p) {
     constexpr int XUNITS = G::NIMG * CC * G::ROWS * W4;
     constexpr int WUNITS = G::WSZ / 4;
 
-    for (int c0 = 0; c0 < p.C; c0 += CC) {
-        __syncthreads();
-        for (int u = tid; u < XUNITS; u += 256) {
+    constexpr int XU = (XUNITS + 255) / 256, WU = (WUNITS + 255) / 256;
+    f32x4 rx[XU], rw[WU];
+    auto gload = [&](int c0) {
+#pragma unroll
+        for (int k = 0; k < XU; ++k) {
+            const int u = tid + k * 256;
             const int x4 = u % W4;
             int t = u / W4;
             const int lr = t % G::ROWS; t /= G::ROWS;
             const int c = t % CC, i2 = t / CC;
             const int ir = row0 - 1 + lr, n = img0 + i2, ch = c0 + c;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ir >= 0 && ir < G::HS && n < p.N && ch < p.C)
+            if (u < XUNITS && ir >= 0 && ir < G::HS && n < p.N && ch < p.C)
                 v = *reinterpret_cast<const f32x4*>(p.in + (((long)n * p.C + ch) * G::HS + ir) * WS + x4 * 4);
-            *reinterpret_cast<f32x4*>(&Xs[(i2 * CC + c) * G::CH + lr * G::WP + 4 + x4 * 4]) = v;
+            rx[k] = v;
         }
-        for (int u = tid; u < WUNITS; u += 256) {
+#pragma unroll
+        for (int k = 0; k < WU; ++k) {
+            const int u = tid + k * 256;
             const int col4 = u % (G::WCOLS / 4), kr = u / (G::WCOLS / 4);
             const int ch = c0 + kr / 25;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ch < p.C)
+            if (u < WUNITS && ch < p.C)
                 v = *reinterpret_cast<const f32x4*>(p.wp + ((long)(c0 * 25 + kr)) * p.O + o0 + col4 * 4);
-            reinterpret_cast<f32x4*>(Ws)[u] = v;
+            rw[k] = v;
+        }
+    };
+    gload(0);
+    for (int c0 = 0; c0 < p.C; c0 += CC) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < XU; ++k) {
+            const int u = tid + k * 256;
+            if (u < XUNITS) {
+                const int x4 = u % W4;
+                int t = u / W4;
+                const int lr = t % G::ROWS; t /= G::ROWS;
+                const int c = t % CC, i2 = t / CC;
+                *reinterpret_cast<f32x4*>(&Xs[(i2 * CC + c) * G::CH + lr * G::WP + 4 + x4 * 4]) = rx[k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < WU; ++k) {
+            const int u = tid + k * 256;
+            if (u < WUNITS) reinterpret_cast<f32x4*>(Ws)[u] = rw[k];
         }
         __syncthreads();
+        if (c0 + CC < p.C) gload(c0 + CC);
 #pragma unroll
         for (int cp = 0; cp < CC / 2; ++cp) {
             float nb[3][3];                                       // 3x3 neighbourhood of this lane's pixel

@@ -48,7 +48,7 @@ struct WgGeom {
 };
 
 template <int S, int WS, int CB>
-__global__ __launch_bounds__(256) void conv5_wgrad_kernel(WgP p) {
+__global__ __launch_bounds__(256, 2) void conv5_wgrad_kernel(WgP p) {
     using G = WgGeom<S, WS, CB>;
     __shared__ __attribute__((aligned(16))) float lds[G::QS + G::PSZ];
     float* Qs = lds;
@@ -90,41 +90,75 @@ __global__ __launch_bounds__(256) void conv5_wgrad_kernel(WgP p) {
     constexpr int PUNITS = 32 * G::TPIX / 4;
     const int HB = G::HS * S;
 
-    for (int n = n_beg; n < n_end; ++n) {
-        for (int tile = 0; tile < G::TILES; ++tile) {
-            const int row0 = tile * G::TH;
-            const int in_row0 = row0 * S - p.P;
-            __syncthreads();
-            for (int u = tid; u < QUNITS; u += 256) {
+    // (image, row-tile) work items of this workgroup, software-pipelined: the global loads of item i+1 are in
+    // flight (registers) under the MFMAs of item i.
+    constexpr int QU = (QUNITS + 255) / 256, PU = (PUNITS + 255) / 256;
+    f32x4 rq[QU], rp[PU];
+    auto gload = [&](int item) {
+        const int n = item / G::TILES, tile = item % G::TILES;
+        const int row0 = tile * G::TH;
+        const int in_row0 = row0 * S - p.P;
+#pragma unroll
+        for (int k = 0; k < QU; ++k) {
+            const int u = tid + k * 256;
+            const int x4 = u % W4;
+            const int t = u / W4;
+            const int lr = t % G::ROWS, c = t / G::ROWS;
+            const int ir = in_row0 + lr;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (u < QUNITS && ir >= 0 && ir < HB && c < cb_here)
+                v = *reinterpret_cast<const f32x4*>(p.q + (((long)n * p.Cb + b0 + c) * HB + ir) * G::WB + x4 * 4);
+            rq[k] = v;
+        }
+#pragma unroll
+        for (int k = 0; k < PU; ++k) {
+            const int u = tid + k * 256;
+            const int p4 = u % (G::TPIX / 4), a = u / (G::TPIX / 4);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (u < PUNITS && a0 + a < p.Ca)
+                v = *reinterpret_cast<const f32x4*>(p.ps + (((long)n * p.Ca + a0 + a) * G::HS + row0) * WS + p4 * 4);
+            rp[k] = v;
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int k = 0; k < QU; ++k) {
+            const int u = tid + k * 256;
+            if (u < QUNITS) {
                 const int x4 = u % W4;
-                int t = u / W4;
+                const int t = u / W4;
                 const int lr = t % G::ROWS, c = t / G::ROWS;
-                const int ir = in_row0 + lr;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (ir >= 0 && ir < HB && c < cb_here)
-                    v = *reinterpret_cast<const f32x4*>(p.q + (((long)n * p.Cb + b0 + c) * HB + ir) * G::WB + x4 * 4);
-                *reinterpret_cast<f32x4*>(&Qs[c * G::CH + lr * G::WP + 4 + x4 * 4]) = v;
+                *reinterpret_cast<f32x4*>(&Qs[c * G::CH + lr * G::WP + 4 + x4 * 4]) = rq[k];
             }
-            for (int u = tid; u < PUNITS; u += 256) {
+        }
+#pragma unroll
+        for (int k = 0; k < PU; ++k) {
+            const int u = tid + k * 256;
+            if (u < PUNITS) {
                 const int p4 = u % (G::TPIX / 4), a = u / (G::TPIX / 4);
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (a0 + a < p.Ca)
-                    v = *reinterpret_cast<const f32x4*>(p.ps + (((long)n * p.Ca + a0 + a) * G::HS + row0) * WS + p4 * 4);
                 float* d = &Pt[a * G::PPITCH + p4 * 4];
-                d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+                d[0] = rp[k][0]; d[1] = rp[k][1]; d[2] = rp[k][2]; d[3] = rp[k][3];
             }
-            __syncthreads();
+        }
+    };
+
+    const int item_beg = n_beg * G::TILES, item_end = n_end * G::TILES;
+    if (item_beg < item_end) gload(item_beg);
+    for (int item = item_beg; item < item_end; ++item) {
+        __syncthreads();
+        lstore();
+        __syncthreads();
+        if (item + 1 < item_end) gload(item + 1);
 #pragma unroll
-            for (int ks = 0; ks < G::TPIX / 2; ++ks) {
-                const int pix = 2 * ks;                                   // + half (folded into aoff / boff)
-                const int qoff = (pix / WS) * S * G::WP + (pix % WS) * S; // compile-time after unrolling
-                const float a = Pt[aoff + pix];
+        for (int ks = 0; ks < G::TPIX / 2; ++ks) {
+            const int pix = 2 * ks;                                   // + half (folded into aoff / boff)
+            const int qoff = (pix / WS) * S * G::WP + (pix % WS) * S; // compile-time after unrolling
+            const float a = Pt[aoff + pix];
 #pragma unroll
-                for (int t = 0; t < G::NBT; ++t) {
-                    if ((wave * G::NBT + t) < G::NTILE) {                 // wave-uniform
-                        const float b = Qs[boff[t] + qoff];
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
-                    }
+            for (int t = 0; t < G::NBT; ++t) {
+                if ((wave * G::NBT + t) < G::NTILE) {                 // wave-uniform
+                    const float b = Qs[boff[t] + qoff];
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
                 }
             }
         }
@@ -177,7 +211,10 @@ int launch_wg(const WgP& p, hipStream_t st) {
     return 0;
 }
 
-inline int pick_cb(int S, int WS) { return (S == 1 && (WS == 16 || WS == 32)) ? 32 : 16; }
+inline int pick_cb(int S, int WS, int Cb) {
+    if (Cb <= 4) return 4;                      // 3-channel tensors (image side of the first / last layer)
+    return 16;
+}
 
 }  // namespace
 
@@ -190,7 +227,7 @@ bool jvae_conv5_wgrad_ok(int Ca, int HS, int WS, int Cb, int HB, int WB, int S, 
 }
 
 static int slab_count(int N, int Ca, int Cb, int S, int WS) {
-    const int cb = pick_cb(S, WS);
+    const int cb = pick_cb(S, WS, Cb);
     const int per = ((Ca + 31) / 32) * ((Cb + cb - 1) / cb);
     int g = 512 / per;
     if (g < 1) g = 1;
@@ -207,11 +244,27 @@ int jvae_conv5_wgrad(const float* ps, const float* q, float* dw, int accumulate,
                      int N, int Ca, int WS, int Cb, int S, int P, float* ws, hipStream_t st) {
     WgP p{ps, q, ws, N, Ca, Cb, P, slab_count(N, Ca, Cb, S, WS)};
     int rc = JVAE_ENOTSUP;
-    if (S == 1) {
+    if (Cb <= 4) {
+        if (S == 1) {
+            switch (WS) {
+                case 8: rc = launch_wg<1, 8, 4>(p, st); break;
+                case 16: rc = launch_wg<1, 16, 4>(p, st); break;
+                case 32: rc = launch_wg<1, 32, 4>(p, st); break;
+                case 64: rc = launch_wg<1, 64, 4>(p, st); break;
+            }
+        } else {
+            switch (WS) {
+                case 8: rc = launch_wg<2, 8, 4>(p, st); break;
+                case 16: rc = launch_wg<2, 16, 4>(p, st); break;
+                case 32: rc = launch_wg<2, 32, 4>(p, st); break;
+                case 64: rc = launch_wg<2, 64, 4>(p, st); break;
+            }
+        }
+    } else if (S == 1) {
         switch (WS) {
             case 8: rc = launch_wg<1, 8, 16>(p, st); break;
-            case 16: rc = launch_wg<1, 16, 32>(p, st); break;
-            case 32: rc = launch_wg<1, 32, 32>(p, st); break;
+            case 16: rc = launch_wg<1, 16, 16>(p, st); break;
+            case 32: rc = launch_wg<1, 32, 16>(p, st); break;
             case 64: rc = launch_wg<1, 64, 16>(p, st); break;
         }
     } else {

@@ -22,6 +22,7 @@ struct GemmP {
     float* C; long sCm, sCn, sCb;
     const float* bias;   // nullptr or per-n (mode 1) / per-m (mode 2)
     int bias_mode;
+    int bias_div;        // mode 1: bias[n / bias_div] (transposed conv on a 1x1 input: channel = column / (KH*KW))
     int M, N, K;
     int splitk;          // grid.z = batch * splitk
     int kchunk;          // K elements per split (multiple of BK)
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
         for (int j = 0; j < TN; ++j) {
             const int n = n0 + wn0 + j * 32 + l31;
             if (n >= p.N) continue;
-            float bn = (p.bias_mode == 1 && lead) ? p.bias[n] : 0.f;
+            float bn = (p.bias_mode == 1 && lead) ? p.bias[n / p.bias_div] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -199,12 +200,21 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 }  // namespace
 
-// Internal entry used by the other translation units (see jvae_internal.h).
 int jvae_gemm_launch(int M, int N, int K, int batch,
                      const float* A, long sAm, long sAk, long sAb,
                      const float* B, long sBk, long sBn, long sBb,
                      float* C, long sCm, long sCn, long sCb,
                      const float* bias, int bias_mode, int flags, int splitk, hipStream_t st) {
+    return jvae_gemm_launch_ex(M, N, K, batch, A, sAm, sAk, sAb, B, sBk, sBn, sBb, C, sCm, sCn, sCb, bias, bias_mode, 1,
+                               flags, splitk, st);
+}
+
+// Internal entry used by the other translation units (see jvae_internal.h).
+int jvae_gemm_launch_ex(int M, int N, int K, int batch,
+                        const float* A, long sAm, long sAk, long sAb,
+                        const float* B, long sBk, long sBn, long sBb,
+                        float* C, long sCm, long sCn, long sCb,
+                        const float* bias, int bias_mode, int bias_div, int flags, int splitk, hipStream_t st) {
     if (M <= 0 || N <= 0 || batch <= 0) return 0;
     if (K < 0 || !A || !B || !C) return JVAE_EINVAL;
     if (bias_mode && !bias) return JVAE_EINVAL;
@@ -212,7 +222,7 @@ int jvae_gemm_launch(int M, int N, int K, int batch,
     p.A = A; p.sAm = sAm; p.sAk = sAk; p.sAb = sAb;
     p.B = B; p.sBk = sBk; p.sBn = sBn; p.sBb = sBb;
     p.C = C; p.sCm = sCm; p.sCn = sCn; p.sCb = sCb;
-    p.bias = bias; p.bias_mode = bias_mode;
+    p.bias = bias; p.bias_mode = bias_mode; p.bias_div = bias_div > 0 ? bias_div : 1;
     p.M = M; p.N = N; p.K = K;
     if (splitk < 1) splitk = 1;
     int ktiles = cdiv(K, BK);

@@ -11,6 +11,12 @@ int jvae_gemm_launch(int M, int N, int K, int batch,
                      float* C, long sCm, long sCn, long sCb,
                      const float* bias, int bias_mode, int flags, int splitk, hipStream_t st);
 
+int jvae_gemm_launch_ex(int M, int N, int K, int batch,
+                        const float* A, long sAm, long sAk, long sAb,
+                        const float* B, long sBk, long sBn, long sBb,
+                        float* C, long sCm, long sCn, long sCb,
+                        const float* bias, int bias_mode, int bias_div, int flags, int splitk, hipStream_t st);
+
 // Geometry of one (transposed) convolution.  "big" side = the tensor that is unfolded (conv input /
 // transposed-conv output), "small" side = the tensor on the folded grid (conv output / transposed-conv input).
 struct ConvGeom {

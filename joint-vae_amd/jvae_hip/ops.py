@@ -24,6 +24,20 @@ def _f32(t, what):
     return t
 
 
+def _grad_slot(param):
+    """The tensor a parameter gradient can be accumulated into in place (its existing, dense .grad), or None.
+
+    When the optimiser has flattened the model every .grad is a view of one zeroed flat buffer: the backward
+    kernels then add their result straight into it (exactly what autograd's AccumulateGrad would do with one
+    more elementwise kernel per parameter) and hand `None` back to autograd."""
+    if param is None or not isinstance(param, torch.nn.Parameter):
+        return None
+    g = param.grad
+    if g is None or not g.is_contiguous() or g.dtype != torch.float32 or g.shape != param.shape or not g.is_cuda:
+        return None
+    return g
+
+
 # ------------------------------------------------------------------------------------------- gemm
 def gemm(M, N, K, A, sA, B, sB, C, sC, bias=None, bias_mode=0, flags=0, splitk=1, batch=1):
     """Raw strided product on the current stream.  sA = (sAm, sAk, sAb) etc. (elements)."""
@@ -47,6 +61,7 @@ class _Linear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, act):
         x2 = _c(_f32(x, 'linear').reshape(-1, x.shape[-1]))
+        w_in = w
         w = _c(w)
         R, I = x2.shape
         O = w.shape[0]
@@ -59,6 +74,7 @@ class _Linear(torch.autograd.Function):
         ctx.act = act
         ctx.has_bias = b is not None
         ctx.xshape = x.shape
+        ctx.w_ref, ctx.b_ref = w_in, b
         return y.reshape(*x.shape[:-1], O)
 
     @staticmethod
@@ -78,12 +94,19 @@ class _Linear(torch.autograd.Function):
             gemm(R, I, O, gy, (O, 1, 0), w, (I, 1, 0), gx, (I, 1, 0))
             gx = gx.reshape(ctx.xshape)
         if ctx.needs_input_grad[1]:
-            gw = torch.zeros((O, I), device=gy.device, dtype=torch.float32)
+            slot = _grad_slot(ctx.w_ref)
+            gw = slot if slot is not None else torch.zeros((O, I), device=gy.device, dtype=torch.float32)
             tiles = ((O + 63) // 64) * ((I + 63) // 64)
             splitk = max(1, min(R // 64, 256 // max(tiles, 1)))
-            gemm(O, I, R, gy, (1, O, 0), x2, (I, 1, 0), gw, (I, 1, 0), splitk=splitk)
+            gemm(O, I, R, gy, (1, O, 0), x2, (I, 1, 0), gw, (I, 1, 0), splitk=splitk, flags=1)
+            if slot is not None:
+                gw = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = channel_sum(gy, R, O, 1)
+            slot = _grad_slot(ctx.b_ref)
+            if slot is not None:
+                channel_sum(gy, R, O, 1, out=slot, accumulate=True)
+            else:
+                gb = channel_sum(gy, R, O, 1)
         return gx, gw, gb, None
 
 
@@ -136,29 +159,36 @@ def conv_dgrad_raw(gy, w, spec, xshape):
     return gx
 
 
-def conv_wgrad_raw(x, gy, spec, wshape, want_bias):
+def conv_wgrad_raw(x, gy, spec, wshape, want_bias, w_slot=None, b_slot=None):
+    """-> (gw, gb).  With w_slot / b_slot (existing .grad tensors) the result is ADDED there and None is returned
+    for that gradient.  The C entry point takes one accumulate flag: both slots or neither."""
     N, _, H, W = x.shape
-    gw = torch.empty(wshape, device=x.device, dtype=torch.float32)
-    gb = torch.empty(spec.cout, device=x.device, dtype=torch.float32) if want_bias else None
+    inplace = w_slot is not None and (b_slot is not None or not want_bias)
+    gw = w_slot if inplace else torch.empty(wshape, device=x.device, dtype=torch.float32)
+    gb = None
+    if want_bias:
+        gb = b_slot if inplace else torch.empty(spec.cout, device=x.device, dtype=torch.float32)
     geom = spec.geom(N, H, W)
     ws, nb = _conv_ws(geom, x.device)
-    rc = L.load().jvae_conv2d_wgrad_f32(L.ptr(x), L.ptr(gy), L.ptr(gw), L.ptr(gb), 0, *geom, L.ptr(ws), nb,
+    rc = L.load().jvae_conv2d_wgrad_f32(L.ptr(x), L.ptr(gy), L.ptr(gw), L.ptr(gb), int(inplace), *geom, L.ptr(ws), nb,
                                         L.stream_ptr())
     L.check(rc, 'jvae_conv2d_wgrad_f32')
-    return gw, gb
+    return (None, None) if inplace else (gw, gb)
 
 
 class _Conv(torch.autograd.Function):
     """nn.Conv2d / nn.ConvTranspose2d (conv.py:186-196)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, spec):
+    def forward(ctx, x, w, b, spec, dead_bias):
         x = _c(_f32(x, 'conv'))
+        ctx.w_ref, ctx.b_ref = w, b
         w = _c(w)
         y = conv_fwd_raw(x, w, b, spec)
         ctx.save_for_backward(x, w)
         ctx.spec = spec
         ctx.has_bias = b is not None
+        ctx.dead_bias = dead_bias
         return y
 
     @staticmethod
@@ -168,13 +198,19 @@ class _Conv(torch.autograd.Function):
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             gx = conv_dgrad_raw(gy, w, ctx.spec, x.shape)
-        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            gw, gb = conv_wgrad_raw(x, gy, ctx.spec, w.shape, ctx.has_bias and ctx.needs_input_grad[2])
-        return gx, gw, gb, None
+        want_b = ctx.has_bias and ctx.needs_input_grad[2] and not ctx.dead_bias
+        if ctx.needs_input_grad[1] or want_b:
+            gw, gb = conv_wgrad_raw(x, gy, ctx.spec, w.shape, want_b, _grad_slot(ctx.w_ref),
+                                    _grad_slot(ctx.b_ref) if want_b else None)
+        if ctx.dead_bias and ctx.has_bias and ctx.needs_input_grad[2] and _grad_slot(ctx.b_ref) is None:
+            gb = torch.zeros_like(ctx.b_ref)          # exact value; makes the bias a regular optimiser citizen
+        return gx, gw, gb, None, None
 
 
-def conv2d(x, w, b, spec):
-    return _Conv.apply(x, w, b, spec)
+def conv2d(x, w, b, spec, dead_bias=False):
+    """dead_bias: the bias feeds a train-mode BatchNorm, which removes the channel mean: its true gradient is
+    exactly zero (what autograd would produce is rounding noise), so the channel reduction is skipped."""
+    return _Conv.apply(x, w, b, spec, dead_bias)
 
 
 # ------------------------------------------------------------------------------------------- batch norm
@@ -200,6 +236,7 @@ class _BatchNormAct(torch.autograd.Function):
             ctx.save_for_backward(x, gamma, beta, mean, invstd)
             ctx.relu = relu
             ctx.dims = (N, C, P)
+            ctx.g_ref, ctx.b_ref = gamma, beta
         else:
             ctx.dims = None
         return y
@@ -213,13 +250,18 @@ class _BatchNormAct(torch.autograd.Function):
         gy = _c(gy)
         lib = L.load()
         gx = torch.empty_like(x)
-        gg = torch.empty(C, device=x.device, dtype=torch.float32)
-        gb = torch.empty(C, device=x.device, dtype=torch.float32)
+        sg, sb = _grad_slot(ctx.g_ref), _grad_slot(ctx.b_ref)
+        inplace = sg is not None and sb is not None
+        gg = sg if inplace else torch.empty(C, device=x.device, dtype=torch.float32)
+        gb = sb if inplace else torch.empty(C, device=x.device, dtype=torch.float32)
         nb = lib.jvae_bn_workspace_bytes(C)
         ws = L.workspace(nb, x.device)
         rc = lib.jvae_bn_bwd_f32(L.ptr(gy), L.ptr(x), L.ptr(gamma), L.ptr(beta), L.ptr(mean), L.ptr(invstd), L.ptr(gx),
-                                 L.ptr(gg), L.ptr(gb), 0, N, C, P, int(ctx.relu), L.ptr(ws), ws.numel(), L.stream_ptr())
+                                 L.ptr(gg), L.ptr(gb), int(inplace), N, C, P, int(ctx.relu), L.ptr(ws), ws.numel(),
+                                 L.stream_ptr())
         L.check(rc, 'jvae_bn_bwd_f32')
+        if inplace:
+            gg = gb = None
         return gx, gg, gb, None, None, None, None, None, None, None
 
 

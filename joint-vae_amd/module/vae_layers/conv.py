@@ -93,8 +93,8 @@ class HipConv2d(nn.Conv2d):
     def _spec(self):
         return ops.ConvSpec(self.in_channels, self.out_channels, self.kernel_size[0], self.stride[0], self.padding[0])
 
-    def forward(self, x):
-        return ops.conv2d(x, self.weight, self.bias, self._spec())
+    def forward(self, x, dead_bias=False):
+        return ops.conv2d(x, self.weight, self.bias, self._spec(), dead_bias)
 
 
 class HipConvTranspose2d(nn.ConvTranspose2d):
@@ -102,8 +102,8 @@ class HipConvTranspose2d(nn.ConvTranspose2d):
         return ops.ConvSpec(self.in_channels, self.out_channels, self.kernel_size[0], self.stride[0], self.padding[0],
                             self.output_padding[0], transposed=True)
 
-    def forward(self, x, output_size=None):
-        return ops.conv2d(x, self.weight, self.bias, self._spec())
+    def forward(self, x, output_size=None, dead_bias=False):
+        return ops.conv2d(x, self.weight, self.bias, self._spec(), dead_bias)
 
 
 class HipBatchNorm2d(nn.BatchNorm2d):
@@ -127,7 +127,11 @@ class HipConvStack(nn.Sequential):
                 x = m(x, relu=ACT_OF_MODULE[type(mods[i + 1])] == ops.RELU)
                 i += 2
                 continue
-            x = m(x)
+            if isinstance(m, (HipConv2d, HipConvTranspose2d)) and i + 1 < len(mods) \
+                    and isinstance(mods[i + 1], HipBatchNorm2d) and mods[i + 1].training:
+                x = m(x, dead_bias=True)      # BatchNorm removes the channel mean: d(loss)/d(bias) == 0 exactly
+            else:
+                x = m(x)
             i += 1
         return x
 
