@@ -54,67 +54,70 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
     }
 }
 
-// coef[c] = (scale, shift) with y = x*scale + shift;  updates running stats;  saves mean / invstd.
-__global__ void bn_finalize_kernel(const float* __restrict__ x, const float* __restrict__ partial,
-                                   const float* __restrict__ gamma, const float* __restrict__ beta,
-                                   float* running_mean, float* running_var, long long* num_batches_tracked,
-                                   float* save_mean, float* save_invstd, float* coef,
-                                   int N, int C, int P, int nsplit, float momentum, float eps) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;
-    if (c >= C) return;
-    double s1 = 0., s2 = 0.;
-    for (int s = 0; s < nsplit; ++s) {
-        s1 += (double)partial[((long)c * nsplit + s) * 2 + 0];
-        s2 += (double)partial[((long)c * nsplit + s) * 2 + 1];
+// Forward apply, one block per (channel, image chunk).  The block first folds the channel's partial sums
+// (or the running statistics in eval mode) into y = fmaf(x, scale, shift); chunk 0 also publishes mean / invstd
+// and updates the running statistics, so no separate finalize launch is needed.
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ partial,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       float* running_mean, float* running_var, long long* num_batches_tracked,
+                                                       float* save_mean, float* save_invstd, float* __restrict__ y,
+                                                       int N, int C, int P, int nsplit, int nchunk, float momentum, float eps,
+                                                       int training, int relu) {
+    __shared__ float cs[2];
+    const int c = blockIdx.x, j = blockIdx.y;
+    if (threadIdx.x == 0) {
+        const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+        float mean, invstd;
+        if (training) {
+            double s1 = 0., s2 = 0.;
+            for (int s = 0; s < nsplit; ++s) {
+                s1 += (double)partial[((long)c * nsplit + s) * 2 + 0];
+                s2 += (double)partial[((long)c * nsplit + s) * 2 + 1];
+            }
+            const double n = (double)N * P;
+            const double dm = s1 / n;
+            double var = s2 / n - dm * dm;
+            if (var < 0.) var = 0.;
+            mean = (float)((double)x[(long)c * P] + dm);
+            invstd = (float)(1.0 / sqrt(var + (double)eps));
+            if (j == 0) {
+                save_mean[c] = mean;
+                save_invstd[c] = invstd;
+                if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+                if (running_var) {
+                    const float unbiased = (float)(n > 1. ? var * n / (n - 1.) : var);
+                    running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+                }
+                if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;
+            }
+        } else {
+            mean = running_mean[c];
+            invstd = rsqrtf(running_var[c] + eps);
+        }
+        bn_coef(g, b, mean, invstd, &cs[0], &cs[1]);
     }
-    const double n = (double)N * P;
-    const double dm = s1 / n;
-    double var = s2 / n - dm * dm;
-    if (var < 0.) var = 0.;
-    const float mean = (float)((double)x[(long)c * P] + dm);
-    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-    save_mean[c] = mean;
-    save_invstd[c] = invstd;
-    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
-    bn_coef(g, b, mean, invstd, &coef[2 * c + 0], &coef[2 * c + 1]);
-    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
-    if (running_var) {
-        const float unbiased = (float)(n > 1. ? var * n / (n - 1.) : var);
-        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
-    }
-}
-
-// eval mode: coefficients from the running statistics
-__global__ void bn_eval_coef_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
-                                    const float* __restrict__ running_mean, const float* __restrict__ running_var,
-                                    float* coef, int C, float eps) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    const float invstd = rsqrtf(running_var[c] + eps);
-    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
-    bn_coef(g, b, running_mean[c], invstd, &coef[2 * c + 0], &coef[2 * c + 1]);
-}
-
-// y = x*scale[c] + shift[c]  (optionally ReLU)
-__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ coef,
-                                                       float* __restrict__ y, long total, int C, int P, int relu) {
+    __syncthreads();
+    const float sc = cs[0], sh = cs[1];
+    const int per = (N + nchunk - 1) / nchunk;
+    const int nb = j * per, ne = min(N, nb + per);
     if ((P & 3) == 0) {
-        const long t4 = total >> 2;
         const int P4 = P >> 2;
-        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < t4; i += (long)gridDim.x * blockDim.x) {
-            const int c = (int)((i / P4) % C);
-            const float sc = coef[2 * c], sh = coef[2 * c + 1];
-            f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+        const long cnt = (long)(ne - nb) * P4;
+        for (long i = threadIdx.x; i < cnt; i += blockDim.x) {
+            const long n = nb + i / P4, q = i % P4;
+            const long off = (n * C + c) * (long)P + q * 4;
+            f32x4 v = *reinterpret_cast<const f32x4*>(x + off);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { float t = fmaf(v[j], sc, sh); v[j] = relu ? fmaxf(t, 0.f) : t; }
-            reinterpret_cast<f32x4*>(y)[i] = v;
+            for (int e = 0; e < 4; ++e) { const float t = fmaf(v[e], sc, sh); v[e] = relu ? fmaxf(t, 0.f) : t; }
+            *reinterpret_cast<f32x4*>(y + off) = v;
         }
     } else {
-        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-            const int c = (int)((i / P) % C);
-            float t = fmaf(x[i], coef[2 * c], coef[2 * c + 1]);
-            y[i] = relu ? fmaxf(t, 0.f) : t;
+        const long cnt = (long)(ne - nb) * P;
+        for (long i = threadIdx.x; i < cnt; i += blockDim.x) {
+            const long n = nb + i / P, q = i % P;
+            const long off = (n * C + c) * (long)P + q;
+            const float t = fmaf(x[off], sc, sh);
+            y[off] = relu ? fmaxf(t, 0.f) : t;
         }
     }
 }
@@ -134,15 +137,31 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     const int per = (N + nsplit - 1) / nsplit;
     const int nb = s * per, ne = min(N, nb + per);
     float s1 = 0.f, s2 = 0.f;
-    const long cnt = (long)(ne - nb) * P;
-    for (long i = threadIdx.x; i < cnt; i += blockDim.x) {
-        const long n = nb + i / P, q = i % P;
-        const long idx = (n * C + c) * (long)P + q;
-        const float xv = x[idx];
-        const float xh = (xv - mu) * is;
-        float g = dy[idx];
-        if (relu && !(fmaf(xv, sc, sh) > 0.f)) g = 0.f;
-        s1 += g; s2 += g * xh;
+    if ((P & 3) == 0) {
+        const int P4 = P >> 2;
+        const long cnt = (long)(ne - nb) * P4;
+        for (long i = threadIdx.x; i < cnt; i += blockDim.x) {
+            const long n = nb + i / P4, q = i % P4;
+            const long off = (n * C + c) * (long)P + q * 4;
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(x + off);
+            const f32x4 gv = *reinterpret_cast<const f32x4*>(dy + off);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float g = gv[e];
+                if (relu && !(fmaf(xv[e], sc, sh) > 0.f)) g = 0.f;
+                s1 += g; s2 += g * ((xv[e] - mu) * is);
+            }
+        }
+    } else {
+        const long cnt = (long)(ne - nb) * P;
+        for (long i = threadIdx.x; i < cnt; i += blockDim.x) {
+            const long n = nb + i / P, q = i % P;
+            const long idx = (n * C + c) * (long)P + q;
+            const float xv = x[idx];
+            float g = dy[idx];
+            if (relu && !(fmaf(xv, sc, sh) > 0.f)) g = 0.f;
+            s1 += g; s2 += g * ((xv - mu) * is);
+        }
     }
     s1 = block_sum(s1, red);
     s2 = block_sum(s2, red);
@@ -152,40 +171,65 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     }
 }
 
-// sums[c] = (sum g / M, sum g*xhat / M); dgamma / dbeta written (or accumulated)
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, float* __restrict__ sums,
-                                       float* dgamma, float* dbeta, int accumulate, int N, int C, int P, int nsplit) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s1 = 0., s2 = 0.;
-    for (int s = 0; s < nsplit; ++s) {
-        s1 += (double)partial[((long)c * nsplit + s) * 2 + 0];
-        s2 += (double)partial[((long)c * nsplit + s) * 2 + 1];
-    }
-    const double M = (double)N * P;
-    sums[2 * c + 0] = (float)(s1 / M);
-    sums[2 * c + 1] = (float)(s2 / M);
-    if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s1;
-    if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)s2;
-}
-
-// dx = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat))
+// dx = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)); one block per (channel, image chunk); the block folds the
+// partial sums itself and chunk 0 writes (or accumulates) dgamma / dbeta.
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                           const float* __restrict__ sums, float* __restrict__ dx,
-                                                           long total, int C, int P, int relu) {
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int c = (int)((i / P) % C);
-        const float is = invstd[c];
-        const float g_ = gamma ? gamma[c] : 1.f, b_ = beta ? beta[c] : 0.f;
-        float sc, sh;
-        bn_coef(g_, b_, mean[c], is, &sc, &sh);
-        const float xv = x[i];
-        const float xh = (xv - mean[c]) * is;
-        float g = dy[i];
-        if (relu && !(fmaf(xv, sc, sh) > 0.f)) g = 0.f;
-        dx[i] = g_ * is * (g - sums[2 * c] - xh * sums[2 * c + 1]);
+                                                           const float* __restrict__ partial, float* __restrict__ dx,
+                                                           float* dgamma, float* dbeta, int accumulate,
+                                                           int N, int C, int P, int nsplit, int nchunk, int relu) {
+    __shared__ float ms[2];
+    const int c = blockIdx.x, j = blockIdx.y;
+    if (threadIdx.x == 0) {
+        double s1 = 0., s2 = 0.;
+        for (int s = 0; s < nsplit; ++s) {
+            s1 += (double)partial[((long)c * nsplit + s) * 2 + 0];
+            s2 += (double)partial[((long)c * nsplit + s) * 2 + 1];
+        }
+        const double M = (double)N * P;
+        ms[0] = (float)(s1 / M);
+        ms[1] = (float)(s2 / M);
+        if (j == 0) {
+            if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s1;
+            if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)s2;
+        }
+    }
+    __syncthreads();
+    const float m1 = ms[0], m2 = ms[1];
+    const float mu = mean[c], is = invstd[c];
+    const float g_ = gamma ? gamma[c] : 1.f, b_ = beta ? beta[c] : 0.f;
+    float sc, sh;
+    bn_coef(g_, b_, mu, is, &sc, &sh);
+    const float k = g_ * is;
+    const int per = (N + nchunk - 1) / nchunk;
+    const int nb = j * per, ne = min(N, nb + per);
+    if ((P & 3) == 0) {
+        const int P4 = P >> 2;
+        const long cnt = (long)(ne - nb) * P4;
+        for (long i = threadIdx.x; i < cnt; i += blockDim.x) {
+            const long n = nb + i / P4, q = i % P4;
+            const long off = (n * C + c) * (long)P + q * 4;
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(x + off);
+            f32x4 gv = *reinterpret_cast<const f32x4*>(dy + off);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float g = gv[e];
+                if (relu && !(fmaf(xv[e], sc, sh) > 0.f)) g = 0.f;
+                gv[e] = k * (g - m1 - ((xv[e] - mu) * is) * m2);
+            }
+            *reinterpret_cast<f32x4*>(dx + off) = gv;
+        }
+    } else {
+        const long cnt = (long)(ne - nb) * P;
+        for (long i = threadIdx.x; i < cnt; i += blockDim.x) {
+            const long n = nb + i / P, q = i % P;
+            const long idx = (n * C + c) * (long)P + q;
+            const float xv = x[idx];
+            float g = dy[idx];
+            if (relu && !(fmaf(xv, sc, sh) > 0.f)) g = 0.f;
+            dx[idx] = k * (g - m1 - ((xv - mu) * is) * m2);
+        }
     }
 }
 
@@ -200,9 +244,15 @@ inline int pick_split(int N, int C, int P) {
     return s < 1 ? 1 : s;
 }
 
-inline int ew_grid(long total4) {
-    long b = (total4 + 255) / 256;
-    return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
+// image chunks per channel for the apply kernels: ~16K elements per block, <= 64 chunks
+inline int pick_chunk(int N, int C, int P) {
+    long work = (long)N * P;
+    int s = (int)(work / 16384);
+    if (s < 1) s = 1;
+    int cap = (4096 + C - 1) / C;
+    if (s > cap) s = cap;
+    if (s > N) s = N;
+    return s < 1 ? 1 : s;
 }
 
 }  // namespace
@@ -222,24 +272,18 @@ int jvae_bn_fwd_f32(const float* x, const float* gamma, const float* beta,
     if (N == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     float* partial = (float*)ws;
-    float* coef = partial + (size_t)2 * C * MAX_SPLIT;
+    int ns = 1;
     if (training) {
         if (!save_mean || !save_invstd) return JVAE_EINVAL;
-        const int ns = pick_split(N, C, P);
+        ns = pick_split(N, C, P);
         hipLaunchKernelGGL(bn_stats_kernel, dim3(C, ns), dim3(256), 0, st, x, partial, N, C, P, ns);
         JVAE_LAUNCH_CHECK();
-        hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, x, partial, gamma, beta,
-                           running_mean, running_var, num_batches_tracked, save_mean, save_invstd, coef,
-                           N, C, P, ns, momentum, eps);
-        JVAE_LAUNCH_CHECK();
-    } else {
-        if (!running_mean || !running_var) return JVAE_EINVAL;
-        hipLaunchKernelGGL(bn_eval_coef_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, gamma, beta, running_mean,
-                           running_var, coef, C, eps);
-        JVAE_LAUNCH_CHECK();
+    } else if (!running_mean || !running_var) {
+        return JVAE_EINVAL;
     }
-    const long total = (long)N * C * P;
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(total / 4 + 1)), dim3(256), 0, st, x, coef, y, total, C, P, relu);
+    const int nc = pick_chunk(N, C, P);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(C, nc), dim3(256), 0, st, x, partial, gamma, beta, running_mean, running_var,
+                       num_batches_tracked, save_mean, save_invstd, y, N, C, P, ns, nc, momentum, eps, training, relu);
     JVAE_LAUNCH_CHECK();
     return 0;
 }
@@ -253,17 +297,13 @@ int jvae_bn_bwd_f32(const float* dy, const float* x, const float* gamma, const f
     if (N == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     float* partial = (float*)ws;
-    float* sums = partial + (size_t)2 * C * MAX_SPLIT;
     const int ns = pick_split(N, C, P);
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C, ns), dim3(256), 0, st, dy, x, gamma, beta, save_mean, save_invstd,
                        partial, N, C, P, ns, relu);
     JVAE_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, partial, sums, dgamma, dbeta,
-                       accumulate, N, C, P, ns);
-    JVAE_LAUNCH_CHECK();
-    const long total = (long)N * C * P;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(total)), dim3(256), 0, st, dy, x, gamma, beta, save_mean,
-                       save_invstd, sums, dx, total, C, P, relu);
+    const int nc = pick_chunk(N, C, P);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(C, nc), dim3(256), 0, st, dy, x, gamma, beta, save_mean, save_invstd,
+                       partial, dx, dgamma, dbeta, accumulate, N, C, P, ns, nc, relu);
     JVAE_LAUNCH_CHECK();
     return 0;
 }

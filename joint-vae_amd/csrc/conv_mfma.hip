@@ -213,11 +213,18 @@ int launch_fwd(const FwdP& p, hipStream_t st) {
     return 0;
 }
 
+// Tile choice: the largest tile that still gives the chip >= ~3 workgroups per CU (256 CUs); small feature maps
+// (8x8, 16x16 at batch 512) fall back to 256- or 128-pixel tiles x 32 channels.
 template <int S, int OW>
 int launch_fwd_ow(const FwdP& p, hipStream_t st) {
-    if (p.Cout % 64 == 0) return launch_fwd<S, OW, 2, 2, 4>(p, st);
+    const long pixels = (long)p.N * OW * OW;
+    auto wgs = [&](int mt, int nt) { return ((pixels + mt * 128 - 1) / (mt * 128)) * (p.Cout / (nt * 32)); };
+    constexpr long ENOUGH = 768;
     if (p.Cin <= 4) return launch_fwd<S, OW, 4, 1, 4>(p, st);      // 3-channel inputs: one chunk of 2 channel pairs
-    return launch_fwd<S, OW, 4, 1, (S == 1 ? 8 : 4)>(p, st);
+    if (p.Cout % 64 == 0 && wgs(2, 2) >= ENOUGH) return launch_fwd<S, OW, 2, 2, 4>(p, st);
+    if (wgs(4, 1) >= ENOUGH) return launch_fwd<S, OW, 4, 1, (S == 1 ? 8 : 4)>(p, st);
+    if (wgs(2, 1) >= ENOUGH) return launch_fwd<S, OW, 2, 1, 4>(p, st);
+    return launch_fwd<S, OW, 1, 1, 4>(p, st);
 }
 
 }  // namespace

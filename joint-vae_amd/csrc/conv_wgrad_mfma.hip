@@ -227,12 +227,15 @@ bool jvae_conv5_wgrad_ok(int Ca, int HS, int WS, int Cb, int HB, int WB, int S, 
 }
 
 static int slab_count(int N, int Ca, int Cb, int S, int WS) {
+    // ~512 workgroups in total (2 per CU; fatter slabs amortise the zero-fill / slab write / reduce), every slab
+    // with the same number of images (no idle tail)
     const int cb = pick_cb(S, WS, Cb);
     const int per = ((Ca + 31) / 32) * ((Cb + cb - 1) / cb);
-    int g = 512 / per;
-    if (g < 1) g = 1;
-    if (g > N) g = N;
-    return g;
+    int target = 512 / per;
+    if (target < 1) target = 1;
+    int imgs = (N + target - 1) / target;         // images per slab
+    if (imgs < 1) imgs = 1;
+    return (N + imgs - 1) / imgs;
 }
 
 size_t jvae_conv5_wgrad_ws_floats(int N, int Ca, int Cb, int S, int WS) {

@@ -14,7 +14,8 @@
 
 namespace {
 
-constexpr int BK = 16;
+constexpr int BK = 32;          // 64 MFMAs (128x128 tile) between two barriers
+constexpr int KQ = BK / 4;      // float4 groups along k
 
 struct GemmP {
     const float* A; long sAm, sAk, sAb;
@@ -80,7 +81,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
 #pragma unroll
         for (int g = 0; g < GA; ++g) {
             if (AK) {
-                const int kq = tid & 3, row = (tid >> 2) + g * 64;
+                const int kq = tid % KQ, row = tid / KQ + g * (256 / KQ);
                 const int m = m0 + row, k = k0 + kq * 4;
                 const float* src = A + (long)m * p.sAm + (long)k * p.sAk;
                 ra[g] = p.vecA ? load4<true>(src, p.sAk, k, kend, m < p.M) : load4<false>(src, p.sAk, k, kend, m < p.M);
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
                 const float* src = B + (long)k * p.sBk + (long)n * p.sBn;
                 rb[g] = p.vecB ? load4<true>(src, p.sBn, n, p.N, k < kend) : load4<false>(src, p.sBn, n, p.N, k < kend);
             } else {
-                const int kq = tid & 3, col = (tid >> 2) + g * 64;
+                const int kq = tid % KQ, col = tid / KQ + g * (256 / KQ);
                 const int n = n0 + col, k = k0 + kq * 4;
                 const float* src = B + (long)k * p.sBk + (long)n * p.sBn;
                 rb[g] = p.vecB ? load4<true>(src, p.sBk, k, kend, n < p.N) : load4<false>(src, p.sBk, k, kend, n < p.N);
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
 #pragma unroll
         for (int g = 0; g < GA; ++g) {
             if (AK) {
-                const int kq = tid & 3, row = (tid >> 2) + g * 64;
+                const int kq = tid % KQ, row = tid / KQ + g * (256 / KQ);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) As[(kq * 4 + j) * LDA + row] = ra[g][j];
             } else {
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
                 const int nq = tid % GPR, kr = tid / GPR + g * (256 / GPR);
                 *reinterpret_cast<f32x4*>(&Bs[kr * LDB + nq * 4]) = rb[g];
             } else {
-                const int kq = tid & 3, col = (tid >> 2) + g * 64;
+                const int kq = tid % KQ, col = tid / KQ + g * (256 / KQ);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) Bs[(kq * 4 + j) * LDB + col] = rb[g][j];
             }
