@@ -58,9 +58,13 @@ def dominant_kernel_roofline(device, reps=20):
     torch.cuda.synchronize()
     sec = e0.elapsed_time(e1) * 1e-3 / reps
     flops = 2.0 * N * H * H * C * C * 25
+    traffic = None
+    pmc = os.path.join(REPO, 'profiles', 'r01_dominant_kernel_pmc.json')
+    if os.path.exists(pmc):           # HBM bytes per launch from the separate rocprofv3 --pmc passes
+        traffic = json.load(open(pmc)).get('hbm_bytes_per_launch')
     return {'bound': 'mfma', 'kernel': 'conv2d_fwd imager.15 (ConvT 32->32 5x5 s1, 1024x32x32x32)',
             'achieved': flops / sec / 1e12, 'peak': MFMA_F32_PEAK / 1e12, 'unit': 'TFLOP/s',
-            'frac': flops / sec / MFMA_F32_PEAK, 'traffic': None, 'launch_ms': sec * 1e3}
+            'frac': flops / sec / MFMA_F32_PEAK, 'traffic': traffic, 'launch_ms': sec * 1e3}
 
 
 def cpu_baseline(max_seconds=25.0):

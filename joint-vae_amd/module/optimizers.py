@@ -147,11 +147,9 @@ class Optimizer:
         known = self._flat_ids()
         fresh = [p for p in self._all if id(p) not in known and p.requires_grad and p.grad is not None]
         if fresh:
-            dev = fresh[0].device
-            if dev.type != 'cuda':
-                raise RuntimeError('module.optimizers.Optimizer runs on the GPU only (parameters are on {}); '
-                                   'there is no CPU fallback'.format(dev))
-            self._groups.append(_FlatGroup(fresh, dev))
+            # flattening itself is device-agnostic (the data-parallel exchange is tested on CPU with gloo);
+            # clip() / step() launch HIP kernels and raise for tensors that are not on the GPU
+            self._groups.append(_FlatGroup(fresh, fresh[0].device))
 
     def _rebuild(self):
         """Something moved the parameters (.to(), load_state_dict, requires_grad flip): re-flatten, keep state."""
