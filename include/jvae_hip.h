@@ -113,6 +113,22 @@ int jvae_recon_bwd_f32(const float* x_reco, const float* x, const float* sigma, 
                        const float* g_wmse, const float* wmse, float* g_x_reco, float* gsigma, int accumulate_sigma,
                        int L, int N, int D, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- ELBO assembly (cvae.py:773-791,887-902): wmse = mean_l wmse_s; cross_x = D/2 (2 log sigma + wmse + log 2pi);
+ * total = cross_x + cw * ce + beta * kl   (ce may be NULL).  Backward takes the upstream gradients of the three
+ * outputs (any may be NULL) and returns g_wmse_s (L,N), g_kl, g_ce (N,) and d/d sigma of the 2 log sigma term. */
+int jvae_elbo_fwd_f32(const float* wmse_s, const float* kl, const float* ce, const float* sigma, int sigma_is_log,
+                      float* wmse, float* cross_x, float* total, int L, int N, int D, float beta, float cw, void* stream);
+int jvae_elbo_bwd_f32(const float* g_wmse, const float* g_cx, const float* g_tot, const float* sigma, int sigma_is_log,
+                      float* g_wmse_s, float* g_kl, float* g_ce, float* gsigma, int accumulate_sigma,
+                      int L, int N, int D, float beta, float cw, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- running measures of evaluate() in ONE device buffer (cvae.py:619-624,689-724,747-762; Encoder.capacity /
+ * dict_min_distance layers.py:323-348): out[10] = sigma, mean x^2, mean mse, rmse, mean zdist, mean var_kl, ld-norm,
+ * imut-zy, d-mind, optimiser non-finite flag.  sumsq_x = sum(x^2) from jvae_sqnorm_accum_f32; means may be NULL. */
+int jvae_measures_f32(const float* sumsq_x, long nx, const float* wmse, const float* zdist, const float* var_kl, int N,
+                      const float* sigma, int sigma_is_log, const float* means, int C, int K, const int* flag,
+                      float* out, void* stream);
+
 /* ---- classification term: per-row cross entropy, target y[r % N] (x_loss, module/losses.py:52-86) -- */
 int jvae_xent_fwd_f32(const float* logits, const long long* y, float* ce, int R, int N, int C, void* stream);
 int jvae_xent_bwd_f32(const float* logits, const long long* y, const float* g_ce, float* g_logits, int R, int N, int C,

@@ -129,6 +129,110 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
     }
 }
 
+// ---- ELBO assembly (cvae.py:773-791,887-902): per-sample, N threads ------------------------------------------
+//   wmse = mean_l wmse_s ; cross_x = D/2 (2 log sigma + wmse + log 2pi) ; total = cross_x + cw*ce + beta*kl
+__global__ __launch_bounds__(256) void elbo_fwd_kernel(const float* __restrict__ wmse_s, const float* __restrict__ kl,
+                                                       const float* __restrict__ ce, const float* __restrict__ sigma,
+                                                       int sigma_is_log, float* __restrict__ wmse, float* __restrict__ cross_x,
+                                                       float* __restrict__ total, int L, int N, float D, float beta, float cw) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int l = 0; l < L; ++l) s += wmse_s[(long)l * N + n];
+    s /= L;
+    const float ls = sigma_is_log ? sigma[0] : __logf(sigma[0]);
+    const float cx = 0.5f * D * (2.f * ls + s + 1.8378770664093453f);
+    wmse[n] = s;
+    cross_x[n] = cx;
+    total[n] = cx + (ce ? cw * ce[n] : 0.f) + beta * kl[n];
+}
+
+// upstream g_wmse / g_cx / g_tot (N,) (any may be null) -> g_wmse_s (L,N), g_kl, g_ce (N,), gsig_part (N,)
+__global__ __launch_bounds__(256) void elbo_bwd_kernel(const float* __restrict__ g_wmse, const float* __restrict__ g_cx,
+                                                       const float* __restrict__ g_tot, const float* __restrict__ sigma,
+                                                       int sigma_is_log, float* __restrict__ g_wmse_s, float* __restrict__ g_kl,
+                                                       float* __restrict__ g_ce, float* __restrict__ gsig_part,
+                                                       int L, int N, float D, float beta, float cw) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float gt = g_tot ? g_tot[n] : 0.f;
+    const float gc = (g_cx ? g_cx[n] : 0.f) + gt;
+    const float gw = ((g_wmse ? g_wmse[n] : 0.f) + gc * 0.5f * D) / L;
+    for (int l = 0; l < L; ++l) g_wmse_s[(long)l * N + n] = gw;
+    if (g_kl) g_kl[n] = beta * gt;
+    if (g_ce) g_ce[n] = cw * gt;
+    if (gsig_part) gsig_part[n] = sigma_is_log ? gc * D : gc * D / sigma[0];
+}
+
+// ---- packed measures (cvae.py:619-624,689-724,747-762 + layers.py:323-348): ONE device buffer, ONE read-back -----
+// out[0] sigma rms, [1] mean x^2 (from sumsq), [2] mean mse, [3] rmse = sqrt([2]), [4] mean zdist, [5] mean var_kl,
+// [6] ld-norm = mean(m^2), [7] imut-zy (capacity bound), [8] d-mind, [9] non-finite flag of the optimiser
+__global__ __launch_bounds__(256) void measures_kernel(const float* __restrict__ sumsq_x, float nx,
+                                                       const float* __restrict__ wmse, const float* __restrict__ zdist,
+                                                       const float* __restrict__ var_kl, int N,
+                                                       const float* __restrict__ sigma, int sigma_is_log,
+                                                       const float* __restrict__ means, int C, int K,
+                                                       const int* __restrict__ flag, float* __restrict__ out) {
+    __shared__ float red[17];
+    __shared__ float rowsum[128];
+    const int tid = threadIdx.x;
+    const float sg = sigma_is_log ? __expf(sigma[0]) : sigma[0];
+    float a = 0.f, b = 0.f, c = 0.f;
+    for (int i = tid; i < N; i += blockDim.x) { a += wmse[i]; b += zdist[i]; c += var_kl[i]; }
+    a = block_sum(a, red); b = block_sum(b, red); c = block_sum(c, red);
+    float msq = 0.f, mx = 0.f;
+    if (means) {
+        for (int i = tid; i < C * K; i += blockDim.x) msq += means[i] * means[i];
+        msq = block_sum(msq, red);
+    }
+    float cap = 0.f, dmin = INFINITY;
+    if (means) {
+        // pairwise squared distances; row r handled by thread groups: C <= 128 rows per pass
+        for (int r0 = 0; r0 < C; r0 += 128) {
+            __syncthreads();
+            if (tid < 128) rowsum[tid] = 0.f;
+            __syncthreads();
+            float maxn = 0.f;
+            for (int r = r0 + tid; r < C && r < r0 + 128; r += blockDim.x) {
+                float e = 0.f, nr = 0.f;
+                for (int k = 0; k < K; ++k) nr += means[(long)r * K + k] * means[(long)r * K + k];
+                for (int q = 0; q < C; ++q) {
+                    float d2 = 0.f;
+                    for (int k = 0; k < K; ++k) { const float t = means[(long)r * K + k] - means[(long)q * K + k]; d2 += t * t; }
+                    e += __expf(-d2 / 4.f);
+                    if (q != r) dmin = fminf(dmin, sqrtf(d2));
+                }
+                cap += __logf(e);
+                maxn = fmaxf(maxn, sqrtf(nr));
+            }
+            mx = fmaxf(mx, maxn);
+        }
+        cap = block_sum(cap, red);
+        // block-wide max / min through the sum helper's scratch: do it with shuffles + LDS
+        float vmax = wave_max(mx), vmin = -wave_max(-dmin);
+        __syncthreads();
+        if ((tid & 63) == 0) { rowsum[tid >> 6] = vmax; rowsum[8 + (tid >> 6)] = vmin; }
+        __syncthreads();
+        if (tid == 0) {
+            const int nw = (blockDim.x + 63) >> 6;
+            for (int w = 0; w < nw; ++w) { mx = fmaxf(mx, rowsum[w]); dmin = fminf(dmin, rowsum[8 + w]); }
+        }
+    }
+    if (tid == 0) {
+        const float mse = a / N * sg * sg;
+        out[0] = sg;
+        out[1] = sumsq_x[0] / nx;
+        out[2] = mse;
+        out[3] = sqrtf(mse);
+        out[4] = b / N;
+        out[5] = c / N;
+        out[6] = means ? msq / (C * K) : 0.f;
+        out[7] = means ? __logf((float)C) - cap / C : 0.f;
+        out[8] = means ? fminf(dmin, 2.f * mx) : 0.f;          // (cdist + 2 max|m| I).min(), layers.py:338-348
+        out[9] = flag ? (float)flag[0] : 0.f;
+    }
+}
+
 inline int ew_grid(long n) {
     long b = (n + 255) / 256;
     return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
@@ -195,6 +299,46 @@ int jvae_act_bwd_f32(const float* dy, const float* y, float* dx, long n, int kin
     if (!dy || !y || !dx || n < 0 || kind < 0 || kind > 2) return JVAE_EINVAL;
     if (n == 0) return 0;
     hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, dy, y, dx, n, kind);
+    JVAE_LAUNCH_CHECK();
+    return 0;
+}
+
+int jvae_elbo_fwd_f32(const float* wmse_s, const float* kl, const float* ce, const float* sigma, int sigma_is_log,
+                      float* wmse, float* cross_x, float* total, int L, int N, int D, float beta, float cw, void* stream) {
+    if (!wmse_s || !kl || !sigma || !wmse || !cross_x || !total || L < 1 || N < 0 || D <= 0) return JVAE_EINVAL;
+    if (N == 0) return 0;
+    hipLaunchKernelGGL(elbo_fwd_kernel, dim3(cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, wmse_s, kl, ce, sigma,
+                       sigma_is_log, wmse, cross_x, total, L, N, (float)D, beta, cw);
+    JVAE_LAUNCH_CHECK();
+    return 0;
+}
+
+// gsigma (1 float, may be null): sum_n (g_cx + g_tot) * D [/ sigma]; ws: N floats when gsigma != null
+int jvae_elbo_bwd_f32(const float* g_wmse, const float* g_cx, const float* g_tot, const float* sigma, int sigma_is_log,
+                      float* g_wmse_s, float* g_kl, float* g_ce, float* gsigma, int accumulate_sigma,
+                      int L, int N, int D, float beta, float cw, void* ws, size_t ws_bytes, void* stream) {
+    if (!sigma || !g_wmse_s || L < 1 || N < 0 || D <= 0) return JVAE_EINVAL;
+    if (gsigma && (!ws || ws_bytes < sizeof(float) * (size_t)N)) return JVAE_EWORKSPACE;
+    if (N == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(elbo_bwd_kernel, dim3(cdiv(N, 256)), dim3(256), 0, st, g_wmse, g_cx, g_tot, sigma, sigma_is_log,
+                       g_wmse_s, g_kl, g_ce, gsigma ? (float*)ws : nullptr, L, N, (float)D, beta, cw);
+    JVAE_LAUNCH_CHECK();
+    if (gsigma) {
+        hipLaunchKernelGGL(vec_sum_kernel, dim3(1), dim3(256), 0, st, (const float*)ws, gsigma, N, accumulate_sigma);
+        JVAE_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+// out: 10 floats on the device (layout: see measures_kernel).  sumsq_x: device scalar = sum(x^2) (jvae_sqnorm_accum_f32).
+int jvae_measures_f32(const float* sumsq_x, long nx, const float* wmse, const float* zdist, const float* var_kl, int N,
+                      const float* sigma, int sigma_is_log, const float* means, int C, int K, const int* flag,
+                      float* out, void* stream) {
+    if (!sumsq_x || !wmse || !zdist || !var_kl || !sigma || !out || N <= 0 || nx <= 0) return JVAE_EINVAL;
+    if (means && (C <= 0 || K <= 0)) return JVAE_EINVAL;
+    hipLaunchKernelGGL(measures_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, sumsq_x, (float)nx, wmse, zdist, var_kl,
+                       N, sigma, sigma_is_log, means, C, K, flag, out);
     JVAE_LAUNCH_CHECK();
     return 0;
 }

@@ -305,28 +305,25 @@ class ClassificationVariationalNetwork(nn.Module):
 
         s = self.sigma
         wmse_s = ops.recon_wmse(x_reco, x, s, s.is_log)                     # (L, N)
-        wmse = wmse_s.mean(0)
-        log_sigma = s.squeeze() if s.is_log else s.log().squeeze()
-        sigma2 = (2 * s).exp() if s.is_log else s ** 2
-        mse = wmse * sigma2
-
+        ce = None
+        if self.y_is_decoded:
+            ce = x_loss(y, logits, batch_mean=False)                         # all L+1 rows, as cvae.py:738 does
+        wmse, cross_x, total = ops.elbo(wmse_s, terms['kl'], ce if cross_y_weight else None, s, s.is_log, D,
+                                        self.beta if with_beta else 1., float(cross_y_weight or 0.))
         losses = {'kl': terms['kl'], 'zdist': terms['distance'], 'var_kl': terms['var_kl']}
         dictionary = self.encoder.prior.mean if self.encoder.prior.conditional else None
         if dictionary is not None:
             losses['dzdist'] = terms['dzdist']
         losses['wmse'] = wmse
-        losses['cross_x'] = D * (2 * log_sigma + wmse + LOG2PI) / 2          # sigma_dims = 1 (scalar sigma)
-        total = losses['cross_x']
-        if self.y_is_decoded:
-            losses['cross_y'] = x_loss(y, logits, batch_mean=False)          # all L+1 rows, as cvae.py:738 does
-            if cross_y_weight:
-                total = total + cross_y_weight * losses['cross_y']
-        total = total + (self.beta if with_beta else 1.) * losses['kl']
+        losses['cross_x'] = cross_x
+        if ce is not None:
+            losses['cross_y'] = ce
         losses['total'] = total
-        if self.training:
-            self.sigma.update(rmse=mse.detach().mean().sqrt())
 
-        measures = self._measures(x, mse, terms, dictionary, batch, current_measures)
+        packed = self._pack_measures(x, wmse, terms, dictionary)
+        if self.training:
+            self.sigma.update(rmse=packed[3])                                # device scalar, as in the reference
+        measures = self._measures(packed.tolist(), dictionary is not None, batch, current_measures)
         if self.training:
             self.training_parameters['sigma'] = self.sigma.host_params(measures['sigma'])
         out = (x_reco, logits[1:].mean(0), losses, measures)
@@ -334,21 +331,21 @@ class ClassificationVariationalNetwork(nn.Module):
             out += (mu, log_var, z)
         return out
 
-    def _measures(self, x, mse, terms, dictionary, batch, current):
-        """Running means as Python floats (cvae.py:619-624,689-724,755-762) from one device->host copy."""
+    def _pack_measures(self, x, wmse, terms, dictionary):
+        """Every scalar evaluate() reports, computed by one kernel into one 10-float device buffer."""
+        with torch.no_grad():
+            if getattr(self, '_scratch', None) is None or self._scratch.device != x.device:
+                self._scratch = torch.zeros(1, device=x.device, dtype=torch.float32)
+            return ops.measures(x, wmse.detach(), terms['distance'].detach(), terms['var_kl'].detach(),
+                                self.sigma.detach(), self.sigma.is_log,
+                                None if dictionary is None else dictionary.detach(),
+                                self.optimizer.nonfinite_flag(), self._scratch)
+
+    def _measures(self, host, has_dictionary, batch, current):
+        """Running means as Python floats (cvae.py:619-624,689-724,755-762) from the ONE device->host copy."""
         if not current:
             current = {k: 0. for k in ('xpow', 'mse', 'dB', 'imut-zy', 'd-mind', 'ld-norm', 'var_kl', 'zdist')}
-        with torch.no_grad():
-            s = self.sigma.detach()
-            vals = [((2 * s).exp() if self.sigma.is_log else s.pow(2)).mean().sqrt(),
-                    x.pow(2).mean(), mse.mean(), terms['distance'].mean(), terms['var_kl'].mean()]
-            if dictionary is not None:
-                vals += [dictionary.pow(2).mean(), self.encoder.capacity(), self.encoder.dict_min_distance()]
-            flag = self.optimizer.nonfinite_flag()
-            if flag is not None:
-                vals.append(flag.float().squeeze())
-            host = torch.stack([v.reshape(()) for v in vals]).tolist()
-        if flag is not None and host[-1] != 0:
+        if host[9] != 0:
             print('GRAD NAN')                       # cvae.py:2454-2457 (reported one step later: no extra sync)
             sys.exit(1)
         m = {'sigma': host[0]}
@@ -359,10 +356,10 @@ class ClassificationVariationalNetwork(nn.Module):
         m['mse'] = run('mse', host[2])
         m['rmse'] = math.sqrt(m['mse'])
         m['dB'] = 10 * math.log10(m['xpow'] / m['mse'])
-        m['zdist'] = run('zdist', host[3])
-        m['var_kl'] = run('var_kl', host[4])
-        if dictionary is not None:
-            m['ld-norm'], m['imut-zy'], m['d-mind'] = host[5], host[6], host[7]
+        m['zdist'] = run('zdist', host[4])
+        m['var_kl'] = run('var_kl', host[5])
+        if has_dictionary:
+            m['ld-norm'], m['imut-zy'], m['d-mind'] = host[6], host[7], host[8]
         return m
 
     # ------------------------------------------------------------------------------------ training loop

@@ -413,6 +413,61 @@ def recon_wmse(x_reco, x, sigma, sigma_is_log):
     return _Recon.apply(x_reco, x, sigma, sigma_is_log)
 
 
+class _Elbo(torch.autograd.Function):
+    """wmse_s (L,N), kl (N,), ce (N,)|None, sigma -> (wmse, cross_x, total) (cvae.py:773-791,887-902)."""
+
+    @staticmethod
+    def forward(ctx, wmse_s, kl, ce, sigma, sigma_is_log, D, beta, cw):
+        wmse_s, kl, sigma = _c(wmse_s), _c(kl), _c(sigma)
+        ce = None if ce is None else _c(ce)
+        Ls, N = wmse_s.shape
+        wmse, cx, tot = (torch.empty(N, device=kl.device, dtype=torch.float32) for _ in range(3))
+        rc = L.load().jvae_elbo_fwd_f32(L.ptr(wmse_s), L.ptr(kl), L.ptr(ce), L.ptr(sigma), int(sigma_is_log), L.ptr(wmse),
+                                        L.ptr(cx), L.ptr(tot), Ls, N, int(D), float(beta), float(cw), L.stream_ptr())
+        L.check(rc, 'jvae_elbo_fwd_f32')
+        ctx.save_for_backward(sigma)
+        ctx.cfg = (sigma_is_log, Ls, N, int(D), float(beta), float(cw), ce is not None)
+        ctx.set_materialize_grads(False)
+        return wmse, cx, tot
+
+    @staticmethod
+    def backward(ctx, g_wmse, g_cx, g_tot):
+        sigma, = ctx.saved_tensors
+        is_log, Ls, N, D, beta, cw, has_ce = ctx.cfg
+        dev = sigma.device
+        g_ws = torch.empty((Ls, N), device=dev, dtype=torch.float32)
+        g_kl = torch.empty(N, device=dev, dtype=torch.float32)
+        g_ce = torch.empty(N, device=dev, dtype=torch.float32) if has_ce else None
+        gs = torch.empty_like(sigma) if ctx.needs_input_grad[3] else None
+        ws = L.workspace(4 * N + 16, dev)
+
+        def opt(t):
+            return None if t is None else _c(t)
+        rc = L.load().jvae_elbo_bwd_f32(L.ptr(opt(g_wmse)), L.ptr(opt(g_cx)), L.ptr(opt(g_tot)), L.ptr(sigma), int(is_log),
+                                        L.ptr(g_ws), L.ptr(g_kl), L.ptr(g_ce), L.ptr(gs), 0, Ls, N, D, beta, cw,
+                                        L.ptr(ws), ws.numel(), L.stream_ptr())
+        L.check(rc, 'jvae_elbo_bwd_f32')
+        return g_ws, g_kl, g_ce, gs, None, None, None, None
+
+
+def elbo(wmse_s, kl, ce, sigma, sigma_is_log, D, beta, cw):
+    return _Elbo.apply(wmse_s, kl, ce, sigma, sigma_is_log, D, beta, cw)
+
+
+def measures(x, wmse, zdist, var_kl, sigma, sigma_is_log, means, flag, scratch):
+    """-> device tensor of 10 floats (layout in csrc/loss.hip measures_kernel); `scratch`: 1-float device tensor."""
+    lib = L.load()
+    x = _c(x)
+    L.check(lib.jvae_sqnorm_accum_f32(L.ptr(x), x.numel(), L.ptr(scratch), 1, L.stream_ptr()), 'sumsq(x)')
+    out = torch.empty(10, device=x.device, dtype=torch.float32)
+    C, K = (means.shape if means is not None else (0, 0))
+    rc = lib.jvae_measures_f32(L.ptr(scratch), x.numel(), L.ptr(_c(wmse)), L.ptr(_c(zdist)), L.ptr(_c(var_kl)), wmse.numel(),
+                               L.ptr(_c(sigma)), int(sigma_is_log), L.ptr(None if means is None else _c(means)), C, K,
+                               L.ptr(flag), L.ptr(out), L.stream_ptr())
+    L.check(rc, 'jvae_measures_f32')
+    return out
+
+
 class _Xent(torch.autograd.Function):
     """Row-wise cross entropy, target y[r % N] (F.cross_entropy(reduction='none'), losses.py:76-86)."""
 
