@@ -52,6 +52,21 @@ __global__ __launch_bounds__(256) void fold_kernel(const float* __restrict__ col
         const int cb = (int)(r % g.Cb);
         const int n = (int)(r / g.Cb);
         float acc = bias ? bias[cb] : 0.f;
+        if (g.Hs * g.Ws < g.KH * g.KW) {
+            // few folded positions (e.g. 2x2): walk them instead of the taps
+            for (int hs = 0; hs < g.Hs; ++hs) {
+                const int kh = hb + g.P - hs * g.S;
+                if (kh < 0 || kh >= g.KH) continue;
+                for (int ws = 0; ws < g.Ws; ++ws) {
+                    const int kw = wb + g.P - ws * g.S;
+                    if (kw < 0 || kw >= g.KW) continue;
+                    const int k = (cb * g.KH + kh) * g.KW + kw;
+                    acc += col[(long)n * sn + (long)k * sk + (long)(hs * g.Ws + ws) * sq];
+                }
+            }
+            xb[(((long)(n0 + n) * g.Cb + cb) * g.Hb + hb) * g.Wb + wb] = acc;
+            continue;
+        }
         for (int kh = 0; kh < g.KH; ++kh) {
             const int th = hb + g.P - kh;
             if (th < 0 || th % g.S) continue;
@@ -136,8 +151,16 @@ int jvae_fold_fwd(const ConvGeom& g, const float* xb, const float* w, const floa
         hipLaunchKernelGGL(unfold_kernel, dim3(grid_for((long)g.N * Kd * Ps)), dim3(256), 0, st, xb, ws, g, 0, g.N,
                            (long)Kd, 1L, (long)g.N * Kd, 1);
         JVAE_LAUNCH_CHECK();
+        const long tiles = (long)cdiv(g.N, 64) * cdiv(g.Cs, 64) * Ps;
+        int splitk = 1;
+        if (tiles < 512 && Kd >= 1024) {
+            splitk = (int)(512 / tiles) + 1;                     // long K, few tiles: split-K onto a zeroed output
+            if (splitk > 8) splitk = 8;
+            hipError_t e = hipMemsetAsync(ys, 0, sizeof(float) * (size_t)g.N * g.Cs * Ps, st);
+            if (e != hipSuccess) return (int)e;
+        }
         return jvae_gemm_launch(g.N, g.Cs, Kd, Ps, ws, Kd, 1, (long)g.N * Kd, w, 1, Kd, 0,
-                                ys, (long)g.Cs * Ps, Ps, 1, bias, bias ? 1 : 0, 0, 1, st);
+                                ys, (long)g.Cs * Ps, Ps, 1, bias, bias ? 1 : 0, 0, splitk, st);
     }
     const int chunk = chunk_images(g, ws_bytes);
     if (chunk < 1) return JVAE_EWORKSPACE;

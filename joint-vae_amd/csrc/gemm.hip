@@ -241,7 +241,7 @@ int jvae_gemm_launch_ex(int M, int N, int K, int batch,
     p.vecA = aligned16(A) && (sAb % 4 == 0) && (ak ? (sAm % 4 == 0) : (sAm == 1 && sAk % 4 == 0));
     p.vecB = aligned16(B) && (sBb % 4 == 0) && (bnc ? (sBk % 4 == 0) : (sBk == 1 && sBn % 4 == 0));
     const long tiles128 = (long)cdiv(M, 128) * cdiv(N, 128) * batch * splitk;
-    if (M > 64 && N > 64 && tiles128 >= 192) return launch_tile<128, 128>(p, batch, st);
+    if (M > 64 && N > 64 && tiles128 >= 512) return launch_tile<128, 128>(p, batch, st);
     return launch_tile<64, 64>(p, batch, st);
 }
 
