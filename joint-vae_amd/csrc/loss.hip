@@ -174,7 +174,6 @@ __global__ __launch_bounds__(256) void measures_kernel(const float* __restrict__
                                                        const float* __restrict__ means, int C, int K,
                                                        const int* __restrict__ flag, float* __restrict__ out) {
     __shared__ float red[17];
-    __shared__ float rowsum[128];
     const int tid = threadIdx.x;
     const float sg = sigma_is_log ? __expf(sigma[0]) : sigma[0];
     float a = 0.f, b = 0.f, c = 0.f;
@@ -187,35 +186,33 @@ __global__ __launch_bounds__(256) void measures_kernel(const float* __restrict__
     }
     float cap = 0.f, dmin = INFINITY;
     if (means) {
-        // pairwise squared distances; row r handled by thread groups: C <= 128 rows per pass
-        for (int r0 = 0; r0 < C; r0 += 128) {
-            __syncthreads();
-            if (tid < 128) rowsum[tid] = 0.f;
-            __syncthreads();
-            float maxn = 0.f;
-            for (int r = r0 + tid; r < C && r < r0 + 128; r += blockDim.x) {
-                float e = 0.f, nr = 0.f;
-                for (int k = 0; k < K; ++k) nr += means[(long)r * K + k] * means[(long)r * K + k];
-                for (int q = 0; q < C; ++q) {
-                    float d2 = 0.f;
-                    for (int k = 0; k < K; ++k) { const float t = means[(long)r * K + k] - means[(long)q * K + k]; d2 += t * t; }
-                    e += __expf(-d2 / 4.f);
-                    if (q != r) dmin = fminf(dmin, sqrtf(d2));
-                }
-                cap += __logf(e);
-                maxn = fmaxf(maxn, sqrtf(nr));
-            }
-            mx = fmaxf(mx, maxn);
-        }
-        cap = block_sum(cap, red);
-        // block-wide max / min through the sum helper's scratch: do it with shuffles + LDS
-        float vmax = wave_max(mx), vmin = -wave_max(-dmin);
+        // all C*C pairs spread over the block; per-row sums of exp(-d^2/4) accumulate in LDS (C <= 1024 rows)
+        __shared__ float rowsum[1024];
+        for (int r = tid; r < C; r += blockDim.x) rowsum[r] = 0.f;
         __syncthreads();
-        if ((tid & 63) == 0) { rowsum[tid >> 6] = vmax; rowsum[8 + (tid >> 6)] = vmin; }
+        for (int pr = tid; pr < C * C; pr += blockDim.x) {
+            const int r = pr / C, q = pr % C;
+            float d2 = 0.f;
+            for (int k = 0; k < K; ++k) { const float t = means[(long)r * K + k] - means[(long)q * K + k]; d2 += t * t; }
+            atomicAdd(&rowsum[r], __expf(-d2 / 4.f));
+            if (q != r) dmin = fminf(dmin, sqrtf(d2));
+            if (q == r) {                                    // row norm once per row
+                float nr = 0.f;
+                for (int k = 0; k < K; ++k) nr += means[(long)r * K + k] * means[(long)r * K + k];
+                mx = fmaxf(mx, sqrtf(nr));
+            }
+        }
+        __syncthreads();
+        for (int r = tid; r < C; r += blockDim.x) cap += __logf(rowsum[r]);
+        cap = block_sum(cap, red);
+        float vmax = wave_max(mx), vmin = -wave_max(-dmin);
+        __shared__ float wred[16];
+        __syncthreads();
+        if ((tid & 63) == 0) { wred[tid >> 6] = vmax; wred[8 + (tid >> 6)] = vmin; }
         __syncthreads();
         if (tid == 0) {
             const int nw = (blockDim.x + 63) >> 6;
-            for (int w = 0; w < nw; ++w) { mx = fmaxf(mx, rowsum[w]); dmin = fminf(dmin, rowsum[8 + w]); }
+            for (int w = 0; w < nw; ++w) { mx = fmaxf(mx, wred[w]); dmin = fminf(dmin, wred[8 + w]); }
         }
     }
     if (tid == 0) {
@@ -336,7 +333,7 @@ int jvae_measures_f32(const float* sumsq_x, long nx, const float* wmse, const fl
                       const float* sigma, int sigma_is_log, const float* means, int C, int K, const int* flag,
                       float* out, void* stream) {
     if (!sumsq_x || !wmse || !zdist || !var_kl || !sigma || !out || N <= 0 || nx <= 0) return JVAE_EINVAL;
-    if (means && (C <= 0 || K <= 0)) return JVAE_EINVAL;
+    if (means && (C <= 0 || K <= 0 || C > 1024)) return JVAE_EINVAL;
     hipLaunchKernelGGL(measures_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, sumsq_x, (float)nx, wmse, zdist, var_kl,
                        N, sigma, sigma_is_log, means, C, K, flag, out);
     JVAE_LAUNCH_CHECK();

@@ -96,11 +96,31 @@ def ptr(t):
 
 
 _workspaces = {}
+_side_streams = {}
+
+
+def side_stream(device):
+    """Second HIP stream of a device: weight-gradient kernels (MFMA-bound, off the critical path of backward) run
+    here so that they overlap the HBM-bound BatchNorm-backward passes of the main stream."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    st = _side_streams.get(idx)
+    if st is None:
+        _side_streams[idx] = st = torch.cuda.Stream(device=idx)
+    return st
+
+
+def join_side_stream(device=None):
+    """Make the current stream wait for everything queued on the side stream(s) (called before gradients are read:
+    all-reduce, clip, Adam)."""
+    for idx, st in _side_streams.items():
+        if device is None or device.index in (None, idx):
+            torch.cuda.current_stream(idx).wait_stream(st)
 
 
 def workspace(nbytes, device):
-    """Stream-ordered scratch shared by all ops of one device (grown on demand, never shrunk)."""
-    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    """Stream-ordered scratch shared by all ops of one (device, stream) (grown on demand, never shrunk)."""
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device(),
+           torch.cuda.current_stream(device).cuda_stream)
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
         _workspaces[key] = ws = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)

@@ -11,6 +11,7 @@ import torch
 from . import lib as L
 
 RELU, SIGMOID, IDENT = 1, 2, 0
+OVERLAP_WGRAD = True          # weight-gradient kernels on a second HIP stream (see _Conv.backward)
 ACT_KIND = {'relu': RELU, 'sigmoid': SIGMOID, 'linear': IDENT, None: IDENT}
 
 
@@ -36,6 +37,22 @@ def _grad_slot(param):
     if g is None or not g.is_contiguous() or g.dtype != torch.float32 or g.shape != param.shape or not g.is_cuda:
         return None
     return g
+
+
+_join_pending = [False]
+
+
+def _join_after_backward():
+    """Once per backward pass: when the autograd engine finishes, the main stream waits for the side stream, so that
+    whoever reads .grad next (optimiser, all-reduce, a test) sees the finished weight gradients."""
+    if _join_pending[0]:
+        return
+    _join_pending[0] = True
+
+    def _cb():
+        _join_pending[0] = False
+        L.join_side_stream()
+    torch.autograd.Variable._execution_engine.queue_callback(_cb)
 
 
 # ------------------------------------------------------------------------------------------- gemm
@@ -200,8 +217,21 @@ class _Conv(torch.autograd.Function):
             gx = conv_dgrad_raw(gy, w, ctx.spec, x.shape)
         want_b = ctx.has_bias and ctx.needs_input_grad[2] and not ctx.dead_bias
         if ctx.needs_input_grad[1] or want_b:
-            gw, gb = conv_wgrad_raw(x, gy, ctx.spec, w.shape, want_b, _grad_slot(ctx.w_ref),
-                                    _grad_slot(ctx.b_ref) if want_b else None)
+            w_slot = _grad_slot(ctx.w_ref)
+            b_slot = _grad_slot(ctx.b_ref) if want_b else None
+            if OVERLAP_WGRAD and w_slot is not None and (b_slot is not None or not want_b):
+                # in-place into the flat gradient buffer: nothing downstream of this node consumes the result before
+                # the optimiser, so the kernel goes to the side stream and overlaps the rest of backward
+                main = torch.cuda.current_stream(x.device)
+                side = L.side_stream(x.device)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    conv_wgrad_raw(x, gy, ctx.spec, w.shape, want_b, w_slot, b_slot)
+                x.record_stream(side)
+                gy.record_stream(side)
+                _join_after_backward()
+            else:
+                gw, gb = conv_wgrad_raw(x, gy, ctx.spec, w.shape, want_b, w_slot, b_slot)
         if ctx.dead_bias and ctx.has_bias and ctx.needs_input_grad[2] and _grad_slot(ctx.b_ref) is None:
             gb = torch.zeros_like(ctx.b_ref)          # exact value; makes the bias a regular optimiser citizen
         return gx, gw, gb, None, None

