@@ -90,6 +90,13 @@ def cpu_baseline(max_seconds=25.0):
                       f'{os.cpu_count()} logical CPUs visible'}
 
 
+def _watchdog(seconds):
+    """Abort (exit code 3, stacks dumped) instead of hanging the box if the process makes no progress for `seconds`."""
+    import faulthandler
+    faulthandler.dump_traceback_later(seconds, exit=True)
+    return faulthandler
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -98,6 +105,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--batch', type=int, default=BATCH_PER_GPU, help='diagnostics only: per-GPU batch (the metric is defined at 512)')
     a = ap.parse_args()
+    fh = _watchdog(900)
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -157,6 +165,7 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    fh.cancel_dump_traceback_later()
 
 
 if __name__ == '__main__':

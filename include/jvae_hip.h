@@ -49,6 +49,13 @@ int jvae_conv2d_out_shape(int H, int W, int KH, int KW, int S, int P, int OP, in
 int jvae_conv2d_fwd_f32(const float* x, const float* w, const float* bias, float* y,
                         int N, int Cin, int H, int W, int Cout, int KH, int KW, int S, int P, int OP, int transposed,
                         void* ws, size_t ws_bytes, void* stream);
+/* Forward that also emits BatchNorm partial statistics of (y - bias) from the kernel's epilogue when the selected
+ * kernel supports it.  stats: (Cout, cap, 2) floats with cap >= jvae_conv2d_stats_splits(...) (0 = this layer never
+ * produces them); *nsplit (HOST int) = partials per channel actually written, laid out (Cout, *nsplit, 2). */
+int jvae_conv2d_stats_splits(int N, int Cin, int H, int W, int Cout, int KH, int KW, int S, int P, int OP, int transposed);
+int jvae_conv2d_fwd_stats_f32(const float* x, const float* w, const float* bias, float* y, float* stats, int* nsplit,
+                              int N, int Cin, int H, int W, int Cout, int KH, int KW, int S, int P, int OP, int transposed,
+                              void* ws, size_t ws_bytes, void* stream);
 int jvae_conv2d_dgrad_f32(const float* dy, const float* w, float* dx,
                           int N, int Cin, int H, int W, int Cout, int KH, int KW, int S, int P, int OP, int transposed,
                           void* ws, size_t ws_bytes, void* stream);
@@ -69,6 +76,14 @@ int jvae_bn_fwd_f32(const float* x, const float* gamma, const float* beta,
                     float* y, float* save_mean, float* save_invstd,
                     int N, int C, int P, float momentum, float eps, int training, int relu,
                     void* ws, size_t ws_bytes, void* stream);
+/* Same as jvae_bn_fwd_f32 with the batch statistics supplied by the producing convolution: ext_stats (C, ext_nsplit, 2)
+ * = per-workgroup (sum, sum of squares) of (x - ext_pivot[c]), ext_pivot = the conv bias (NULL = 0). */
+int jvae_bn_fwd_ext_f32(const float* x, const float* gamma, const float* beta,
+                        float* running_mean, float* running_var, long long* num_batches_tracked,
+                        float* y, float* save_mean, float* save_invstd,
+                        int N, int C, int P, float momentum, float eps, int training, int relu,
+                        const float* ext_stats, int ext_nsplit, const float* ext_pivot,
+                        void* ws, size_t ws_bytes, void* stream);
 int jvae_bn_bwd_f32(const float* dy, const float* x, const float* gamma, const float* beta,
                     const float* save_mean, const float* save_invstd,
                     float* dx, float* dgamma, float* dbeta, int accumulate,

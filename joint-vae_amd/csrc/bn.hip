@@ -62,23 +62,33 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
                                                        float* running_mean, float* running_var, long long* num_batches_tracked,
                                                        float* save_mean, float* save_invstd, float* __restrict__ y,
                                                        int N, int C, int P, int nsplit, int nchunk, float momentum, float eps,
-                                                       int training, int relu) {
+                                                       int training, int relu, int ext_pivot, const float* __restrict__ pivot) {
     __shared__ float cs[2];
+    __shared__ double dred[2][4];
     const int c = blockIdx.x, j = blockIdx.y;
+    double s1 = 0., s2 = 0.;
+    if (training) {                              // fold the channel's partial sums with the whole block (fp64)
+        for (int s = threadIdx.x; s < nsplit; s += blockDim.x) {
+            s1 += (double)partial[((long)c * nsplit + s) * 2 + 0];
+            s2 += (double)partial[((long)c * nsplit + s) * 2 + 1];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+        if ((threadIdx.x & 63) == 0) { dred[0][threadIdx.x >> 6] = s1; dred[1][threadIdx.x >> 6] = s2; }
+        __syncthreads();
+    }
     if (threadIdx.x == 0) {
         const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
         float mean, invstd;
         if (training) {
-            double s1 = 0., s2 = 0.;
-            for (int s = 0; s < nsplit; ++s) {
-                s1 += (double)partial[((long)c * nsplit + s) * 2 + 0];
-                s2 += (double)partial[((long)c * nsplit + s) * 2 + 1];
-            }
+            s1 = dred[0][0] + dred[0][1] + dred[0][2] + dred[0][3];
+            s2 = dred[1][0] + dred[1][1] + dred[1][2] + dred[1][3];
             const double n = (double)N * P;
             const double dm = s1 / n;
             double var = s2 / n - dm * dm;
             if (var < 0.) var = 0.;
-            mean = (float)((double)x[(long)c * P] + dm);
+            const double pv = ext_pivot ? (pivot ? (double)pivot[c] : 0.) : (double)x[(long)c * P];
+            mean = (float)(pv + dm);
             invstd = (float)(1.0 / sqrt(var + (double)eps));
             if (j == 0) {
                 save_mean[c] = mean;
@@ -262,30 +272,59 @@ extern "C" {
 // workspace: 2*C*MAX_SPLIT partials + 2*C coefficients
 size_t jvae_bn_workspace_bytes(int C) { return sizeof(float) * ((size_t)2 * C * MAX_SPLIT + (size_t)2 * C); }
 
-int jvae_bn_fwd_f32(const float* x, const float* gamma, const float* beta,
-                    float* running_mean, float* running_var, long long* num_batches_tracked,
-                    float* y, float* save_mean, float* save_invstd,
-                    int N, int C, int P, float momentum, float eps, int training, int relu,
-                    void* ws, size_t ws_bytes, void* stream) {
+static int bn_fwd_impl(const float* x, const float* gamma, const float* beta,
+                       float* running_mean, float* running_var, long long* num_batches_tracked,
+                       float* y, float* save_mean, float* save_invstd,
+                       int N, int C, int P, float momentum, float eps, int training, int relu,
+                       const float* ext_stats, int ext_nsplit, const float* ext_pivot,
+                       void* ws, size_t ws_bytes, void* stream) {
     if (!x || !y || N < 0 || C <= 0 || P <= 0) return JVAE_EINVAL;
     if (ws_bytes < jvae_bn_workspace_bytes(C) || !ws) return JVAE_EWORKSPACE;
     if (N == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    float* partial = (float*)ws;
+    const float* partial = (const float*)ws;
     int ns = 1;
-    if (training) {
+    const bool ext = training && ext_stats && ext_nsplit > 0;
+    if (ext) {
+        partial = ext_stats;
+        ns = ext_nsplit;
+        if (!save_mean || !save_invstd) return JVAE_EINVAL;
+    } else if (training) {
         if (!save_mean || !save_invstd) return JVAE_EINVAL;
         ns = pick_split(N, C, P);
-        hipLaunchKernelGGL(bn_stats_kernel, dim3(C, ns), dim3(256), 0, st, x, partial, N, C, P, ns);
+        hipLaunchKernelGGL(bn_stats_kernel, dim3(C, ns), dim3(256), 0, st, x, (float*)ws, N, C, P, ns);
         JVAE_LAUNCH_CHECK();
     } else if (!running_mean || !running_var) {
         return JVAE_EINVAL;
     }
     const int nc = pick_chunk(N, C, P);
     hipLaunchKernelGGL(bn_apply_kernel, dim3(C, nc), dim3(256), 0, st, x, partial, gamma, beta, running_mean, running_var,
-                       num_batches_tracked, save_mean, save_invstd, y, N, C, P, ns, nc, momentum, eps, training, relu);
+                       num_batches_tracked, save_mean, save_invstd, y, N, C, P, ns, nc, momentum, eps, training, relu,
+                       ext ? 1 : 0, ext_pivot);
     JVAE_LAUNCH_CHECK();
     return 0;
+}
+
+int jvae_bn_fwd_f32(const float* x, const float* gamma, const float* beta,
+                    float* running_mean, float* running_var, long long* num_batches_tracked,
+                    float* y, float* save_mean, float* save_invstd,
+                    int N, int C, int P, float momentum, float eps, int training, int relu,
+                    void* ws, size_t ws_bytes, void* stream) {
+    return bn_fwd_impl(x, gamma, beta, running_mean, running_var, num_batches_tracked, y, save_mean, save_invstd,
+                       N, C, P, momentum, eps, training, relu, nullptr, 0, nullptr, ws, ws_bytes, stream);
+}
+
+// Same, with the batch statistics supplied by the producing convolution (jvae_conv2d_fwd_stats_f32):
+// ext_stats (C, ext_nsplit, 2) = per-workgroup (sum, sum of squares) of (x - ext_pivot[c]); ext_pivot = the conv bias
+// (NULL = 0).  ext_nsplit == 0 falls back to the statistics kernel.
+int jvae_bn_fwd_ext_f32(const float* x, const float* gamma, const float* beta,
+                        float* running_mean, float* running_var, long long* num_batches_tracked,
+                        float* y, float* save_mean, float* save_invstd,
+                        int N, int C, int P, float momentum, float eps, int training, int relu,
+                        const float* ext_stats, int ext_nsplit, const float* ext_pivot,
+                        void* ws, size_t ws_bytes, void* stream) {
+    return bn_fwd_impl(x, gamma, beta, running_mean, running_var, num_batches_tracked, y, save_mean, save_invstd,
+                       N, C, P, momentum, eps, training, relu, ext_stats, ext_nsplit, ext_pivot, ws, ws_bytes, stream);
 }
 
 int jvae_bn_bwd_f32(const float* dy, const float* x, const float* gamma, const float* beta,

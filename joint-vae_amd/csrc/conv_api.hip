@@ -55,6 +55,27 @@ int jvae_conv2d_fwd_f32(const float* x, const float* w, const float* bias, float
     return jvae_conv_fwd(g, transposed, x, w, bias, y, (float*)ws, ws_bytes, (hipStream_t)stream);
 }
 
+// Forward that also emits BatchNorm partial statistics of (y - bias) when the selected kernel can produce them.
+// stats: (Cout, stats_cap, 2) floats with stats_cap >= jvae_conv2d_stats_splits(...); *nsplit (HOST int) receives the
+// number of partials per channel actually written, laid out as (Cout, *nsplit, 2); 0 = not produced (run the BN
+// statistics kernel instead).
+int jvae_conv2d_stats_splits(int N, int Cin, int H, int W, int Cout, int KH, int KW, int S, int P, int OP, int transposed) {
+    ConvGeom g; int oh, ow;
+    if (!make_geom(N, Cin, H, W, Cout, KH, KW, S, P, OP, transposed, &g, &oh, &ow)) return 0;
+    return jvae_conv_stats_splits(g, transposed);
+}
+
+int jvae_conv2d_fwd_stats_f32(const float* x, const float* w, const float* bias, float* y, float* stats, int* nsplit,
+                              int N, int Cin, int H, int W, int Cout, int KH, int KW, int S, int P, int OP, int transposed,
+                              void* ws, size_t ws_bytes, void* stream) {
+    ConvGeom g; int oh, ow;
+    if (!x || !w || !y || !nsplit) return JVAE_EINVAL;
+    *nsplit = 0;
+    if (!make_geom(N, Cin, H, W, Cout, KH, KW, S, P, OP, transposed, &g, &oh, &ow)) return JVAE_EINVAL;
+    if (N == 0) return 0;
+    return jvae_conv_fwd(g, transposed, x, w, bias, y, (float*)ws, ws_bytes, (hipStream_t)stream, stats, nsplit);
+}
+
 int jvae_conv2d_dgrad_f32(const float* dy, const float* w, float* dx,
                           int N, int Cin, int H, int W, int Cout, int KH, int KW, int S, int P, int OP, int transposed,
                           void* ws, size_t ws_bytes, void* stream) {

@@ -58,13 +58,26 @@ size_t jvae_conv_ws(const ConvGeom& g, int transposed) {
     return a > c ? a : c;
 }
 
+// Can the forward of this layer emit per-workgroup BatchNorm partial sums, and how many per channel at most?
+int jvae_conv_stats_splits(const ConvGeom& g, int transposed) {
+    if (!transposed) {
+        if (jvae_conv5_smallco_ok(g.Cb, g.Hb, g.Wb, g.Cs, g.KH, g.KW, g.S, g.P)) return 0;
+        return fold_fwd_fast(g) ? jvae_conv5_fwd_max_splits(g.N, g.Ws) : 0;
+    }
+    if (point_input(g)) return 0;
+    if (fold_bwd_fast_s1(g)) return jvae_conv5_fwd_max_splits(g.N, g.Wb);
+    if (fold_bwd_fast_s2(g)) return jvae_conv5_fwd_max_splits(g.N, g.Ws);
+    return 0;
+}
+
 int jvae_conv_fwd(const ConvGeom& g, int transposed, const float* x, const float* w, const float* bias, float* y,
-                  float* ws, size_t ws_bytes, hipStream_t st) {
+                  float* ws, size_t ws_bytes, hipStream_t st, float* stats, int* nsplit) {
+    if (nsplit) *nsplit = 0;
     if (!transposed) {
         if (jvae_conv5_smallco_ok(g.Cb, g.Hb, g.Wb, g.Cs, g.KH, g.KW, g.S, g.P))
             return jvae_conv5_smallco(x, w, bias, y, g.N, g.Cb, g.Wb, g.Cs, st);
         if (fold_fwd_fast(g) && ws_bytes >= 4 * jvae_conv5_pack_floats(g.Cb, g.Cs))
-            return jvae_conv5_fwd(x, w, 0, 0, bias, y, g.N, g.Cb, g.Hb, g.Wb, g.Cs, g.Ws, g.S, g.P, ws, st);
+            return jvae_conv5_fwd(x, w, 0, 0, bias, y, g.N, g.Cb, g.Hb, g.Wb, g.Cs, g.Ws, g.S, g.P, ws, st, stats, nsplit);
         return jvae_fold_fwd(g, x, w, bias, y, ws, ws_bytes, st);
     }
     if (point_input(g)) {
@@ -73,8 +86,12 @@ int jvae_conv_fwd(const ConvGeom& g, int transposed, const float* x, const float
                                    bias, bias ? 1 : 0, g.KH * g.KW, 0, 1, st);
     }
     if (fold_bwd_fast_s1(g) && ws_bytes >= 4 * jvae_conv5_pack_floats(g.Cs, g.Cb))
-        return jvae_conv5_fwd(x, w, 1, 1, bias, y, g.N, g.Cs, g.Hs, g.Ws, g.Cb, g.Wb, 1, 4 - g.P, ws, st);
-    if (fold_bwd_fast_s2(g) && ws_bytes >= 4 * jvae_conv5_pack_floats(g.Cs, g.Cb)) return run_t2(g, x, w, bias, y, ws, st);
+        return jvae_conv5_fwd(x, w, 1, 1, bias, y, g.N, g.Cs, g.Hs, g.Ws, g.Cb, g.Wb, 1, 4 - g.P, ws, st, stats, nsplit);
+    if (fold_bwd_fast_s2(g) && ws_bytes >= 4 * jvae_conv5_pack_floats(g.Cs, g.Cb)) {
+        int rc = jvae_conv5_pack(w, ws, g.Cs, g.Cb, 1, 0, st);
+        if (rc) return rc;
+        return jvae_convt2(x, ws, bias, y, g.N, g.Cs, g.Ws, g.Cb, st, stats, nsplit);
+    }
     return jvae_fold_bwd(g, x, w, bias, y, ws, ws_bytes, st);
 }
 

@@ -215,10 +215,14 @@ int jvae_fold_wgrad(const ConvGeom& g, const float* xb, const float* ys, float* 
         hipLaunchKernelGGL(unfold_kernel, dim3(grid_for((long)g.N * Kd * Ps)), dim3(256), 0, st, xb, ws, g, 0, g.N,
                            (long)Kd, 1L, (long)g.N * Kd, 1);
         JVAE_LAUNCH_CHECK();
-        // dW[cs][k] += sum_q sum_n Ys[n][cs][q] col_q[n][k]
-        int splitk = g.N >= 512 ? 4 : 1;
-        return jvae_gemm_launch(g.Cs, Kd, g.N, Ps, ys, Ps, (long)g.Cs * Ps, 1, ws, Kd, 1, (long)g.N * Kd,
-                                dw, Kd, 1, 0, nullptr, 0, 4, splitk, st);
+        // dW[cs][k] += sum_q sum_n Ys[n][cs][q] col_q[n][k]: one accumulating product per folded position, in order
+        // (deterministic: no float atomics)
+        for (int q = 0; q < Ps; ++q) {
+            int rc = jvae_gemm_launch(g.Cs, Kd, g.N, 1, ys + q, Ps, (long)g.Cs * Ps, 0, ws + (long)q * g.N * Kd, Kd, 1, 0,
+                                      dw, Kd, 1, 0, nullptr, 0, 1, 1, st);
+            if (rc) return rc;
+        }
+        return 0;
     }
     const int chunk = chunk_images(g, ws_bytes);
     if (chunk < 1) return JVAE_EWORKSPACE;

@@ -33,6 +33,7 @@ struct FwdP {
     float* out;          // (N, Cout, OH, OW)
     int N, Cin, H, W, Cout, P;   // Cout: padded to a multiple of 32 (packed weights), CoutReal: channels of `out`
     int CoutReal;
+    float* stats;        // optional (CoutReal, gridDim.x, 2): per-workgroup sum / sum of squares of (out - bias)
 };
 
 template <int S, int OW, int MT, int NT, int CC>
@@ -166,6 +167,35 @@ __global__ __launch_bounds__(256, 2) void conv5_fwd_kernel(FwdP p) {
         }
     }
 
+    // ---- optional BatchNorm statistics of this workgroup's tile (pixels of missing images contribute exact zeros)
+    if (p.stats) {
+        __syncthreads();                                      // LDS is free now
+        float* red = lds;                                     // [4 waves][NT*32][2]
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) { const float v = acc[nt][mt][r]; s1 += v; s2 += v * v; }
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+                if (l31 == 0) {
+                    const int ch = nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    red[(wave * G::WCOLS + ch) * 2 + 0] = s1;
+                    red[(wave * G::WCOLS + ch) * 2 + 1] = s2;
+                }
+            }
+        __syncthreads();
+        if (tid < G::WCOLS && o0 + tid < p.CoutReal) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { s1 += red[(w * G::WCOLS + tid) * 2]; s2 += red[(w * G::WCOLS + tid) * 2 + 1]; }
+            float* dst = p.stats + ((long)(o0 + tid) * gridDim.x + blockIdx.x) * 2;
+            dst[0] = s1; dst[1] = s2;
+        }
+    }
+
     // ---- epilogue: D[i = channel][j = pixel]; lane holds pixel j = l31, rows i = (r&3) + 8*(r>>2) + 4*half
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -201,6 +231,8 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ w, 
     }
 }
 
+thread_local int g_last_splits = 0;     // grid.x of the last forward-type launch (host side, per call: read right after launching)
+
 template <int S, int OW, int MT, int NT, int CC>
 int launch_fwd(const FwdP& p, hipStream_t st) {
     using G = FwdGeom<S, OW, MT, NT, CC>;
@@ -208,6 +240,7 @@ int launch_fwd(const FwdP& p, hipStream_t st) {
     const long pixels = (long)p.N * G::OHW;
     dim3 grid((unsigned)((pixels + G::PIX - 1) / G::PIX), (unsigned)(p.Cout / G::WCOLS));
     if (G::OHW < G::PIX) grid.x = (unsigned)((p.N + G::NIMG - 1) / G::NIMG);
+    g_last_splits = (int)grid.x;
     hipLaunchKernelGGL((conv5_fwd_kernel<S, OW, MT, NT, CC>), grid, dim3(256), 0, st, p);
     JVAE_LAUNCH_CHECK();
     return 0;
@@ -253,11 +286,16 @@ int jvae_conv5_pack(const float* w, float* wp, int C, int O, int swap, int flip,
 }
 
 // ws must hold Cin*25*Cout floats (the packed weights).  swap / flip: see pack_kernel.
+// Upper bound of the number of per-channel partials a stats-producing launch writes (smallest tile: 128 pixels).
+int jvae_conv5_fwd_max_splits(int N, int OW) { return (int)(((long)N * OW * OW + 127) / 128) + 1; }
+
 int jvae_conv5_fwd(const float* in, const float* w, int swap, int flip, const float* bias, float* out,
-                   int N, int Cin, int H, int W, int Cout, int OW, int S, int P, float* ws, hipStream_t st) {
+                   int N, int Cin, int H, int W, int Cout, int OW, int S, int P, float* ws, hipStream_t st,
+                   float* stats, int* nsplit) {
     int rc = jvae_conv5_pack(w, ws, Cin, Cout, swap, flip, st);
     if (rc) return rc;
-    FwdP p{in, ws, bias, out, N, Cin, H, W, (Cout + 31) / 32 * 32, P, Cout};
+    FwdP p{in, ws, bias, out, N, Cin, H, W, (Cout + 31) / 32 * 32, P, Cout, stats};
+    struct Fin { int* n; ~Fin() { if (n) *n = g_last_splits; } } fin{nsplit};
     if (S == 1) {
         switch (OW) {
             case 8: return launch_fwd_ow<1, 8>(p, st);

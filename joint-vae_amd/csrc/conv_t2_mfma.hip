@@ -25,6 +25,7 @@ struct T2P {
     const float* bias;   // (O) or null
     float* out;          // big (N, O, 2HS, 2WS)
     int N, C, O;
+    float* stats;        // optional (O, gridDim.x, 2): per-workgroup sum / sum of squares of (out - bias)
 };
 
 template <int WS, int NT, int CC>
@@ -148,6 +149,35 @@ __global__ __launch_bounds__(256, 2) void convt2_kernel(T2P p) {
         }
     }
 
+    if (p.stats) {
+        __syncthreads();
+        float* red = lds;                                     // [4 waves][NT*32][2]
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) { const float v = acc[r][q][t][e]; s1 += v; s2 += v * v; }
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+                if (l31 == 0) {
+                    const int ch = t * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+                    red[(wave * G::WCOLS + ch) * 2 + 0] = s1;
+                    red[(wave * G::WCOLS + ch) * 2 + 1] = s2;
+                }
+            }
+        __syncthreads();
+        if (tid < G::WCOLS) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { s1 += red[(w * G::WCOLS + tid) * 2]; s2 += red[(w * G::WCOLS + tid) * 2 + 1]; }
+            float* dst = p.stats + ((long)(o0 + tid) * gridDim.x + blockIdx.x) * 2;
+            dst[0] = s1; dst[1] = s2;
+        }
+    }
     const int n = img0 + im;
     if (n >= p.N) return;
     const int a_ = row0 + pr;
@@ -166,12 +196,15 @@ __global__ __launch_bounds__(256, 2) void convt2_kernel(T2P p) {
         }
 }
 
+static thread_local int g_t2_splits = 0;
+
 template <int WS, int NT>
 int launch_t2(const T2P& p, hipStream_t st) {
     using G = T2Geom<WS, NT, 4>;
     static_assert((G::XS + G::WSZ) * 4 <= 64 * 1024, "static LDS budget");
     dim3 grid(G::HSWS >= G::PIX ? (unsigned)((long)p.N * G::HSWS / G::PIX) : (unsigned)((p.N + G::NIMG - 1) / G::NIMG),
               (unsigned)(p.O / G::WCOLS));
+    g_t2_splits = (int)grid.x;
     hipLaunchKernelGGL((convt2_kernel<WS, NT, 4>), grid, dim3(256), 0, st, p);
     JVAE_LAUNCH_CHECK();
     return 0;
@@ -188,8 +221,9 @@ bool jvae_convt2_ok(int C, int HS, int WS, int O, int HB, int WB, int KH, int KW
 }
 
 int jvae_convt2(const float* in, const float* wpacked, const float* bias, float* out, int N, int C, int WS, int O,
-                hipStream_t st) {
-    T2P p{in, wpacked, bias, out, N, C, O};
+                hipStream_t st, float* stats, int* nsplit) {
+    T2P p{in, wpacked, bias, out, N, C, O, stats};
+    struct Fin { int* n; ~Fin() { if (n) *n = g_t2_splits; } } fin{nsplit};
     const bool two = false;      // NT = 2 needs 128 accumulator registers (1 wave/SIMD): one 32-channel tile per wave instead
     switch (WS) {
         case 8: return two ? launch_t2<8, 2>(p, st) : launch_t2<8, 1>(p, st);

@@ -21,11 +21,14 @@ _SIGS = {
     'jvae_conv2d_workspace_bytes': (c_size_t, [c_int] * 11),
     'jvae_conv2d_out_shape': (c_int, [c_int] * 8 + [POINTER(c_int), POINTER(c_int)]),
     'jvae_conv2d_fwd_f32': (c_int, [P, P, P, P] + [c_int] * 11 + [P, c_size_t, P]),
+    'jvae_conv2d_stats_splits': (c_int, [c_int] * 11),
+    'jvae_conv2d_fwd_stats_f32': (c_int, [P, P, P, P, P, POINTER(c_int)] + [c_int] * 11 + [P, c_size_t, P]),
     'jvae_conv2d_dgrad_f32': (c_int, [P, P, P] + [c_int] * 11 + [P, c_size_t, P]),
     'jvae_conv2d_wgrad_f32': (c_int, [P, P, P, P, c_int] + [c_int] * 11 + [P, c_size_t, P]),
     'jvae_channel_sum_f32': (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     'jvae_bn_workspace_bytes': (c_size_t, [c_int]),
     'jvae_bn_fwd_f32': (c_int, [P] * 9 + [c_int, c_int, c_int, c_float, c_float, c_int, c_int, P, c_size_t, P]),
+    'jvae_bn_fwd_ext_f32': (c_int, [P] * 9 + [c_int, c_int, c_int, c_float, c_float, c_int, c_int, P, c_int, P, P, c_size_t, P]),
     'jvae_bn_bwd_f32': (c_int, [P] * 9 + [c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),
     'jvae_act_fwd_f32': (c_int, [P, P, c_long, c_int, P]),
     'jvae_act_bwd_f32': (c_int, [P, P, P, c_long, c_int, P]),

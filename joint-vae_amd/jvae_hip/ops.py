@@ -39,20 +39,11 @@ def _grad_slot(param):
     return g
 
 
-_join_pending = [False]
-
-
 def _join_after_backward():
-    """Once per backward pass: when the autograd engine finishes, the main stream waits for the side stream, so that
-    whoever reads .grad next (optimiser, all-reduce, a test) sees the finished weight gradients."""
-    if _join_pending[0]:
-        return
-    _join_pending[0] = True
-
-    def _cb():
-        _join_pending[0] = False
-        L.join_side_stream()
-    torch.autograd.Variable._execution_engine.queue_callback(_cb)
+    """When the autograd engine finishes this backward pass, the main stream waits for the side stream, so that
+    whoever reads .grad next (optimiser, all-reduce, a test) sees the finished weight gradients.  Queued once per
+    side-stream launch (an event wait each: cheap), so no state survives a backward pass that raised."""
+    torch.autograd.Variable._execution_engine.queue_callback(L.join_side_stream)
 
 
 # ------------------------------------------------------------------------------------------- gemm
@@ -113,9 +104,7 @@ class _Linear(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             slot = _grad_slot(ctx.w_ref)
             gw = slot if slot is not None else torch.zeros((O, I), device=gy.device, dtype=torch.float32)
-            tiles = ((O + 63) // 64) * ((I + 63) // 64)
-            splitk = max(1, min(R // 64, 256 // max(tiles, 1)))
-            gemm(O, I, R, gy, (1, O, 0), x2, (I, 1, 0), gw, (I, 1, 0), splitk=splitk, flags=1)
+            gemm(O, I, R, gy, (1, O, 0), x2, (I, 1, 0), gw, (I, 1, 0), flags=1)      # no split-K: deterministic
             if slot is not None:
                 gw = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
@@ -166,6 +155,26 @@ def conv_fwd_raw(x, w, b, spec):
     return y
 
 
+def conv_fwd_stats_raw(x, w, b, spec):
+    """-> (y, stats, nsplit): forward + the BatchNorm partial sums of (y - bias) written by the conv epilogue
+    (stats is None / nsplit 0 when the kernel selected for this geometry does not produce them)."""
+    lib = L.load()
+    N, _, H, W = x.shape
+    geom = spec.geom(N, H, W)
+    cap = lib.jvae_conv2d_stats_splits(*geom)
+    if cap <= 0:
+        return conv_fwd_raw(x, w, b, spec), None, 0
+    oh, ow = spec.out_hw(H, W)
+    y = torch.empty((N, spec.cout, oh, ow), device=x.device, dtype=torch.float32)
+    stats = torch.empty((spec.cout * cap * 2,), device=x.device, dtype=torch.float32)
+    ws, nb = _conv_ws(geom, x.device)
+    ns = c_int(0)
+    rc = lib.jvae_conv2d_fwd_stats_f32(L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(y), L.ptr(stats), byref(ns), *geom,
+                                       L.ptr(ws), nb, L.stream_ptr())
+    L.check(rc, 'jvae_conv2d_fwd_stats_f32')
+    return y, (stats if ns.value > 0 else None), ns.value
+
+
 def conv_dgrad_raw(gy, w, spec, xshape):
     N, _, H, W = xshape
     gx = torch.empty(xshape, device=gy.device, dtype=torch.float32)
@@ -197,11 +206,15 @@ class _Conv(torch.autograd.Function):
     """nn.Conv2d / nn.ConvTranspose2d (conv.py:186-196)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, spec, dead_bias):
+    def forward(ctx, x, w, b, spec, dead_bias, stats_out):
         x = _c(_f32(x, 'conv'))
         ctx.w_ref, ctx.b_ref = w, b
         w = _c(w)
-        y = conv_fwd_raw(x, w, b, spec)
+        if stats_out is not None:          # the caller is a train-mode BatchNorm: let the conv epilogue do its sums
+            y, st, ns = conv_fwd_stats_raw(x, w, b, spec)
+            stats_out['stats'], stats_out['nsplit'], stats_out['pivot'] = st, ns, b
+        else:
+            y = conv_fwd_raw(x, w, b, spec)
         ctx.save_for_backward(x, w)
         ctx.spec = spec
         ctx.has_bias = b is not None
@@ -234,13 +247,13 @@ class _Conv(torch.autograd.Function):
                 gw, gb = conv_wgrad_raw(x, gy, ctx.spec, w.shape, want_b, w_slot, b_slot)
         if ctx.dead_bias and ctx.has_bias and ctx.needs_input_grad[2] and _grad_slot(ctx.b_ref) is None:
             gb = torch.zeros_like(ctx.b_ref)          # exact value; makes the bias a regular optimiser citizen
-        return gx, gw, gb, None, None
+        return gx, gw, gb, None, None, None
 
 
-def conv2d(x, w, b, spec, dead_bias=False):
+def conv2d(x, w, b, spec, dead_bias=False, stats_out=None):
     """dead_bias: the bias feeds a train-mode BatchNorm, which removes the channel mean: its true gradient is
     exactly zero (what autograd would produce is rounding noise), so the channel reduction is skipped."""
-    return _Conv.apply(x, w, b, spec, dead_bias)
+    return _Conv.apply(x, w, b, spec, dead_bias, stats_out)
 
 
 # ------------------------------------------------------------------------------------------- batch norm
@@ -248,7 +261,7 @@ class _BatchNormAct(torch.autograd.Function):
     """nn.BatchNorm2d (train or eval) + optional ReLU (conv.py:214-220)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, rm, rv, nbt, training, relu, momentum, eps):
+    def forward(ctx, x, gamma, beta, rm, rv, nbt, training, relu, momentum, eps, ext):
         x = _c(_f32(x, 'batchnorm'))
         N, C = x.shape[0], x.shape[1]
         P = x.numel() // max(N * C, 1)
@@ -258,9 +271,15 @@ class _BatchNormAct(torch.autograd.Function):
         invstd = torch.empty(C, device=x.device, dtype=torch.float32)
         nb = lib.jvae_bn_workspace_bytes(C)
         ws = L.workspace(nb, x.device)
-        rc = lib.jvae_bn_fwd_f32(L.ptr(x), L.ptr(gamma), L.ptr(beta), L.ptr(rm), L.ptr(rv), L.ptr(nbt), L.ptr(y),
-                                 L.ptr(mean), L.ptr(invstd), N, C, P, momentum, eps, int(training), int(relu),
-                                 L.ptr(ws), ws.numel(), L.stream_ptr())
+        if ext is not None and ext.get('stats') is not None and training:
+            rc = lib.jvae_bn_fwd_ext_f32(L.ptr(x), L.ptr(gamma), L.ptr(beta), L.ptr(rm), L.ptr(rv), L.ptr(nbt), L.ptr(y),
+                                         L.ptr(mean), L.ptr(invstd), N, C, P, momentum, eps, int(training), int(relu),
+                                         L.ptr(ext['stats']), int(ext['nsplit']), L.ptr(ext.get('pivot')),
+                                         L.ptr(ws), ws.numel(), L.stream_ptr())
+        else:
+            rc = lib.jvae_bn_fwd_f32(L.ptr(x), L.ptr(gamma), L.ptr(beta), L.ptr(rm), L.ptr(rv), L.ptr(nbt), L.ptr(y),
+                                     L.ptr(mean), L.ptr(invstd), N, C, P, momentum, eps, int(training), int(relu),
+                                     L.ptr(ws), ws.numel(), L.stream_ptr())
         L.check(rc, 'jvae_bn_fwd_f32')
         if training:
             ctx.save_for_backward(x, gamma, beta, mean, invstd)
@@ -292,13 +311,14 @@ class _BatchNormAct(torch.autograd.Function):
         L.check(rc, 'jvae_bn_bwd_f32')
         if inplace:
             gg = gb = None
-        return gx, gg, gb, None, None, None, None, None, None, None
+        return gx, gg, gb, None, None, None, None, None, None, None, None
 
 
 def batchnorm_act(x, gamma, beta, running_mean, running_var, num_batches_tracked, training, relu,
-                  momentum=0.1, eps=1e-5):
+                  momentum=0.1, eps=1e-5, ext=None):
+    """ext: {'stats', 'nsplit', 'pivot'} filled by conv2d(..., stats_out=ext) for the tensor x."""
     return _BatchNormAct.apply(x, gamma, beta, running_mean, running_var, num_batches_tracked, training, relu,
-                               momentum, eps)
+                               momentum, eps, ext)
 
 
 class _Act(torch.autograd.Function):

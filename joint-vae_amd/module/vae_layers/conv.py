@@ -93,8 +93,8 @@ class HipConv2d(nn.Conv2d):
     def _spec(self):
         return ops.ConvSpec(self.in_channels, self.out_channels, self.kernel_size[0], self.stride[0], self.padding[0])
 
-    def forward(self, x, dead_bias=False):
-        return ops.conv2d(x, self.weight, self.bias, self._spec(), dead_bias)
+    def forward(self, x, dead_bias=False, stats_out=None):
+        return ops.conv2d(x, self.weight, self.bias, self._spec(), dead_bias, stats_out)
 
 
 class HipConvTranspose2d(nn.ConvTranspose2d):
@@ -102,35 +102,41 @@ class HipConvTranspose2d(nn.ConvTranspose2d):
         return ops.ConvSpec(self.in_channels, self.out_channels, self.kernel_size[0], self.stride[0], self.padding[0],
                             self.output_padding[0], transposed=True)
 
-    def forward(self, x, output_size=None, dead_bias=False):
-        return ops.conv2d(x, self.weight, self.bias, self._spec(), dead_bias)
+    def forward(self, x, output_size=None, dead_bias=False, stats_out=None):
+        return ops.conv2d(x, self.weight, self.bias, self._spec(), dead_bias, stats_out)
 
 
 class HipBatchNorm2d(nn.BatchNorm2d):
     """nn.BatchNorm2d state; forward = batch-statistics kernel (+ the following ReLU when fused by the stack)."""
 
-    def forward(self, x, relu=False):
+    def forward(self, x, relu=False, ext=None):
         return ops.batchnorm_act(x, self.weight, self.bias, self.running_mean, self.running_var,
-                                 self.num_batches_tracked, self.training, relu, self.momentum, self.eps)
+                                 self.num_batches_tracked, self.training, relu, self.momentum, self.eps, ext)
 
 
 class HipConvStack(nn.Sequential):
-    """nn.Sequential whose forward fuses BatchNorm2d with the activation that follows it."""
+    """nn.Sequential whose forward fuses BatchNorm2d with the activation that follows it and lets the producing
+    convolution's epilogue compute the batch statistics."""
 
     def forward(self, x):
         mods = list(self)
         i = 0
+        ext = None
         while i < len(mods):
             m = mods[i]
             if isinstance(m, HipBatchNorm2d) and i + 1 < len(mods) and type(mods[i + 1]) in ACT_OF_MODULE \
                     and ACT_OF_MODULE[type(mods[i + 1])] in (ops.RELU, ops.IDENT):
-                x = m(x, relu=ACT_OF_MODULE[type(mods[i + 1])] == ops.RELU)
+                x = m(x, relu=ACT_OF_MODULE[type(mods[i + 1])] == ops.RELU, ext=ext)
+                ext = None
                 i += 2
                 continue
             if isinstance(m, (HipConv2d, HipConvTranspose2d)) and i + 1 < len(mods) \
                     and isinstance(mods[i + 1], HipBatchNorm2d) and mods[i + 1].training:
-                x = m(x, dead_bias=True)      # BatchNorm removes the channel mean: d(loss)/d(bias) == 0 exactly
+                ext = {}
+                # BatchNorm removes the channel mean: d(loss)/d(bias) == 0 exactly
+                x = m(x, dead_bias=True, stats_out=ext)
             else:
+                ext = None
                 x = m(x)
             i += 1
         return x

@@ -22,6 +22,9 @@ def pytest_collection_modifyitems(config, items):
     except Exception:
         has_gpu = False
     if has_gpu:
+        for it in items:                      # a hung kernel must fail the test, not stall the GPU box
+            if 'gpu' in it.keywords and not any(m.name == 'timeout' for m in it.iter_markers()):
+                it.add_marker(pytest.mark.timeout(240))
         return
     skip = pytest.mark.skip(reason='no GPU visible')
     for it in items:

@@ -168,8 +168,17 @@ def test_checkpoint_roundtrip(tmp_path):
     assert sorted(os.listdir(tmp_path)) == ['history.json', 'optimizer.pth', 'params.json', 'state.pth', 'train_params.json']
     other = build(case)
     other.load_weights(str(tmp_path))
+    for (n1, p1), (n2, p2) in zip(net.named_parameters(), other.named_parameters()):
+        assert torch.equal(p1, p2), n1                   # the checkpoint restores the parameters bit for bit
     la, _ = net.train_step(x, y, epsilon=eps)
     lb, _ = other.train_step(x, y, epsilon=eps)
-    assert rel(la['total'], lb['total']) < 1e-6
+    assert rel(la['total'], lb['total']) < 1e-6          # same state, same batch -> same forward
+    # after the step: a few kernels combine partial sums with float atomics (split-K of the 1x1 -> 8x8 layer's dgrad,
+    # channel sums), so two runs differ at 1e-6 in the gradients; Adam turns that into +-lr on the few weights whose
+    # gradient is ~0.  Compare in L2 and through the next forward.
     for (n1, p1), (n2, p2) in zip(net.named_parameters(), other.named_parameters()):
-        assert rel(p1, p2, floor=1e-12) < 1e-4, n1      # the generic 7x7 path accumulates dW with float atomics
+        d = float((p1 - p2).double().norm() / (p2.double().norm() + 1e-12))
+        assert d < 2e-2, (n1, d)
+    _, _, l1, _ = net.evaluate(x, y, with_beta=True, epsilon=eps)
+    _, _, l2, _ = other.evaluate(x, y, with_beta=True, epsilon=eps)
+    assert abs(float(l1['total'].mean()) - float(l2['total'].mean())) < 2e-3 * float(l2['total'].mean())
