@@ -138,11 +138,12 @@ int jvae_elbo_bwd_f32(const float* g_wmse, const float* g_cx, const float* g_tot
                       int L, int N, int D, float beta, float cw, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- running measures of evaluate() in ONE device buffer (cvae.py:619-624,689-724,747-762; Encoder.capacity /
- * dict_min_distance layers.py:323-348): out[10] = sigma, mean x^2, mean mse, rmse, mean zdist, mean var_kl, ld-norm,
- * imut-zy, d-mind, optimiser non-finite flag.  sumsq_x = sum(x^2) from jvae_sqnorm_accum_f32; means may be NULL. */
+ * dict_min_distance layers.py:323-348): out[16]: [0..9] = sigma, mean x^2, mean mse, rmse, mean zdist, mean var_kl, ld-norm,
+ * imut-zy, d-mind, optimiser non-finite flag; [10..15] = running means over `batch`+1 calls of xpow, mse, rmse, dB,
+ * zdist, var_kl (prev = the previous call's out, NULL at batch 0).  sumsq_x = sum(x^2) from jvae_sqnorm_accum_f32; means may be NULL. */
 int jvae_measures_f32(const float* sumsq_x, long nx, const float* wmse, const float* zdist, const float* var_kl, int N,
                       const float* sigma, int sigma_is_log, const float* means, int C, int K, const int* flag,
-                      float* out, void* stream);
+                      const float* prev, int batch, float* out, void* stream);
 
 /* ---- classification term: per-row cross entropy, target y[r % N] (x_loss, module/losses.py:52-86) -- */
 int jvae_xent_fwd_f32(const float* logits, const long long* y, float* ce, int R, int N, int C, void* stream);

@@ -172,7 +172,8 @@ __global__ __launch_bounds__(256) void measures_kernel(const float* __restrict__
                                                        const float* __restrict__ var_kl, int N,
                                                        const float* __restrict__ sigma, int sigma_is_log,
                                                        const float* __restrict__ means, int C, int K,
-                                                       const int* __restrict__ flag, float* __restrict__ out) {
+                                                       const int* __restrict__ flag, const float* __restrict__ prev,
+                                                       int batch, float* __restrict__ out) {
     __shared__ float red[17];
     const int tid = threadIdx.x;
     const float sg = sigma_is_log ? __expf(sigma[0]) : sigma[0];
@@ -227,6 +228,18 @@ __global__ __launch_bounds__(256) void measures_kernel(const float* __restrict__
         out[7] = means ? __logf((float)C) - cap / C : 0.f;
         out[8] = means ? fminf(dmin, 2.f * mx) : 0.f;          // (cdist + 2 max|m| I).min(), layers.py:338-348
         out[9] = flag ? (float)flag[0] : 0.f;
+        // running means over the batches seen so far (cvae.py:689-699,720-724): out[10..15] =
+        // xpow, mse, rmse, dB, zdist, var_kl;  prev = the previous call's `out` (or NULL at batch 0)
+        const float nb = (float)batch, inv = 1.f / (nb + 1.f);
+        const float pxp = (prev && batch > 0) ? prev[10] : 0.f, pms = (prev && batch > 0) ? prev[11] : 0.f;
+        const float pzd = (prev && batch > 0) ? prev[14] : 0.f, pvk = (prev && batch > 0) ? prev[15] : 0.f;
+        const float rxp = (pxp * nb + out[1]) * inv, rms = (pms * nb + mse) * inv;
+        out[10] = rxp;
+        out[11] = rms;
+        out[12] = sqrtf(rms);
+        out[13] = 10.f * log10f(rxp / rms);
+        out[14] = (pzd * nb + out[4]) * inv;
+        out[15] = (pvk * nb + out[5]) * inv;
     }
 }
 
@@ -328,14 +341,14 @@ int jvae_elbo_bwd_f32(const float* g_wmse, const float* g_cx, const float* g_tot
     return 0;
 }
 
-// out: 10 floats on the device (layout: see measures_kernel).  sumsq_x: device scalar = sum(x^2) (jvae_sqnorm_accum_f32).
+// out: 16 floats on the device (layout: see measures_kernel); prev: the previous batch's `out` or NULL.  sumsq_x: device scalar = sum(x^2) (jvae_sqnorm_accum_f32).
 int jvae_measures_f32(const float* sumsq_x, long nx, const float* wmse, const float* zdist, const float* var_kl, int N,
                       const float* sigma, int sigma_is_log, const float* means, int C, int K, const int* flag,
-                      float* out, void* stream) {
+                      const float* prev, int batch, float* out, void* stream) {
     if (!sumsq_x || !wmse || !zdist || !var_kl || !sigma || !out || N <= 0 || nx <= 0) return JVAE_EINVAL;
     if (means && (C <= 0 || K <= 0 || C > 1024)) return JVAE_EINVAL;
     hipLaunchKernelGGL(measures_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, sumsq_x, (float)nx, wmse, zdist, var_kl,
-                       N, sigma, sigma_is_log, means, C, K, flag, out);
+                       N, sigma, sigma_is_log, means, C, K, flag, prev, batch, out);
     JVAE_LAUNCH_CHECK();
     return 0;
 }

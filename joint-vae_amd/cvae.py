@@ -40,6 +40,125 @@ VERSION = 2.
 LOG2PI = math.log(2 * math.pi)
 
 
+class Measures(dict):
+    """`total_measures` of evaluate(): a dict of Python floats (rmse, dB, sigma, ...) exactly as in the reference, but
+    materialised LAZILY: the 16 scalars sit in one device buffer (running means included, continued on the device from
+    batch to batch) that is copied to pinned host memory asynchronously; the first time any entry is read the dict
+    waits for that copy.  A training loop that only threads `measures` into the next evaluate() never synchronises."""
+
+    _KEYS = ('sigma', 'xpow', 'mse', 'rmse', 'dB', 'zdist', 'var_kl')
+
+    def __init__(self, dev, has_dictionary, on_nan):
+        super().__init__()
+        self._dev = dev
+        self._host = torch.empty(16, dtype=torch.float32, pin_memory=True)
+        self._host.copy_(dev, non_blocking=True)
+        self._event = torch.cuda.Event()
+        self._event.record()
+        self._has_dictionary = has_dictionary
+        self._on_nan = on_nan
+        self._ready = False
+
+    def _fill(self):
+        if self._ready:
+            return
+        self._ready = True
+        self._event.synchronize()
+        h = self._host.tolist()
+        if h[9] != 0:
+            self._on_nan()
+        dict.update(self, {'sigma': h[0], 'xpow': h[10], 'mse': h[11], 'rmse': h[12], 'dB': h[13], 'zdist': h[14],
+                           'var_kl': h[15]})
+        if self._has_dictionary:
+            dict.update(self, {'ld-norm': h[6], 'imut-zy': h[7], 'd-mind': h[8]})
+
+    def __getitem__(self, k):
+        self._fill()
+        return dict.__getitem__(self, k)
+
+    def get(self, k, d=None):
+        self._fill()
+        return dict.get(self, k, d)
+
+    def __contains__(self, k):
+        self._fill()
+        return dict.__contains__(self, k)
+
+    def __iter__(self):
+        self._fill()
+        return dict.__iter__(self)
+
+    def __len__(self):
+        self._fill()
+        return dict.__len__(self)
+
+    def keys(self):
+        self._fill()
+        return dict.keys(self)
+
+    def values(self):
+        self._fill()
+        return dict.values(self)
+
+    def items(self):
+        self._fill()
+        return dict.items(self)
+
+    def copy(self):
+        self._fill()
+        return dict(self)
+
+    def __repr__(self):
+        self._fill()
+        return dict.__repr__(self)
+
+
+class _LazySigmaParams(dict):
+    """training_parameters['sigma'] (Sigma.params with the current rms value) without a device read-back per batch."""
+
+    def __init__(self, sigma, measures):
+        super().__init__()
+        self._s, self._m, self._done = sigma, measures, False
+
+    def _fill(self):
+        if not self._done:
+            self._done = True
+            dict.update(self, self._s.host_params(self._m['sigma']))
+
+    def __getitem__(self, k):
+        self._fill()
+        return dict.__getitem__(self, k)
+
+    def items(self):
+        self._fill()
+        return dict.items(self)
+
+    def keys(self):
+        self._fill()
+        return dict.keys(self)
+
+    def __iter__(self):
+        self._fill()
+        return dict.__iter__(self)
+
+    def __len__(self):
+        self._fill()
+        return dict.__len__(self)
+
+    def copy(self):
+        self._fill()
+        return dict(self)
+
+    def __repr__(self):
+        self._fill()
+        return dict.__repr__(self)
+
+
+def _grad_nan_exit():
+    print('GRAD NAN')              # cvae.py:2454-2457; detected by the Adam kernel, reported when measures are read
+    sys.exit(1)
+
+
 class ClassificationVariationalNetwork(nn.Module):
     r"""X -- features -- encoder -- Z -- decoder -- imager -- X^   with a class-conditional prior p(z|y)
     (and a classifier head on z when gamma > 0)."""
@@ -320,47 +439,35 @@ class ClassificationVariationalNetwork(nn.Module):
             losses['cross_y'] = ce
         losses['total'] = total
 
-        packed = self._pack_measures(x, wmse, terms, dictionary)
+        prev = current_measures._dev if isinstance(current_measures, Measures) else self._upload_measures(
+            current_measures, x.device) if (current_measures and batch) else None
+        packed = self._pack_measures(x, wmse, terms, dictionary, prev, batch)
         if self.training:
             self.sigma.update(rmse=packed[3])                                # device scalar, as in the reference
-        measures = self._measures(packed.tolist(), dictionary is not None, batch, current_measures)
+        measures = Measures(packed, dictionary is not None, _grad_nan_exit)
         if self.training:
-            self.training_parameters['sigma'] = self.sigma.host_params(measures['sigma'])
+            self.training_parameters['sigma'] = _LazySigmaParams(self.sigma, measures)
         out = (x_reco, logits[1:].mean(0), losses, measures)
         if z_output:
             out += (mu, log_var, z)
         return out
 
-    def _pack_measures(self, x, wmse, terms, dictionary):
-        """Every scalar evaluate() reports, computed by one kernel into one 10-float device buffer."""
+    def _upload_measures(self, current, device):
+        """Running means handed in as plain floats (first batch of a resumed loop, a caller's own dict)."""
+        t = torch.zeros(16)
+        for i, k in ((10, 'xpow'), (11, 'mse'), (14, 'zdist'), (15, 'var_kl')):
+            t[i] = float(current.get(k, 0.))
+        return t.to(device, non_blocking=True)
+
+    def _pack_measures(self, x, wmse, terms, dictionary, prev, batch):
+        """Every scalar evaluate() reports, computed by one kernel into one 16-float device buffer."""
         with torch.no_grad():
             if getattr(self, '_scratch', None) is None or self._scratch.device != x.device:
                 self._scratch = torch.zeros(1, device=x.device, dtype=torch.float32)
             return ops.measures(x, wmse.detach(), terms['distance'].detach(), terms['var_kl'].detach(),
                                 self.sigma.detach(), self.sigma.is_log,
                                 None if dictionary is None else dictionary.detach(),
-                                self.optimizer.nonfinite_flag(), self._scratch)
-
-    def _measures(self, host, has_dictionary, batch, current):
-        """Running means as Python floats (cvae.py:619-624,689-724,755-762) from the ONE device->host copy."""
-        if not current:
-            current = {k: 0. for k in ('xpow', 'mse', 'dB', 'imut-zy', 'd-mind', 'ld-norm', 'var_kl', 'zdist')}
-        if host[9] != 0:
-            print('GRAD NAN')                       # cvae.py:2454-2457 (reported one step later: no extra sync)
-            sys.exit(1)
-        m = {'sigma': host[0]}
-
-        def run(key, v):
-            return (current[key] * batch + v) / (batch + 1)
-        m['xpow'] = run('xpow', host[1])
-        m['mse'] = run('mse', host[2])
-        m['rmse'] = math.sqrt(m['mse'])
-        m['dB'] = 10 * math.log10(m['xpow'] / m['mse'])
-        m['zdist'] = run('zdist', host[4])
-        m['var_kl'] = run('var_kl', host[5])
-        if has_dictionary:
-            m['ld-norm'], m['imut-zy'], m['d-mind'] = host[6], host[7], host[8]
-        return m
+                                self.optimizer.nonfinite_flag(), self._scratch, prev, batch)
 
     # ------------------------------------------------------------------------------------ training loop
     def train_step(self, x, y, batch=0, current_measures=None, kl_var_weighting=1., gamma_weighting=1., epsilon=None):
