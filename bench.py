@@ -114,8 +114,14 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        ndev = torch.cuda.device_count()
+        backend = os.environ.get('JVAE_BENCH_BACKEND', 'nccl')       # 'gloo': rehearsal of the DP path on one GPU
+        local = local % max(ndev, 1)
         torch.cuda.set_device(local)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group(backend)
     device = torch.device('cuda', local)
     torch.cuda.set_device(device)
 
@@ -157,7 +163,7 @@ def main():
                           'global_batch': world * BATCH_PER_GPU, 'parallelism': f'dp{world}',
                           'bn_statistics': 'per-rank (local)'},
                'step_mfma_frac': value / world * FLOP_PER_IMAGE / MFMA_F32_PEAK,
-               'final_loss': float(losses['total'].mean())}
+               'final_loss': float(losses['total'].detach().mean())}
         out['roofline'] = dominant_kernel_roofline(device)
         if world == 1 and not a.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()

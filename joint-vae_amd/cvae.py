@@ -301,6 +301,7 @@ class ClassificationVariationalNetwork(nn.Module):
         self.testing = {0: {m: {'n': 0, 'epochs': 0, 'accuracy': 0} for m in self.predict_methods}}
         self.ood_results = {}
         self.optimizer = Optimizer(self.parameters(), **optimizer)
+        self.optimizer.set_early_bucket(list(self.imager.parameters()) + list(self.decoder.parameters()))
         self.training_parameters['optimizer'] = self.optimizer.params
         self.train_history = {'epochs': 0}
 
@@ -419,6 +420,9 @@ class ClassificationVariationalNetwork(nn.Module):
         feats = self._features_of(x).reshape(N, -1)
         y1h = onehot_encoding(y, self.num_labels).float() if self.y_is_coded else None
         mu, log_var, z, eps, _, terms = self.encoder.encode(feats, y1h, y, kl_var_weighting, epsilon)
+        if self.training and self.optimizer._world > 1 and z.requires_grad:
+            # data-parallel: the decoder's gradients are final once d(loss)/dz exists -> start their all-reduce there
+            z.register_hook(self._early_reduce_hook)
         x_, logits = self._decode(z)
         x_reco = x_.view(L + 1, N, *self.input_shape)
 
@@ -451,6 +455,10 @@ class ClassificationVariationalNetwork(nn.Module):
         if z_output:
             out += (mu, log_var, z)
         return out
+
+    def _early_reduce_hook(self, grad):
+        self.optimizer.reduce_early_bucket()
+        return grad
 
     def _upload_measures(self, current, device):
         """Running means handed in as plain floats (first batch of a resumed loop, a caller's own dict)."""

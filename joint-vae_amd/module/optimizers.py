@@ -123,6 +123,46 @@ class Optimizer:
         self._world = int(world_size)
         self._pg = process_group
 
+    def set_early_bucket(self, params):
+        """Parameters whose gradients are complete first in backward (the decoder / imager): their slice of the flat
+        buffer is all-reduced as soon as `reduce_early_bucket()` is called, overlapping the rest of backward."""
+        self._early = [p for p in params]
+        self._early_work = None
+        self._early_range = None
+
+    def _early_slice(self):
+        """(group, lo, hi) of the contiguous flat range holding the early-bucket parameters, or None."""
+        ids = {id(p) for p in getattr(self, '_early', [])}
+        if not ids or len(self._groups) != 1:
+            return None
+        g = self._groups[0]
+        idx = [i for i, p in enumerate(g.params) if id(p) in ids]
+        if not idx or idx != list(range(idx[0], idx[-1] + 1)):
+            return None
+        lo = g.offsets[idx[0]]
+        hi = g.offsets[idx[-1] + 1] if idx[-1] + 1 < len(g.params) else g.numel
+        return g, lo, hi
+
+    def reduce_early_bucket(self):
+        """Called from a hook once the early bucket's backward kernels are queued (main + side stream)."""
+        if self._world <= 1 or self._reduced or getattr(self, '_early_work', None) is not None:
+            return
+        sl = self._early_slice()
+        if sl is None or not all(gr.intact() for gr in self._groups):
+            return
+        import torch.distributed as dist
+        from jvae_hip import lib as _lib
+        g, lo, hi = sl
+        dev = g.g.device
+        if dev.type == 'cuda':
+            side = _lib.side_stream(dev)
+            side.wait_stream(torch.cuda.current_stream(dev))      # dgrad chain so far + wgrads already on `side`
+            with torch.cuda.stream(side):
+                self._early_work = dist.all_reduce(g.g[lo:hi], op=dist.ReduceOp.AVG, group=self._pg, async_op=True)
+        else:
+            self._early_work = dist.all_reduce(g.g[lo:hi], op=dist.ReduceOp.AVG, group=self._pg, async_op=True)
+        self._early_range = (lo, hi)
+
     def reduce_gradients(self):
         from jvae_hip import lib as _lib
         if _lib._side_streams:
@@ -130,8 +170,18 @@ class Optimizer:
         if self._world > 1 and not self._reduced:
             import torch.distributed as dist
             self._adopt_new()
+            early = getattr(self, '_early_work', None)
             for g in self._groups:
-                dist.all_reduce(g.g, op=dist.ReduceOp.AVG, group=self._pg)
+                if early is not None and g is self._groups[0]:
+                    lo, hi = self._early_range            # the rest of the buffer: two slices around the early bucket
+                    if lo > 0:
+                        dist.all_reduce(g.g[:lo], op=dist.ReduceOp.AVG, group=self._pg)
+                    if hi < g.numel:
+                        dist.all_reduce(g.g[hi:], op=dist.ReduceOp.AVG, group=self._pg)
+                    early.wait()
+                else:
+                    dist.all_reduce(g.g, op=dist.ReduceOp.AVG, group=self._pg)
+            self._early_work = None
             self._reduced = True
 
     # ---- flat-buffer management -------------------------------------------------------------------
@@ -213,6 +263,7 @@ class Optimizer:
                 p.grad = None
         self._clip_pending = False
         self._reduced = False
+        self._early_work = None
 
     def clip(self, parameters=None):
         """clip_grad_norm_(all parameters, grad_clipping): the norm is reduced here, the coefficient is

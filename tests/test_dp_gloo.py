@@ -54,6 +54,15 @@ def _worker(rank, world, port, out_dir):
     assert torch.equal(torch.cat([p.grad.reshape(-1) for p in params]), before)
     opt.zero_grad()
     assert all(float(p.grad.abs().max()) == 0. for p in params) and params[0].grad.data_ptr() == base
+    # second "step": an early bucket (params 1..2) is exchanged asynchronously first, the rest afterwards
+    opt.set_early_bucket(params[1:3])
+    for p, gr in zip(params, local):
+        p.grad.copy_(gr)
+    opt.reduce_early_bucket()
+    assert opt._early_work is not None and opt._early_range is not None
+    opt.reduce_gradients()
+    for p, e in zip(params, exp):
+        assert torch.allclose(p.grad, e, atol=1e-6)
     open(os.path.join(out_dir, f'ok{rank}'), 'w').close()
     dist.destroy_process_group()
 
