@@ -15,6 +15,7 @@
 // pitch (conflict-free A reads).  Accumulators live in registers across the whole image loop; each
 // workgroup writes one slab, and a second kernel reduces the slabs in a fixed order (deterministic, no
 // float atomics) into dW (optionally accumulating, optionally transposing / flipping for the swapped form).
+#include <stdlib.h>
 #include "common.h"
 #include "jvae_internal.h"
 #include "conv_dispatch.h"
@@ -47,7 +48,7 @@ struct WgGeom {
     static constexpr int NBT = (NTILE + 3) / 4;               // per wave
 };
 
-template <int S, int WS, int CB>
+template <int S, int WS, int CB, bool PF>
 __global__ __launch_bounds__(256, 2) void conv5_wgrad_kernel(WgP p) {
     using G = WgGeom<S, WS, CB>;
     __shared__ __attribute__((aligned(16))) float lds[G::QS + G::PSZ];
@@ -143,12 +144,13 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_kernel(WgP p) {
     };
 
     const int item_beg = n_beg * G::TILES, item_end = n_end * G::TILES;
-    if (item_beg < item_end) gload(item_beg);
+    if (PF && item_beg < item_end) gload(item_beg);
     for (int item = item_beg; item < item_end; ++item) {
         __syncthreads();
+        if (!PF) gload(item);                    // wide (CB = 32) variant: no registers to spare for a prefetch
         lstore();
         __syncthreads();
-        if (item + 1 < item_end) gload(item + 1);
+        if (PF && item + 1 < item_end) gload(item + 1);
 #pragma unroll
         for (int ks = 0; ks < G::TPIX / 2; ++ks) {
             const int pix = 2 * ks;                                   // + half (folded into aoff / boff)
@@ -201,19 +203,24 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     dw[dst] = accumulate ? dw[dst] + s : s;
 }
 
-template <int S, int WS, int CB>
+template <int S, int WS, int CB, bool PF = true>
 int launch_wg(const WgP& p, hipStream_t st) {
     using G = WgGeom<S, WS, CB>;
     static_assert((G::QS + G::PSZ) * 4 <= 64 * 1024, "static LDS budget");
     dim3 grid(p.G, (p.Ca + 31) / 32, (p.Cb + CB - 1) / CB);
-    hipLaunchKernelGGL((conv5_wgrad_kernel<S, WS, CB>), grid, dim3(256), 0, st, p);
+    hipLaunchKernelGGL((conv5_wgrad_kernel<S, WS, CB, PF>), grid, dim3(256), 0, st, p);
     JVAE_LAUNCH_CHECK();
     return 0;
 }
 
+static int g_wide = -1;      // JVAE_WGRAD_WIDE=0 disables the 32-channel (25 tiles / 28 slots) variant: tuning knob
+inline bool wide_ok(int S, int WS, int Cb) {
+    if (g_wide < 0) { const char* e = getenv("JVAE_WGRAD_WIDE"); g_wide = (e && e[0] == '0') ? 0 : 1; }
+    return g_wide && S == 1 && (WS == 16 || WS == 32) && Cb % 32 == 0;
+}
 inline int pick_cb(int S, int WS, int Cb) {
     if (Cb <= 4) return 4;                      // 3-channel tensors (image side of the first / last layer)
-    return 16;
+    return wide_ok(S, WS, Cb) ? 32 : 16;
 }
 
 }  // namespace
@@ -263,6 +270,8 @@ int jvae_conv5_wgrad(const float* ps, const float* q, float* dw, int accumulate,
                 case 64: rc = launch_wg<2, 64, 4>(p, st); break;
             }
         }
+    } else if (wide_ok(S, WS, Cb)) {
+        rc = WS == 16 ? launch_wg<1, 16, 32, false>(p, st) : launch_wg<1, 32, 32, false>(p, st);
     } else if (S == 1) {
         switch (WS) {
             case 8: rc = launch_wg<1, 8, 16>(p, st); break;
