@@ -140,8 +140,9 @@ int jvae_elbo_bwd_f32(const float* g_wmse, const float* g_cx, const float* g_tot
 /* ---- running measures of evaluate() in ONE device buffer (cvae.py:619-624,689-724,747-762; Encoder.capacity /
  * dict_min_distance layers.py:323-348): out[16]: [0..9] = sigma, mean x^2, mean mse, rmse, mean zdist, mean var_kl, ld-norm,
  * imut-zy, d-mind, optimiser non-finite flag; [10..15] = running means over `batch`+1 calls of xpow, mse, rmse, dB,
- * zdist, var_kl (prev = the previous call's out, NULL at batch 0).  sumsq_x = sum(x^2) from jvae_sqnorm_accum_f32; means may be NULL. */
-int jvae_measures_f32(const float* sumsq_x, long nx, const float* wmse, const float* zdist, const float* var_kl, int N,
+ * zdist, var_kl (prev = the previous call's out, NULL at batch 0); wmse has N entries, zdist / var_kl Nz (= N, or C*N
+ * for the all-class evaluation).  sumsq_x = sum(x^2) from jvae_sqnorm_accum_f32; means may be NULL. */
+int jvae_measures_f32(const float* sumsq_x, long nx, const float* wmse, const float* zdist, const float* var_kl, int N, int Nz,
                       const float* sigma, int sigma_is_log, const float* means, int C, int K, const int* flag,
                       const float* prev, int batch, float* out, void* stream);
 

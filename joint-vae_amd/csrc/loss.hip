@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void elbo_bwd_kernel(const float* __restrict__
 // [6] ld-norm = mean(m^2), [7] imut-zy (capacity bound), [8] d-mind, [9] non-finite flag of the optimiser
 __global__ __launch_bounds__(256) void measures_kernel(const float* __restrict__ sumsq_x, float nx,
                                                        const float* __restrict__ wmse, const float* __restrict__ zdist,
-                                                       const float* __restrict__ var_kl, int N,
+                                                       const float* __restrict__ var_kl, int N, int Nz,
                                                        const float* __restrict__ sigma, int sigma_is_log,
                                                        const float* __restrict__ means, int C, int K,
                                                        const int* __restrict__ flag, const float* __restrict__ prev,
@@ -178,7 +178,8 @@ __global__ __launch_bounds__(256) void measures_kernel(const float* __restrict__
     const int tid = threadIdx.x;
     const float sg = sigma_is_log ? __expf(sigma[0]) : sigma[0];
     float a = 0.f, b = 0.f, c = 0.f;
-    for (int i = tid; i < N; i += blockDim.x) { a += wmse[i]; b += zdist[i]; c += var_kl[i]; }
+    for (int i = tid; i < N; i += blockDim.x) a += wmse[i];
+    for (int i = tid; i < Nz; i += blockDim.x) { b += zdist[i]; c += var_kl[i]; }
     a = block_sum(a, red); b = block_sum(b, red); c = block_sum(c, red);
     float msq = 0.f, mx = 0.f;
     if (means) {
@@ -222,8 +223,8 @@ __global__ __launch_bounds__(256) void measures_kernel(const float* __restrict__
         out[1] = sumsq_x[0] / nx;
         out[2] = mse;
         out[3] = sqrtf(mse);
-        out[4] = b / N;
-        out[5] = c / N;
+        out[4] = b / Nz;
+        out[5] = c / Nz;
         out[6] = means ? msq / (C * K) : 0.f;
         out[7] = means ? __logf((float)C) - cap / C : 0.f;
         out[8] = means ? fminf(dmin, 2.f * mx) : 0.f;          // (cdist + 2 max|m| I).min(), layers.py:338-348
@@ -342,13 +343,13 @@ int jvae_elbo_bwd_f32(const float* g_wmse, const float* g_cx, const float* g_tot
 }
 
 // out: 16 floats on the device (layout: see measures_kernel); prev: the previous batch's `out` or NULL.  sumsq_x: device scalar = sum(x^2) (jvae_sqnorm_accum_f32).
-int jvae_measures_f32(const float* sumsq_x, long nx, const float* wmse, const float* zdist, const float* var_kl, int N,
+int jvae_measures_f32(const float* sumsq_x, long nx, const float* wmse, const float* zdist, const float* var_kl, int N, int Nz,
                       const float* sigma, int sigma_is_log, const float* means, int C, int K, const int* flag,
                       const float* prev, int batch, float* out, void* stream) {
-    if (!sumsq_x || !wmse || !zdist || !var_kl || !sigma || !out || N <= 0 || nx <= 0) return JVAE_EINVAL;
+    if (!sumsq_x || !wmse || !zdist || !var_kl || !sigma || !out || N <= 0 || Nz <= 0 || nx <= 0) return JVAE_EINVAL;
     if (means && (C <= 0 || K <= 0 || C > 1024)) return JVAE_EINVAL;
     hipLaunchKernelGGL(measures_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, sumsq_x, (float)nx, wmse, zdist, var_kl,
-                       N, sigma, sigma_is_log, means, C, K, flag, prev, batch, out);
+                       N, Nz, sigma, sigma_is_log, means, C, K, flag, prev, batch, out);
     JVAE_LAUNCH_CHECK();
     return 0;
 }

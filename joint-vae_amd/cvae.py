@@ -407,8 +407,7 @@ class ClassificationVariationalNetwork(nn.Module):
         All Python floats of `total_measures` come from ONE packed device read-back.
         """
         if y is None:
-            raise NotImplementedError('all-class evaluation (y=None: accuracy / OOD scoring, SURVEY.md §8f-1) is not '
-                                      'part of this build; the training step always provides y')
+            return self._evaluate_all_classes(x, batch, current_measures, with_beta, z_output, epsilon)
         if x.dim() != self.input_dim + 1:
             x = x.reshape(-1, *self.input_shape)
             y = y.reshape(-1)
@@ -454,6 +453,120 @@ class ClassificationVariationalNetwork(nn.Module):
         out = (x_reco, logits[1:].mean(0), losses, measures)
         if z_output:
             out += (mu, log_var, z)
+        return out
+
+    # ------------------------------------------------------------------------------------ evaluation
+    def _evaluate_all_classes(self, x, batch, current_measures, with_beta, z_output, epsilon):
+        """evaluate(x) without labels (cvae.py:548-600, 793-873): every class is tried as the prior component.
+        Losses kl / zdist / var_kl / total / iws [/ cross_y] are (C, N); wmse / cross_x / dzdist stay (N,).
+        The heavy parts (conv stacks on (L+1)N latents, BatchNorm, latent / KL kernel on C*N rows, reconstruction,
+        Mahalanobis distances of the L*C*N sampled latents) run on the HIP kernels; the final importance-weight
+        assembly is a handful of elementwise expressions on (L, C, N) tensors."""
+        if self.y_is_coded:
+            raise NotImplementedError('y_is_coded models need labels')
+        if x.dim() != self.input_dim + 1:
+            x = x.reshape(-1, *self.input_shape)
+        N, C, K = x.shape[0], self.num_labels, self.latent_dim
+        L = self.latent_sampling
+        D = int(np.prod(self.input_shape))
+        pr = self.encoder.prior
+        with torch.no_grad():
+            feats = self._features_of(x).reshape(N, -1)
+            dummy = torch.zeros(N, dtype=torch.int64, device=x.device)
+            mu, log_var, z, eps, _, _ = self.encoder.encode(feats, None, dummy, 1., epsilon)
+            x_, logits = self._decode(z)
+            x_reco = x_.view(L + 1, N, *self.input_shape)
+            s = self.sigma
+            wmse_s = ops.recon_wmse(x_reco, x, s, s.is_log)                               # (L, N)
+            y_all = torch.arange(C, device=x.device).unsqueeze(1).expand(C, N)
+            kd = pr.kl(mu, log_var, y=y_all if pr.conditional else None)                  # (C, N) each
+            zero_kl = torch.zeros(N, device=x.device)
+            wmse, cross_x, _ = ops.elbo(wmse_s, zero_kl, None, s, s.is_log, D, 1., 0.)
+            losses = {'kl': kd['kl'], 'zdist': kd['distance'], 'var_kl': kd['var_kl']}
+            dictionary = pr.mean if pr.conditional else None
+            terms = {'distance': kd['distance'].reshape(-1), 'var_kl': kd['var_kl'].reshape(-1)}
+            if dictionary is not None:
+                _, _, _, _, _, dz = ops.latent(mu, log_var, torch.zeros((1, N, K), device=x.device), dummy,
+                                               dictionary, pr._var_parameter, var_dim=pr.var_dim, sampled=False)
+                losses['dzdist'] = dz
+            losses['wmse'], losses['cross_x'] = wmse, cross_x
+            if self.y_is_decoded:
+                losses['cross_y'] = x_loss(None, logits, batch_mean=False)                # (C, N)
+            beta = self.beta if with_beta else 1.
+            losses['total'] = cross_x.unsqueeze(0) + beta * kd['kl']
+            # importance-weighted bound: log p(x|z_l) + log p(z_l|y) - log q(z_l|x), cvae.py:672-676,793-873
+            log_sigma = s.squeeze() if s.is_log else s.log().squeeze()
+            log_px = -D / 2 * (wmse_s + 2 * log_sigma + LOG2PI)                           # (L, N)
+            z_s = z[1:]
+            if pr.conditional:
+                z_y = z_s.unsqueeze(1).expand(L, C, N, K)
+                y_s = y_all.unsqueeze(0).expand(L, C, N)
+                log_pz = pr.log_density(z_y, y_s)                                         # (L, C, N)
+                log_px = log_px.unsqueeze(1)
+            else:
+                log_pz = pr.log_density(z_s, None)
+            log_inv_q = ((eps ** 2).sum(-1) + log_var.sum(-1)) / 2 + K / 2 * LOG2PI       # (L, N)
+            if pr.conditional:
+                log_inv_q = log_inv_q.unsqueeze(1)
+            li = log_px + log_pz + log_inv_q
+            rem = li.max(0)[0]
+            losses['iws'] = (li - rem).exp().mean(0) + rem                                # sic: cvae.py:868
+            prev = current_measures._dev if isinstance(current_measures, Measures) else None
+            packed = self._pack_measures(x, wmse, terms, dictionary, prev, batch)
+        measures = Measures(packed, dictionary is not None, _grad_nan_exit)
+        out = (x_reco, logits[1:].mean(0), losses, measures)
+        if z_output:
+            out += (mu, log_var, z)
+        return out
+
+    def predict_after_evaluate(self, logits, losses, method='default'):
+        """Class prediction from the all-class losses (cvae.py:938-970)."""
+        if method == 'default':
+            method = self.predict_methods[0]
+        if method is None:
+            return logits.softmax(-1)
+        table = {'iws': lambda: losses['iws'].argmax(0), 'closest': lambda: losses['zdist'].argmin(0),
+                 'loss': lambda: losses['total'].argmin(0), 'esty': lambda: logits.argmax(-1),
+                 'mean': lambda: logits.softmax(-1).mean(0).argmax(-1), 'already': lambda: losses['y_est_already']}
+        if method not in table:
+            raise ValueError(f'Unknown method {method}')
+        return table[method]()
+
+    def predict(self, x, method=None, **kw):
+        _, logits, losses, _ = self.evaluate(x)
+        return self.predict_after_evaluate(logits, losses, method=method or 'default')
+
+    def batch_dist_measures(self, logits, losses, methods, to_cpu=False):
+        """OOD scores per sample (higher = more in-distribution) for the cvae methods (cvae.py:972-1085); the
+        '-2s' / '-a-x-y' suffixes only name the thresholding done downstream."""
+        C = self.num_labels
+        out = {}
+        for name in methods:
+            m = name[:-3] if name.endswith('-2s') else name
+            m = m.split('-')[0] if '-a-' in m else m
+            if m in ('elbo', 'max'):
+                v = (-losses['total']).max(0)[0]
+            elif m == 'iws':
+                top = losses['iws'].max(0)[0]
+                v = (losses['iws'] - top).exp().sum(0).log() + top + math.log(C)
+            elif m in ('soft', 'softkl'):
+                v = (-losses['kl']).softmax(0).max(0)[0]
+            elif m.startswith('softkl-'):
+                v = (-losses['kl'] / float(m[7:])).softmax(0).max(0)[0]
+            elif m in ('zdist', 'kl'):
+                v = (-losses[m]).max(0)[0]
+            elif m == 'mse':
+                v = -losses['cross_x']
+            elif m == 'wmse':
+                v = -losses['wmse']
+            elif m == 'logits':
+                v = logits.max(-1)[0]
+            elif m.startswith('baseline'):
+                T = float(m.split('-')[-1]) if '-' in m else 1.
+                v = (logits / T).softmax(-1).max(-1)[0]
+            else:
+                raise NotImplementedError(f'{name}: OOD method outside this build')
+            out[name] = v.cpu() if to_cpu else v
         return out
 
     def _early_reduce_hook(self, grad):

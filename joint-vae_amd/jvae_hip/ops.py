@@ -512,7 +512,7 @@ def measures(x, wmse, zdist, var_kl, sigma, sigma_is_log, means, flag, scratch, 
     L.check(lib.jvae_sqnorm_accum_f32(L.ptr(x), x.numel(), L.ptr(scratch), 1, L.stream_ptr()), 'sumsq(x)')
     out = torch.empty(16, device=x.device, dtype=torch.float32)
     C, K = (means.shape if means is not None else (0, 0))
-    rc = lib.jvae_measures_f32(L.ptr(scratch), x.numel(), L.ptr(_c(wmse)), L.ptr(_c(zdist)), L.ptr(_c(var_kl)), wmse.numel(),
+    rc = lib.jvae_measures_f32(L.ptr(scratch), x.numel(), L.ptr(_c(wmse)), L.ptr(_c(zdist)), L.ptr(_c(var_kl)), wmse.numel(), zdist.numel(),
                                L.ptr(_c(sigma)), int(sigma_is_log), L.ptr(None if means is None else _c(means)), C, K,
                                L.ptr(flag), L.ptr(prev), int(batch), L.ptr(out), L.stream_ptr())
     L.check(rc, 'jvae_measures_f32')

@@ -65,8 +65,20 @@ CASES = {
 }
 
 
+# Evaluation-mode cases: evaluate(x) WITHOUT labels in eval mode -> all-class losses (C, N), the
+# importance-weighted bound `iws`, predictions and OOD scores.  BatchNorm runs on its running statistics.
+EVAL_CASES = {
+    'e2_n8_L3': dict(net=_conv(10, test_latent_sampling=3), N=8),
+    'e3_n6_diag_L2': dict(net=_conv(100, test_latent_sampling=2,
+                                    prior=dict(distribution='gaussian', init_mean=0., learned_means=True,
+                                               var_dim='diag', freeze_means=0)), N=6),
+    'e2_n8_gamma_L2': dict(net=_conv(10, gamma=2.0, classifier=[20], test_latent_sampling=2), N=8),
+}
+EVAL_OOD_METHODS = ['iws', 'mse', 'elbo', 'soft', 'zdist', 'iws-2s', 'elbo-a-4-1']
+
+
 def get_case(name):
-    return copy.deepcopy(CASES[name])
+    return copy.deepcopy(CASES[name] if name in CASES else EVAL_CASES[name])
 
 
 def full_config(which, N=512):

@@ -27,7 +27,7 @@ REPO = os.path.dirname(HERE)
 REF = '/root/reference'
 sys.path.insert(0, REPO)
 
-from oracle.cases import CASES, get_case            # noqa: E402
+from oracle.cases import CASES, EVAL_CASES, EVAL_OOD_METHODS, get_case            # noqa: E402
 from oracle.det_init import load_det_state, det_inputs  # noqa: E402
 
 FULL_GRAD_MAX = 8192      # parameters up to this many elements get their full gradient stored
@@ -153,12 +153,48 @@ def run_case(Net, name):
           f'|g|={out["total_grad_norm"]:.5f} nparams={out["nparams"]} -> {path} ({kb:.0f} KiB)')
 
 
+def run_eval_case(Net, name):
+    """evaluate(x) without labels in eval mode (cvae.py:548-600,793-873) + predict_after_evaluate (:938-970) +
+    batch_dist_measures (:972-1085) of the reference."""
+    case = get_case(name)
+    kw = case['net']
+    N = case['N']
+    torch.manual_seed(0)
+    net = Net(**kw)
+    load_det_state(net, seed=0)
+    net.eval()
+    L = net.latent_sampling
+    x, y, eps = det_inputs(N, kw['input_shape'], kw['num_labels'], L, kw['latent_dim'])
+    out = {}
+    with torch.no_grad(), inject_eps(eps):
+        x_reco, y_est, losses, measures = net.evaluate(x, batch=0)
+    out['L'] = np.int64(L)
+    out['x_reco'] = x_reco.numpy()
+    out['y_est'] = y_est.numpy()
+    for k, v in losses.items():
+        out['loss.' + k] = v.numpy()
+    for k, v in measures.items():
+        out['measure.' + k] = np.float64(v)
+    for m in net.predict_methods:
+        out['predict.' + m] = net.predict_after_evaluate(y_est, losses, method=m).numpy()
+    dm = net.batch_dist_measures(y_est, losses, EVAL_OOD_METHODS)
+    for k, v in dm.items():
+        out['ood.' + k] = v.numpy()
+    out['predict_methods'] = np.array(net.predict_methods)
+    path = os.path.join(REPO, 'tests', 'golden', name + '.npz')
+    np.savez_compressed(path, **out)
+    print(f'{name}: L={L} iws[0,:3]={out["loss.iws"][0, :3]} -> {path} ({os.path.getsize(path) / 1024:.0f} KiB)')
+
+
 def main():
-    names = sys.argv[1:] or list(CASES)
+    names = sys.argv[1:] or (list(CASES) + list(EVAL_CASES))
     Net = import_reference()
     torch.set_num_threads(8)
     for n in names:
-        run_case(Net, n)
+        if n in EVAL_CASES:
+            run_eval_case(Net, n)
+        else:
+            run_case(Net, n)
 
 
 if __name__ == '__main__':

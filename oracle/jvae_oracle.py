@@ -389,6 +389,119 @@ def evaluate(sp, P, x, y, eps, kl_var_weighting=1.0, gamma_weighting=1.0, with_b
     return x_reco, logits[1:].mean(0), losses, meas, mu, log_var, z
 
 
+def evaluate_all_classes(sp, P, x, eps):
+    """evaluate(x) WITHOUT labels in eval mode (cvae.py:548-600,619-762,793-873): every class is tried as the prior
+    component; returns (x_reco, y_est, losses with (C,N) entries incl. `iws`, measures).  eps: (Ltest+1, N, K)."""
+    N = x.shape[0]
+    K, C = sp['K'], sp['C']
+    L = eps.shape[0] - 1
+    D = int(np.prod(sp['input_shape']))
+    t = run_stack(P, 'features', sp['features'], sp['bn_e'], x, None, False) if sp['features'] else x
+    u = t.reshape(N, -1)
+    for j in range(len(sp['enc'])):
+        u = torch.relu(F.linear(u, P[f'encoder.dense_projs.{2 * j}.weight'], P[f'encoder.dense_projs.{2 * j}.bias']))
+    mu = F.linear(u, P['encoder.dense_mean.weight'], P['encoder.dense_mean.bias'])
+    log_var = torch.clip(F.linear(u, P['encoder.dense_log_var.weight'], P['encoder.dense_log_var.bias']), -20, 20)
+    z = mu + torch.exp(0.5 * log_var) * eps * float(sp['sampled'])
+    h = z
+    for j in range(len(sp['dec'])):
+        h = torch.relu(F.linear(h, P[f'decoder.{2 * j}.weight'], P[f'decoder.{2 * j}.bias']))
+    if sp['imager']:
+        xr = run_stack(P, 'imager', sp['imager'], sp['bn_d'], h.reshape(-1, *sp['imager_in']), sp['out_act'], False)
+    else:
+        xr = _act(F.linear(h, P['imager.0.weight'], P['imager.0.bias']), sp['out_act'])
+    x_reco = xr.reshape(L + 1, N, *sp['input_shape'])
+    c = z
+    nclf = len(sp['clf'])
+    for j in range(nclf):
+        c = torch.relu(F.linear(c, P[f'classifier.{2 * j}.weight'], P[f'classifier.{2 * j}.bias']))
+    logits = F.linear(c, P[f'classifier.{2 * nclf}.weight'], P[f'classifier.{2 * nclf}.bias'])
+
+    s = P['sigma']
+    sigma_, log_sigma = (s.exp(), s.squeeze()) if sp['sigma'].get('learned') else (s, s.log().squeeze())
+    wmse_s = ((x_reco[1:] / sigma_ - (x / sigma_).unsqueeze(0)) ** 2).reshape(L, N, -1).mean(-1)
+    wmse = wmse_s.mean(0)
+    log_iws = -D / 2 * (wmse_s + 2 * log_sigma + math.log(2 * math.pi))                 # (L, N)   cvae.py:672-676
+    y_all = torch.arange(C).repeat_interleave(N)                                        # class-major (C*N,)
+    kd = prior_kl(sp, P, mu.repeat(C, 1), log_var.repeat(C, 1), y_all, 1.0)
+    losses = {k2: kd[k1].reshape(C, N) for k1, k2 in (('kl', 'kl'), ('distance', 'zdist'), ('var_kl', 'var_kl'))}
+    dic = P['encoder.prior.mean']
+    dmean = dic.mean(0)
+    losses['dzdist'] = (mu - dmean).pow(2).sum(1) + (dic.pow(2).sum(1).mean(0) - dmean.pow(2).sum())
+    losses['wmse'] = wmse
+    losses['cross_x'] = D * (2 * log_sigma + wmse + math.log(2 * math.pi)) / 2
+    if sp['gamma']:
+        log_p = (logits.softmax(-1) + 1e-6).log()                                       # losses.py:60-68
+        losses['cross_y'] = -(log_p[1:].mean(0) if L + 1 > 1 else log_p[0]).t()
+    losses['total'] = losses['cross_x'].unsqueeze(0) + losses['kl']                     # beta = 1 (with_beta False)
+    # importance-weighted bound (cvae.py:793-873); gaussian prior: log p(z|y) = -K/2 log 2pi - mahala/2 - log|S_y|/2
+    T = prior_T(sp, P)
+    d = z[1:].unsqueeze(1) - dic.unsqueeze(0).unsqueeze(2)                              # (L, C, N, K)
+    if T.ndim == 3:
+        wd = torch.einsum('cij,lcnj->lcni', T, d)
+        logdet = -2 * torch.diagonal(T, dim1=-2, dim2=-1).abs().log().sum(-1)
+    elif T.ndim == 2:
+        wd = d * T.view(1, C, 1, K)
+        logdet = -2 * T.abs().log().sum(-1)
+    else:
+        wd = d * T.view(1, C, 1, 1)
+        logdet = -2 * K * T.log()
+    log_p_z_y = -math.log(2 * math.pi) * K / 2 - wd.pow(2).sum(-1) / 2 - logdet.view(1, C, 1) / 2
+    if sp['prior'].get('distribution') == 'tilted':
+        log_p_z_y = log_p_z_y - z[1:].norm(dim=-1).unsqueeze(1)
+    log_inv_q = ((eps[1:] ** 2).sum(-1) + log_var.sum(-1)) / 2 + K / 2 * math.log(2 * math.pi)   # (L, N)
+    li = log_iws.unsqueeze(1) + log_p_z_y + log_inv_q.unsqueeze(1)
+    rem = li.max(0)[0]
+    losses['iws'] = (li - rem).exp().mean(0) + rem                                      # sic (cvae.py:868)
+    with torch.no_grad():
+        mse = wmse * sigma_ ** 2
+        xpow, mse_m = x.pow(2).mean().item(), mse.mean().item()
+        cd = torch.cdist(dic, dic)
+        meas = {'sigma': float(sigma_.pow(2).mean().sqrt()), 'xpow': xpow, 'mse': mse_m, 'rmse': math.sqrt(mse_m),
+                'dB': 10 * math.log10(xpow / mse_m), 'zdist': losses['zdist'].mean().item(),
+                'var_kl': losses['var_kl'].mean().item(), 'ld-norm': dic.pow(2).mean().item(),
+                'imut-zy': (math.log(C) - 1 / C * torch.exp(-cd.pow(2) / 4).sum(0).log().sum()).item(),
+                'd-mind': (cd + 2 * dic.norm(dim=1).max() * torch.eye(C)).min().item()}
+    return x_reco, logits[1:].mean(0), losses, meas
+
+
+def predict(losses, y_est, method):
+    """predict_after_evaluate, cvae.py:938-970 (methods of the cvae type)."""
+    if method == 'iws':
+        return losses['iws'].argmax(0)
+    if method == 'closest':
+        return losses['zdist'].argmin(0)
+    if method == 'esty':
+        return y_est.argmax(-1)
+    if method == 'loss':
+        return losses['total'].argmin(0)
+    raise ValueError(method)
+
+
+def ood_scores(losses, C, methods):
+    """batch_dist_measures, cvae.py:972-1085, for the cvae type's OOD methods (suffixes -2s / -a-x-y name the
+    thresholding applied later, not the score)."""
+    out = {}
+    for m_ in methods:
+        m = m_[:-3] if m_.endswith('-2s') else m_
+        m = m.split('-')[0] if '-a-' in m else m
+        if m == 'elbo':
+            v = (-losses['total']).max(0)[0]
+        elif m == 'iws':
+            mx = losses['iws'].max(0)[0]
+            v = (losses['iws'] - mx).exp().sum(0).log() + mx + math.log(C)
+        elif m in ('soft', 'softkl'):
+            v = (-losses['kl']).softmax(0).max(0)[0]
+        elif m in ('zdist', 'kl'):
+            v = (-losses[m]).max(0)[0]
+        elif m == 'mse':
+            v = -losses['cross_x']
+        else:
+            raise ValueError(m_)
+        out[m_] = v
+    return out
+
+
 # ----------------------------------------------------------------------------------------------- step
 class AdamState:
     """torch.optim.Adam(lr, betas=(.9,.999), eps=1e-8, weight_decay=L2-in-grad) + clip_grad_norm_

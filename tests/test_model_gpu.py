@@ -182,3 +182,36 @@ def test_checkpoint_roundtrip(tmp_path):
     _, _, l1, _ = net.evaluate(x, y, with_beta=True, epsilon=eps)
     _, _, l2, _ = other.evaluate(x, y, with_beta=True, epsilon=eps)
     assert abs(float(l1['total'].mean()) - float(l2['total'].mean())) < 2e-3 * float(l2['total'].mean())
+
+
+from oracle.cases import EVAL_CASES, EVAL_OOD_METHODS   # noqa: E402
+
+
+@pytest.mark.parametrize('name', list(EVAL_CASES))
+def test_eval_path_matches_reference_golden(name, golden_dir):
+    """evaluate(x) without labels in eval mode (BatchNorm on running statistics, L = test sampling):
+    all-class losses (C,N), the importance-weighted bound, predictions (bit-exact) and OOD scores."""
+    g = np.load(os.path.join(golden_dir, name + '.npz'))
+    case = get_case(name)
+    kw = case['net']
+    from cvae import ClassificationVariationalNetwork as Net
+    net = Net(**kw)
+    load_det_state(net, seed=0)
+    net.to(DEV)
+    net.eval()
+    L = int(g['L'])
+    assert net.latent_sampling == L
+    x, y, eps = det_inputs(case['N'], kw['input_shape'], kw['num_labels'], L, kw['latent_dim'])
+    x_reco, y_est, losses, meas = net.evaluate(x.to(DEV), epsilon=eps.to(DEV))
+    assert rel(x_reco, g['x_reco']) < RTOL and rel(y_est, g['y_est']) < 5e-4
+    for k in [f[5:] for f in g.files if f.startswith('loss.')]:
+        assert tuple(losses[k].shape) == g['loss.' + k].shape, k
+        assert rel(losses[k], g['loss.' + k]) < RTOL, k
+    for k in [f[8:] for f in g.files if f.startswith('measure.')]:
+        ref = float(g['measure.' + k])
+        assert abs(meas[k] - ref) <= 2e-4 * max(1.0, abs(ref)), (k, meas[k], ref)
+    for m in g['predict_methods']:
+        assert np.array_equal(net.predict_after_evaluate(y_est, losses, method=str(m)).cpu().numpy(), g['predict.' + str(m)])
+    scores = net.batch_dist_measures(y_est, losses, EVAL_OOD_METHODS)
+    for m in EVAL_OOD_METHODS:
+        assert rel(scores[m], g['ood.' + m]) < RTOL, m

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from oracle import jvae_oracle as O
-from oracle.cases import CASES, get_case
+from oracle.cases import CASES, EVAL_CASES, EVAL_OOD_METHODS, get_case
 from oracle.det_init import det_inputs
 
 RTOL = 2e-5
@@ -74,3 +74,28 @@ def test_oracle_matches_reference(name, golden_dir):
     for f in g.files:
         if f.startswith('buffer_after.'):
             _close(P[f[13:]].detach().double(), g[f], rtol=1e-5, what=f)
+
+
+@pytest.mark.parametrize('name', list(EVAL_CASES))
+def test_oracle_eval_path_matches_reference(name, golden_dir):
+    """evaluate(x) without labels in eval mode: all-class losses, iws, predictions, OOD scores."""
+    g = np.load(os.path.join(golden_dir, name + '.npz'))
+    case = get_case(name)
+    sp = O.make_spec(**case['net'])
+    P = O.init_state(sp, seed=0)
+    L = int(g['L'])
+    x, y, eps = det_inputs(case['N'], sp['input_shape'], sp['C'], L, sp['K'])
+    with torch.no_grad():
+        x_reco, y_est, losses, meas = O.evaluate_all_classes(sp, P, x, eps)
+    _close(x_reco, g['x_reco'], what='x_reco')
+    _close(y_est, g['y_est'], rtol=1e-4, what='y_est')
+    for k in [f[5:] for f in g.files if f.startswith('loss.')]:
+        assert tuple(losses[k].shape) == g['loss.' + k].shape, k
+        _close(losses[k], g['loss.' + k], what='loss.' + k)
+    for k in [f[8:] for f in g.files if f.startswith('measure.')]:
+        assert abs(meas[k] - float(g['measure.' + k])) <= 1e-4 * max(1.0, abs(float(g['measure.' + k]))), k
+    for m in g['predict_methods']:
+        assert np.array_equal(O.predict(losses, y_est, str(m)).numpy(), g['predict.' + str(m)]), m
+    scores = O.ood_scores(losses, sp['C'], EVAL_OOD_METHODS)
+    for m in EVAL_OOD_METHODS:
+        _close(scores[m], g['ood.' + m], rtol=5e-5, what='ood.' + m)
