@@ -672,11 +672,54 @@ class ClassificationVariationalNetwork(nn.Module):
                 json.dump(obj, f, default=str)
         dump(self.architecture, 'params.json')
         dump(tp, 'train_params.json')
+        dump(self.testing, 'test.json')
+        dump(self.ood_results, 'ood.json')
         dump(self.train_history, 'history.json')
         torch.save(self.state_dict(), os.path.join(dir_name, 'state.pth'))
         torch.save(self.optimizer.state_dict(), os.path.join(dir_name, 'optimizer.pth'))
         self.saved_dir = dir_name
         return dir_name
+
+    @classmethod
+    def load(cls, dir_name, build_module=True, load_state=True, load_net=True, load_test=True, strict=True,
+             device=None, **kw):
+        """Rebuild a model from a job directory written by save() of this class OR of the reference
+        (cvae.py:2677-2857): params.json + train_params.json give the constructor arguments, state.pth /
+        optimizer.pth the tensors."""
+        def read(name):
+            with open(os.path.join(dir_name, name)) as f:
+                return json.load(f)
+        arch = read('params.json')
+        tp = read('train_params.json')
+        ctor = {k: arch[k] for k in ('input_shape', 'num_labels', 'type', 'output_distribution', 'representation',
+                                     'encoder', 'batch_norm', 'dropout', 'activation', 'encoder_forced_variance',
+                                     'latent_dim', 'test_latent_sampling', 'decoder', 'upsampler', 'classifier',
+                                     'output_activation') if k in arch}
+        ctor['features'] = arch.get('features')
+        prior = dict(arch.get('prior', {}))
+        for drop in ('dim', 'num_priors'):
+            prior.pop(drop, None)
+        ctor['prior'] = prior
+        sig = {k: v for k, v in dict(tp.get('sigma', {'value': 1})).items()
+               if k in ('value', 'learned', 'is_rmse', 'sdim', 'input_dim', 'reach', 'decay', 'max_step', 'sigma0', 'is_log')}
+        if sig.get('learned'):          # `value` in the json is the CURRENT rms; the state_dict restores the tensor anyway
+            sig['value'] = sig.get('sigma0') or sig.get('value')
+        if not sig.get('reach'):
+            sig.pop('reach', None)
+        ctor['sigma'] = sig
+        ctor['beta'] = tp.get('beta', 1.)
+        ctor['gamma'] = tp.get('gamma') or 0.
+        ctor['latent_sampling'] = tp.get('latent_sampling', 1)
+        ctor['optimizer'] = dict(tp.get('optimizer', {}))
+        net = cls(**ctor)
+        net.training_parameters.update({k: v for k, v in tp.items() if k not in ('sigma', 'optimizer')})
+        net.saved_dir = dir_name
+        if device is not None:
+            net.to(device)
+        if load_state and os.path.exists(os.path.join(dir_name, 'state.pth')):
+            net.load_weights(dir_name, strict=strict)
+            net.trained = max(net.trained, int(tp.get('epochs', 0)) or 1)
+        return net
 
     def load_weights(self, dir_name, strict=True, with_optimizer=True):
         """Load state.pth (+ optimizer.pth) written by save() of this class or of the reference."""

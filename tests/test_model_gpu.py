@@ -215,3 +215,37 @@ def test_eval_path_matches_reference_golden(name, golden_dir):
     scores = net.batch_dist_measures(y_est, losses, EVAL_OOD_METHODS)
     for m in EVAL_OOD_METHODS:
         assert rel(scores[m], g['ood.' + m]) < RTOL, m
+
+
+def test_reference_checkpoint_interop(tmp_path, golden_dir):
+    """a job directory written by the REFERENCE's save() (tests/golden/ckpt_ref, produced by
+    oracle/gen_ckpt_fixture.py) loads into the drop-in model; the next optimiser step reproduces the reference's own
+    next step (Adam moments, step count, lr restored); our save() writes the same files / keys / shapes back."""
+    import json
+    from cvae import ClassificationVariationalNetwork as Net
+    src = os.path.join(golden_dir, 'ckpt_ref')
+    g = np.load(os.path.join(src, 'next_step.npz'))
+    net = Net.load(src, device=DEV)
+    net.train()
+    ref_state = torch.load(os.path.join(src, 'state.pth'), map_location='cpu')
+    assert list(net.state_dict().keys()) == list(ref_state.keys())
+    for k, v in net.state_dict().items():
+        assert torch.equal(v.cpu(), ref_state[k]), k
+    x, y, eps = det_inputs(5, (1, 8, 8), 4, 1, 6, seed=4321)
+    losses, _ = net.train_step(x.to(DEV), y.to(DEV), epsilon=eps.to(DEV))
+    for k in [f[5:] for f in g.files if f.startswith('loss.')]:
+        assert rel(losses[k], g['loss.' + k]) < RTOL, k
+    for n_, p in net.named_parameters():
+        assert rel(p, g['param_after.' + n_], floor=1e-6) < 2e-5, n_     # second Adam step: moments came from the file
+    net.save(str(tmp_path))
+    for f in ('params.json', 'train_params.json', 'test.json', 'ood.json', 'history.json', 'state.pth', 'optimizer.pth'):
+        assert os.path.exists(os.path.join(tmp_path, f)), f
+    mine, theirs = json.load(open(os.path.join(tmp_path, 'params.json'))), json.load(open(os.path.join(src, 'params.json')))
+    assert mine == theirs
+    o_m = torch.load(os.path.join(tmp_path, 'optimizer.pth'), map_location='cpu')
+    o_r = torch.load(os.path.join(src, 'optimizer.pth'), map_location='cpu')
+    assert sorted(o_m['state'].keys()) == sorted(o_r['state'].keys())
+    for i in o_r['state']:
+        assert o_m['state'][i]['exp_avg'].shape == o_r['state'][i]['exp_avg'].shape
+        assert float(o_m['state'][i]['step']) == float(o_r['state'][i]['step']) + 1
+    assert set(o_r['param_groups'][0]) <= set(o_m['param_groups'][0])
