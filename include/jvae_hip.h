@@ -161,6 +161,13 @@ int jvae_adam_step_f32(float* p, const float* g, float* m, float* v, long n,
                        float lr, float beta1, float beta2, float eps, float weight_decay, long step,
                        float max_norm, const float* sqnorm, int* nonfinite_flag, void* stream);
 
+/* ---- input pipeline in front of the path: uint8 batch (NHWC if nhwc else NCHW) -> horizontal flip
+ * where flip[n] != 0 -> edge padding by `pad` + crop at offsets (dy[n], dx[n]) in [0, 2*pad] -> float32 NCHW / 255.
+ * Replaces RandomHorizontalFlip + RandomCrop(padding_mode='edge') + ToTensor of utils/torch_load.py:405-426.
+ * flip / dy / dx may be NULL (no flip / centred crop).  dy, dx: int32 on the device. */
+int jvae_augment_u8_f32(const unsigned char* in, const unsigned char* flip, const int* dy, const int* dx,
+                        float* out, int N, int C, int H, int W, int pad, int nhwc, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -42,6 +42,7 @@ _SIGS = {
     'jvae_measures_f32': (c_int, [P, c_long, P, P, P, c_int, c_int, P, c_int, P, c_int, c_int, P, P, c_int, P, P]),
     'jvae_xent_fwd_f32': (c_int, [P, P, P, c_int, c_int, c_int, P]),
     'jvae_xent_bwd_f32': (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
+    'jvae_augment_u8_f32': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     'jvae_sqnorm_accum_f32': (c_int, [P, c_long, P, c_int, P]),
     'jvae_clip_scale_f32': (c_int, [P, c_long, P, c_float, P]),
     'jvae_adam_step_f32': (c_int, [P, P, P, P, c_long] + [c_float] * 5 + [c_long, c_float, P, P, P]),

@@ -561,3 +561,33 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, max_norm=0.
     rc = L.load().jvae_adam_step_f32(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), p.numel(), lr, beta1, beta2, eps,
                                      weight_decay, step, float(max_norm or 0.), L.ptr(sqnorm), L.ptr(flag), L.stream_ptr())
     L.check(rc, 'jvae_adam_step_f32')
+
+
+# ------------------------------------------------------------------------------------------- input pipeline
+def augment_batch(images_u8, flip=None, dy=None, dx=None, pad=0, nhwc=True):
+    """uint8 batch (N,H,W,C) [or (N,C,H,W) with nhwc=False] -> float32 (N,C,H,W) in [0,1] with the reference's training
+    augmentation (utils/torch_load.py:405-426): horizontal flip where flip[n], then edge padding by `pad` and a crop at
+    (dy[n], dx[n]) in [0, 2*pad].  flip: uint8/bool (N,), dy/dx: int32 (N,), all on the device (None = identity)."""
+    if images_u8.dtype != torch.uint8:
+        raise L.JvaeHipError('augment_batch expects a uint8 batch')
+    images_u8 = _c(images_u8)
+    if nhwc:
+        N, H, W, C = images_u8.shape
+    else:
+        N, C, H, W = images_u8.shape
+    out = torch.empty((N, C, H, W), device=images_u8.device, dtype=torch.float32)
+    f = None if flip is None else _c(flip.to(torch.uint8))
+    a = None if dy is None else _c(dy.to(torch.int32))
+    b = None if dx is None else _c(dx.to(torch.int32))
+    rc = L.load().jvae_augment_u8_f32(L.ptr(images_u8), L.ptr(f), L.ptr(a), L.ptr(b), L.ptr(out), N, C, H, W, int(pad),
+                                      int(nhwc), L.stream_ptr())
+    L.check(rc, 'jvae_augment_u8_f32')
+    return out
+
+
+def draw_augmentation(N, pad, device, generator=None, flip=True, crop=True):
+    """Random decisions of RandomHorizontalFlip(p=0.5) / RandomCrop(padding=pad) for N images, on the device."""
+    f = (torch.rand(N, device=device, generator=generator) < 0.5) if flip else None
+    dy = torch.randint(0, 2 * pad + 1, (N,), device=device, generator=generator, dtype=torch.int32) if crop else None
+    dx = torch.randint(0, 2 * pad + 1, (N,), device=device, generator=generator, dtype=torch.int32) if crop else None
+    return f, dy, dx

@@ -247,3 +247,27 @@ def test_clip_and_adam_against_torch():
     gd = torch.full((n,), float('nan'), device=DEV)
     ops.adam_step(pd, gd, m, v, 1e-3, 0.9, 0.999, 1e-8, 3e-5, 4, flag=flag)
     assert int(flag) == 1
+
+
+@pytest.mark.parametrize('N,H,C,pad', [(64, 32, 3, 4), (7, 28, 1, 3), (5, 64, 3, 8)])
+def test_input_pipeline_bit_exact(N, H, C, pad):
+    """flip + edge-pad crop + /255 on the device equals the numpy restatement of the reference's
+    torchvision transform chain bit for bit (byte / index work)."""
+    import numpy as np
+    from jvae_hip import ops
+    from oracle.augment_oracle import augment
+    rng = np.random.default_rng(N * 100 + H)
+    imgs = rng.integers(0, 256, size=(N, H, H, C), dtype=np.uint8)
+    flip = rng.integers(0, 2, size=N).astype(bool)
+    dy = rng.integers(0, 2 * pad + 1, size=N).astype(np.int32)
+    dx = rng.integers(0, 2 * pad + 1, size=N).astype(np.int32)
+    dy[0], dx[0], dy[-1], dx[-1] = 0, 0, 2 * pad, 2 * pad            # the extreme crops (pure edge replication)
+    ref = augment(imgs, flip, dy, dx, pad)
+    out = ops.augment_batch(torch.from_numpy(imgs).to(DEV), torch.from_numpy(flip).to(DEV), torch.from_numpy(dy).to(DEV),
+                            torch.from_numpy(dx).to(DEV), pad=pad)
+    assert out.shape == (N, C, H, H) and out.dtype == torch.float32
+    assert np.array_equal(out.cpu().numpy(), ref)
+    ident = ops.augment_batch(torch.from_numpy(imgs).to(DEV))
+    assert np.array_equal(ident.cpu().numpy(), imgs.transpose(0, 3, 1, 2).astype(np.float32) / np.float32(255))
+    f, a, b = ops.draw_augmentation(N, pad, torch.device(DEV))
+    assert f.shape == (N,) and int(a.max()) <= 2 * pad and int(b.min()) >= 0
