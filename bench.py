@@ -28,11 +28,22 @@ MFMA_F32_PEAK = 157.3e12          # MI355X dense fp32 MFMA, MI355X_MICROARCH.md
 BATCH_PER_GPU = 512
 
 
-def build_model(device):
+WORKLOADS = {   # id -> (description, FLOP per image fwd+bwd)   (BASELINE.json configs; the metric is quoted on 2)
+    2: ('BASELINE configs[1]: CIFAR-10 3x32x32 conv CVAE (conv32/deconv32, latent_dim=64, C=10, batch_norm=both, '
+        'learned sigma, L=1), bs=512 per GPU, fp32, fwd+bwd+clip+Adam', 923.2e6),
+    3: ('BASELINE configs[2]: CIFAR-100 3x32x32 conv CVAE, class-conditional gaussian prior C=100, bs=512 per GPU, fp32',
+        923.2e6),
+    5: ('BASELINE configs[4] geometry in fp32 (no bf16 path yet): 3x64x64 conv32+/deconv32+, latent_dim=200, C=20, '
+        'bs=256 per GPU', 5105e6),
+}
+
+
+def build_model(device, workload=2):
     from cvae import ClassificationVariationalNetwork as Net
-    from oracle.cases import full_config       # constructor kwargs only (data, not the oracle's arithmetic)
+    from oracle.cases import full_config, get_case       # constructor kwargs only (data, not the oracle's arithmetic)
     torch.manual_seed(0)
-    net = Net(**full_config(2, BATCH_PER_GPU)['net'])
+    kw = get_case('c5_n4')['net'] if workload == 5 else full_config(workload, BATCH_PER_GPU)['net']
+    net = Net(**kw)
     net.to(device)
     net.train()
     return net
@@ -103,9 +114,13 @@ def main():
     ap.add_argument('--steps', type=int, default=30)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--batch', type=int, default=BATCH_PER_GPU, help='diagnostics only: per-GPU batch (the metric is defined at 512)')
+    ap.add_argument('--batch', type=int, default=None, help='diagnostics only: per-GPU batch (the metric is defined at 512)')
+    ap.add_argument('--workload', type=int, default=2, choices=sorted(WORKLOADS), help='diagnostics: other BASELINE configs')
     a = ap.parse_args()
     fh = _watchdog(900)
+    if a.batch is None:
+        a.batch = 256 if a.workload == 5 else BATCH_PER_GPU
+    side, ncls = (64, 20) if a.workload == 5 else (32, 100 if a.workload == 3 else 10)
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -125,12 +140,12 @@ def main():
     device = torch.device('cuda', local)
     torch.cuda.set_device(device)
 
-    net = build_model(device)
+    net = build_model(device, a.workload)
     if world > 1:
         net.optimizer.set_distributed(world)
     g = torch.Generator(device=device).manual_seed(1234 + rank)
-    x = torch.rand(a.batch, 3, 32, 32, device=device, generator=g)
-    y = torch.randint(0, 10, (a.batch,), device=device, generator=g)
+    x = torch.rand(a.batch, 3, side, side, device=device, generator=g)
+    y = torch.randint(0, ncls, (a.batch,), device=device, generator=g)
 
     def sync():
         torch.cuda.synchronize()
@@ -157,12 +172,10 @@ def main():
         out = {'metric': 'training_images_per_sec', 'value': value, 'unit': 'images/s', 'n_gpus': world,
                'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': dt / a.steps * 1e3, 'higher_is_better': True,
                'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-               'config': {'workload': 'BASELINE configs[1]: CIFAR-10 3x32x32 conv CVAE (conv32/deconv32, latent_dim=64, '
-                                      'C=10, batch_norm=both, learned sigma, L=1), bs=512 per GPU, fp32, '
-                                      'fwd+bwd+clip+Adam',
-                          'global_batch': world * BATCH_PER_GPU, 'parallelism': f'dp{world}',
+               'config': {'workload': WORKLOADS[a.workload][0],
+                          'global_batch': world * a.batch, 'parallelism': f'dp{world}',
                           'bn_statistics': 'per-rank (local)'},
-               'step_mfma_frac': value / world * FLOP_PER_IMAGE / MFMA_F32_PEAK,
+               'step_mfma_frac': value / world * WORKLOADS[a.workload][1] / MFMA_F32_PEAK,
                'final_loss': float(losses['total'].detach().mean())}
         out['roofline'] = dominant_kernel_roofline(device)
         if world == 1 and not a.no_cpu_baseline:

@@ -235,19 +235,32 @@ __global__ __launch_bounds__(256) void latent_bwd_kernel(LatentP p, const float*
 }
 
 // dict[0..K) = mean over classes of the dictionary rows; dict[K] = mean_c |m_c|^2 - |mean|^2   (cvae.py:747-752)
-__global__ void dict_stats_kernel(const float* __restrict__ means, float* __restrict__ dict, int C, int K) {
+// One block; the C rows are split over blockDim/K (at least 1) thread groups per latent dimension.
+__global__ __launch_bounds__(1024) void dict_stats_kernel(const float* __restrict__ means, float* __restrict__ dict, int C, int K) {
     __shared__ float red[17];
+    __shared__ float part[1024];
+    const int tid = threadIdx.x;
+    const int groups = max(1, (int)blockDim.x / K);          // row groups
     float sq = 0.f, msq = 0.f;
-    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    for (int k0 = 0; k0 < K; k0 += blockDim.x / groups) {
+        const int k = k0 + tid % (blockDim.x / groups), grp = tid / (blockDim.x / groups);
         float s = 0.f;
-        for (int c = 0; c < C; ++c) { const float v = means[(long)c * K + k]; s += v; sq += v * v; }
-        s /= C;
-        dict[k] = s;
-        msq += s * s;
+        if (k < K && grp < groups)
+            for (int c = grp; c < C; c += groups) { const float v = means[(long)c * K + k]; s += v; sq += v * v; }
+        part[tid] = s;
+        __syncthreads();
+        if (grp == 0 && k < K) {
+            float t = 0.f;
+            for (int g2 = 0; g2 < groups; ++g2) t += part[g2 * (blockDim.x / groups) + tid % (blockDim.x / groups)];
+            t /= C;
+            dict[k] = t;
+            msq += t * t;
+        }
+        __syncthreads();
     }
     sq = block_sum(sq, red);
     msq = block_sum(msq, red);
-    if (threadIdx.x == 0) dict[K] = sq / C - msq;
+    if (tid == 0) dict[K] = sq / C - msq;
 }
 
 // forward-only helper for the uniform prior's backward: terms[n] = (sum elogq + sum nel, vk)
@@ -296,7 +309,7 @@ extern "C" {
 
 int jvae_dict_stats_f32(const float* means, float* dict, int C, int K, void* stream) {
     if (!means || !dict || C <= 0 || K <= 0) return JVAE_EINVAL;
-    hipLaunchKernelGGL(dict_stats_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, means, dict, C, K);
+    hipLaunchKernelGGL(dict_stats_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, means, dict, C, K);
     JVAE_LAUNCH_CHECK();
     return 0;
 }

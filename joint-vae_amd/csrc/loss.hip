@@ -188,19 +188,27 @@ __global__ __launch_bounds__(256) void measures_kernel(const float* __restrict__
     }
     float cap = 0.f, dmin = INFINITY;
     if (means) {
-        // all C*C pairs spread over the block; per-row sums of exp(-d^2/4) accumulate in LDS (C <= 1024 rows)
+        // all C*C pairs spread over the block; per-row sums of exp(-d^2/4) accumulate in LDS (C <= 1024 rows).
+        // The dictionary itself is staged in LDS when it fits (C*K <= 12288 floats), with an odd row pitch.
         __shared__ float rowsum[1024];
+        __shared__ float dict_lds[12288 + 1024];
+        const int KP = K | 1;
+        const bool in_lds = (long)C * KP <= 12288 + 1024;
         for (int r = tid; r < C; r += blockDim.x) rowsum[r] = 0.f;
+        if (in_lds)
+            for (int i = tid; i < C * K; i += blockDim.x) dict_lds[(i / K) * KP + (i % K)] = means[i];
         __syncthreads();
+        const float* mm = in_lds ? dict_lds : means;
+        const int pitch = in_lds ? KP : K;
         for (int pr = tid; pr < C * C; pr += blockDim.x) {
             const int r = pr / C, q = pr % C;
             float d2 = 0.f;
-            for (int k = 0; k < K; ++k) { const float t = means[(long)r * K + k] - means[(long)q * K + k]; d2 += t * t; }
+            for (int k = 0; k < K; ++k) { const float t = mm[r * pitch + k] - mm[q * pitch + k]; d2 += t * t; }
             atomicAdd(&rowsum[r], __expf(-d2 / 4.f));
             if (q != r) dmin = fminf(dmin, sqrtf(d2));
             if (q == r) {                                    // row norm once per row
                 float nr = 0.f;
-                for (int k = 0; k < K; ++k) nr += means[(long)r * K + k] * means[(long)r * K + k];
+                for (int k = 0; k < K; ++k) nr += mm[r * pitch + k] * mm[r * pitch + k];
                 mx = fmaxf(mx, sqrtf(nr));
             }
         }

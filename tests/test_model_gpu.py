@@ -165,7 +165,8 @@ def test_checkpoint_roundtrip(tmp_path):
     x, y, eps = x.to(DEV), y.to(DEV), eps.to(DEV)
     net.train_step(x, y, epsilon=eps)
     net.save(str(tmp_path))
-    assert sorted(os.listdir(tmp_path)) == ['history.json', 'optimizer.pth', 'params.json', 'state.pth', 'train_params.json']
+    assert sorted(os.listdir(tmp_path)) == ['history.json', 'ood.json', 'optimizer.pth', 'params.json', 'state.pth',
+                                            'test.json', 'train_params.json']      # the reference's job-directory files
     other = build(case)
     other.load_weights(str(tmp_path))
     for (n1, p1), (n2, p2) in zip(net.named_parameters(), other.named_parameters()):
