@@ -77,7 +77,18 @@ EVAL_CASES = {
 EVAL_OOD_METHODS = ['iws', 'mse', 'elbo', 'soft', 'zdist', 'iws-2s', 'elbo-a-4-1']
 
 
+# WIM fine-tuning step (ft/wim.py:215-255, ft/job.py:380-399): one batch evaluated under the original
+# class-conditional prior, a second ("mixture") batch under an alternate, non-conditional prior N(mean_shift, I), one
+# backward on  total_in.mean() + alpha * total_mix.mean(),  then optimizer.step() BEFORE optimizer.clip() (sic).
+WIM_CASES = {
+    'w2_n8': dict(net=_conv(10), N=8, alpha=0.1,
+                  alternate_prior=dict(distribution='gaussian', init_mean=0., mean_shift=1.5, var_dim='scalar')),
+}
+
+
 def get_case(name):
+    if name in WIM_CASES:
+        return copy.deepcopy(WIM_CASES[name])
     return copy.deepcopy(CASES[name] if name in CASES else EVAL_CASES[name])
 
 

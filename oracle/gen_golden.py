@@ -27,7 +27,7 @@ REPO = os.path.dirname(HERE)
 REF = '/root/reference'
 sys.path.insert(0, REPO)
 
-from oracle.cases import CASES, EVAL_CASES, EVAL_OOD_METHODS, get_case            # noqa: E402
+from oracle.cases import CASES, EVAL_CASES, EVAL_OOD_METHODS, WIM_CASES, get_case            # noqa: E402
 from oracle.det_init import load_det_state, det_inputs  # noqa: E402
 
 FULL_GRAD_MAX = 8192      # parameters up to this many elements get their full gradient stored
@@ -186,12 +186,72 @@ def run_eval_case(Net, name):
     print(f'{name}: L={L} iws[0,:3]={out["loss.iws"][0, :3]} -> {path} ({os.path.getsize(path) / 1024:.0f} KiB)')
 
 
+def run_wim_case(Net, name):
+    """The WIM fine-tuning step with the reference's model class and prior factory, written out as ft/wim.py:215-255
+    + ft/job.py:380-399 do it (the WIMJob class itself needs the job / dataset machinery of ft/)."""
+    from module.priors import build_prior
+    case = get_case(name)
+    kw = case['net']
+    N, K = case['N'], kw['latent_dim']
+    torch.manual_seed(0)
+    net = Net(**kw)
+    load_det_state(net, seed=0)
+    original = net.encoder.prior
+    alternate = build_prior(dim=K, num_priors=1, **case['alternate_prior'])
+    for p in alternate.parameters():
+        p.requires_grad_(False)
+    x_in, y_in, eps_in = det_inputs(N, kw['input_shape'], kw['num_labels'], 1, K, seed=1234)
+    x_mix, _, eps_mix = det_inputs(N, kw['input_shape'], kw['num_labels'], 1, K, seed=777)
+    y_mix = torch.zeros(N, dtype=int)
+    out = {}
+    net.optimizer.zero_grad()
+    net.train()
+    with inject_eps(eps_in):
+        _, _, in_loss, _ = net.evaluate(x_in, y_in, batch=0, with_beta=True)
+    L = in_loss['total'].mean()
+    net.encoder.prior = alternate
+    net.num_labels = 1
+    net.train()
+    with inject_eps(eps_mix):
+        _, _, mix_loss, mix_meas = net.evaluate(x_mix, y_mix, batch=0, with_beta=True)
+    L = L + case['alpha'] * mix_loss['total'].mean()
+    net.encoder.prior = original
+    net.num_labels = kw['num_labels']
+    out['L'] = np.float64(L.item())
+    for k, v in in_loss.items():
+        out['in.' + k] = v.detach().numpy()
+    for k, v in mix_loss.items():
+        out['mix.' + k] = v.detach().numpy()
+    for k, v in mix_meas.items():
+        out['mixmeasure.' + k] = np.float64(v)
+    L.backward()
+    names = []
+    for n_, p in net.named_parameters():
+        if p.grad is not None:
+            names.append(n_)
+            out['gnorm.' + n_] = np.float64(p.grad.double().norm().item())
+    out['grad_names'] = np.array(names)
+    out['total_grad_norm'] = np.float64(torch.sqrt(sum(p.grad.double().pow(2).sum() for p in net.parameters()
+                                                       if p.grad is not None)).item())
+    net.optimizer.step()
+    net.optimizer.clip(net.parameters())
+    for n_, p in net.named_parameters():
+        out['pnorm_after.' + n_] = np.float64(p.detach().double().norm().item())
+    for n_, b in net.named_buffers():
+        out['buffer_after.' + n_] = b.detach().numpy().copy()
+    path = os.path.join(REPO, 'tests', 'golden', name + '.npz')
+    np.savez_compressed(path, **out)
+    print(f'{name}: L={out["L"]:.5f} mix kl={out["mix.kl"].mean():.4f} -> {path} ({os.path.getsize(path) / 1024:.0f} KiB)')
+
+
 def main():
-    names = sys.argv[1:] or (list(CASES) + list(EVAL_CASES))
+    names = sys.argv[1:] or (list(CASES) + list(EVAL_CASES) + list(WIM_CASES))
     Net = import_reference()
     torch.set_num_threads(8)
     for n in names:
-        if n in EVAL_CASES:
+        if n in WIM_CASES:
+            run_wim_case(Net, n)
+        elif n in EVAL_CASES:
             run_eval_case(Net, n)
         else:
             run_case(Net, n)

@@ -319,8 +319,10 @@ def prior_kl(sp, P, mu, log_var, y, w):
     return dict(distance=distance, var_kl=var_kl, kl=0.5 * (distance + w * var_kl))
 
 
-def evaluate(sp, P, x, y, eps, kl_var_weighting=1.0, gamma_weighting=1.0, with_beta=True, training=True):
-    """Training-branch evaluate (cvae.py:523-917) -> (x_reco, y_est, losses, measures, mu, log_var, z)."""
+def evaluate(sp, P, x, y, eps, kl_var_weighting=1.0, gamma_weighting=1.0, with_beta=True, training=True, alt_prior=None):
+    """Training-branch evaluate (cvae.py:523-917) -> (x_reco, y_est, losses, measures, mu, log_var, z).
+    alt_prior: {'mean': (1,K), 'T': (1,)} = a NON-conditional prior swapped in for this call (WIM, ft/wim.py:54-70):
+    no dictionary terms (dzdist, ld-norm, imut-zy, d-mind), cvae.py:701,746."""
     N = x.shape[0]
     K, L = sp['K'], sp['L']
     D = int(np.prod(sp['input_shape']))
@@ -356,11 +358,17 @@ def evaluate(sp, P, x, y, eps, kl_var_weighting=1.0, gamma_weighting=1.0, with_b
     wmse_s = ((x_reco[1:] / sigma_ - (x / sigma_).unsqueeze(0)) ** 2).reshape(L, N, -1).mean(-1)   # losses.py:8-27
     wmse = wmse_s.mean(0)
     mse = wmse * sigma_ ** 2
-    kd = prior_kl(sp, P, mu, log_var, y, kl_var_weighting)
+    if alt_prior is not None:
+        Pa = {'encoder.prior.mean': alt_prior['mean'], 'encoder.prior._var_parameter': alt_prior['T']}
+        spa = dict(sp, prior=dict(distribution='gaussian', var_dim='scalar'))
+        kd = prior_kl(spa, Pa, mu, log_var, torch.zeros_like(y), kl_var_weighting)
+    else:
+        kd = prior_kl(sp, P, mu, log_var, y, kl_var_weighting)
     losses = dict(kl=kd['kl'], zdist=kd['distance'], var_kl=kd['var_kl'])
     dic = P['encoder.prior.mean']
-    dmean = dic.mean(0)
-    losses['dzdist'] = (mu - dmean).pow(2).sum(1) + (dic.pow(2).sum(1).mean(0) - dmean.pow(2).sum())
+    if alt_prior is None:
+        dmean = dic.mean(0)
+        losses['dzdist'] = (mu - dmean).pow(2).sum(1) + (dic.pow(2).sum(1).mean(0) - dmean.pow(2).sum())
     losses['wmse'] = wmse
     losses['cross_x'] = D * (2 * log_sigma + wmse + math.log(2 * math.pi)) / 2        # cvae.py:773-789, sdim=1
     total = losses['cross_x']
@@ -386,6 +394,9 @@ def evaluate(sp, P, x, y, eps, kl_var_weighting=1.0, gamma_weighting=1.0, with_b
                 'ld-norm': dic.pow(2).mean().item(),
                 'imut-zy': (math.log(C) - 1 / C * torch.exp(-cd.pow(2) / 4).sum(0).log().sum()).item(),
                 'd-mind': (cd + 2 * dic.norm(dim=1).max() * torch.eye(C)).min().item()}
+        if alt_prior is not None:
+            for k in ('ld-norm', 'imut-zy', 'd-mind'):
+                meas.pop(k)
     return x_reco, logits[1:].mean(0), losses, meas, mu, log_var, z
 
 
@@ -532,6 +543,24 @@ class AdamState:
                 denom = (v.sqrt() / math.sqrt(1 - b2 ** self.t)).add_(1e-8)
                 P[k].addcdiv_(m, denom, value=-self.lr / (1 - b1 ** self.t))
         return float(gn)
+
+
+def wim_step(sp, P, opt, x_in, y_in, eps_in, x_mix, eps_mix, alt_prior, alpha):
+    """WIM fine-tuning step (ft/wim.py:215-255 + ft/job.py:380-399): original prior on the in-distribution batch,
+    alternate prior on the mixture batch, L = total_in.mean() + alpha * total_mix.mean(), backward, Adam step
+    (the reference clips AFTER stepping, i.e. without effect)."""
+    for p in P.values():
+        if p.requires_grad:
+            p.grad = None
+    o_in = evaluate(sp, P, x_in, y_in, eps_in, with_beta=True, training=True)
+    o_mix = evaluate(sp, P, x_mix, torch.zeros_like(y_in), eps_mix, with_beta=True, training=True, alt_prior=alt_prior)
+    L = o_in[2]['total'].mean() + alpha * o_mix[2]['total'].mean()
+    L.backward()
+    grads = {k: p.grad for k, p in P.items() if p.requires_grad and p.grad is not None}
+    clip, opt.clip = opt.clip, None
+    gn = opt.step(P, grads)
+    opt.clip = clip
+    return o_in, o_mix, float(L.detach()), grads, gn
 
 
 def train_step(sp, P, opt, x, y, eps, kl_var_weighting=1.0, gamma_weighting=1.0):

@@ -250,3 +250,56 @@ def test_reference_checkpoint_interop(tmp_path, golden_dir):
         assert o_m['state'][i]['exp_avg'].shape == o_r['state'][i]['exp_avg'].shape
         assert float(o_m['state'][i]['step']) == float(o_r['state'][i]['step']) + 1
     assert set(o_r['param_groups'][0]) <= set(o_m['param_groups'][0])
+
+
+def test_wim_finetune_step_matches_reference_golden(golden_dir):
+    """SURVEY.md §8f-4 (ft/wim.py:215-255, ft/job.py:380-399): the WIM fine-tuning step on the drop-in model, exactly as
+    the reference's WIMJob drives its base class: swap `encoder.prior` for a non-conditional alternate prior
+    (`build_prior(num_priors=1, ...)`, `num_labels = 1`), two evaluate passes, one backward, step-then-clip."""
+    from oracle.cases import WIM_CASES
+    from module.priors import build_prior
+    name = 'w2_n8'
+    g = np.load(os.path.join(golden_dir, name + '.npz'))
+    case = get_case(name)
+    kw = case['net']
+    net = build(case)
+    N, K = case['N'], kw['latent_dim']
+    x_in, y_in, eps_in = det_inputs(N, kw['input_shape'], kw['num_labels'], 1, K, seed=1234)
+    x_mix, _, eps_mix = det_inputs(N, kw['input_shape'], kw['num_labels'], 1, K, seed=777)
+    original = net.encoder.prior
+    alternate = build_prior(dim=K, num_priors=1, **case['alternate_prior']).to(DEV)
+    for p in alternate.parameters():
+        p.requires_grad_(False)
+    net.optimizer.zero_grad()
+    _, _, in_loss, _ = net.evaluate(x_in.to(DEV), y_in.to(DEV), batch=0, with_beta=True, epsilon=eps_in.to(DEV))
+    L = in_loss['total'].mean()
+    net.encoder.prior, net.num_labels = alternate, 1
+    _, _, mix_loss, mix_meas = net.evaluate(x_mix.to(DEV), torch.zeros(N, dtype=torch.int64, device=DEV), batch=0,
+                                            with_beta=True, epsilon=eps_mix.to(DEV))
+    L = L + case['alpha'] * mix_loss['total'].mean()
+    net.encoder.prior, net.num_labels = original, kw['num_labels']
+    assert abs(float(L) - float(g['L'])) <= RTOL * abs(float(g['L']))
+    for k in [f[3:] for f in g.files if f.startswith('in.')]:
+        assert rel(in_loss[k], g['in.' + k]) < RTOL, k
+    mix_keys = [f[4:] for f in g.files if f.startswith('mix.')]
+    assert set(mix_keys) == set(mix_loss)                       # no dictionary terms under a non-conditional prior
+    for k in mix_keys:
+        assert rel(mix_loss[k], g['mix.' + k]) < RTOL, k
+    assert set(mix_meas.keys()) == {f[11:] for f in g.files if f.startswith('mixmeasure.')}
+    for k in mix_meas.keys():
+        ref = float(g['mixmeasure.' + k])
+        assert abs(mix_meas[k] - ref) <= 2e-4 * max(1.0, abs(ref)), k
+    L.backward()
+    tot = float(g['total_grad_norm'])
+    got = {n: p.grad for n, p in net.named_parameters() if p.grad is not None}
+    assert set(g['grad_names']) <= set(got)
+    for k in g['grad_names']:
+        ref = float(g['gnorm.' + k])
+        assert abs(float(got[k].double().norm()) - ref) <= 1e-2 * max(ref, 1e-3 * tot), k
+    net.optimizer.step()                                        # sic: step, THEN clip (ft/job.py:397-399)
+    net.optimizer.clip(net.parameters())
+    assert abs(float(net.optimizer.grad_norm()) - tot) <= 1e-4 * tot
+    bufs = dict(net.named_buffers())
+    for f in g.files:
+        if f.startswith('buffer_after.'):                       # BatchNorm saw two batches: running stats updated twice
+            assert rel(bufs[f[13:]].double(), g[f]) < 2e-5, f

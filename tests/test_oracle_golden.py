@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from oracle import jvae_oracle as O
-from oracle.cases import CASES, EVAL_CASES, EVAL_OOD_METHODS, get_case
+from oracle.cases import CASES, EVAL_CASES, EVAL_OOD_METHODS, WIM_CASES, get_case
 from oracle.det_init import det_inputs
 
 RTOL = 2e-5
@@ -99,3 +99,33 @@ def test_oracle_eval_path_matches_reference(name, golden_dir):
     scores = O.ood_scores(losses, sp['C'], EVAL_OOD_METHODS)
     for m in EVAL_OOD_METHODS:
         _close(scores[m], g['ood.' + m], rtol=5e-5, what='ood.' + m)
+
+
+@pytest.mark.parametrize('name', list(WIM_CASES))
+def test_oracle_wim_step_matches_reference(name, golden_dir):
+    """the WIM fine-tuning step (two evaluate passes under the original / alternate prior)."""
+    g = np.load(os.path.join(golden_dir, name + '.npz'))
+    case = get_case(name)
+    kw = case['net']
+    sp = O.make_spec(**kw)
+    P = O.init_state(sp, seed=0)
+    N, K = case['N'], kw['latent_dim']
+    x_in, y_in, eps_in = det_inputs(N, sp['input_shape'], sp['C'], 1, K, seed=1234)
+    x_mix, _, eps_mix = det_inputs(N, sp['input_shape'], sp['C'], 1, K, seed=777)
+    alt = {'mean': torch.full((1, K), float(case['alternate_prior']['mean_shift'])), 'T': torch.ones(1)}
+    o_in, o_mix, L, grads, gn = O.wim_step(sp, P, O.AdamState(sp), x_in, y_in, eps_in, x_mix, eps_mix, alt, case['alpha'])
+    assert abs(L - float(g['L'])) <= 2e-5 * abs(float(g['L']))
+    for k in [f[3:] for f in g.files if f.startswith('in.')]:
+        _close(o_in[2][k].detach(), g['in.' + k], what='in.' + k)
+    mix_keys = [f[4:] for f in g.files if f.startswith('mix.')]
+    assert 'dzdist' not in mix_keys and set(mix_keys) == set(o_mix[2])
+    for k in mix_keys:
+        _close(o_mix[2][k].detach(), g['mix.' + k], what='mix.' + k)
+    assert set(o_mix[3]) == {f[11:] for f in g.files if f.startswith('mixmeasure.')}
+    _close(gn, g['total_grad_norm'], what='grad norm')
+    for k in g['grad_names']:
+        ref = float(g['gnorm.' + k])
+        assert abs(float(grads[k].double().norm()) - ref) <= 1e-4 * max(ref, 1e-3 * float(g['total_grad_norm'])), k
+    for f in g.files:
+        if f.startswith('buffer_after.'):
+            _close(P[f[13:]].detach().double(), g[f], rtol=1e-5, what=f)
