@@ -115,6 +115,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--batch', type=int, default=None, help='diagnostics only: per-GPU batch (the metric is defined at 512)')
+    ap.add_argument('--sync-bn', action='store_true', help='BatchNorm statistics over all ranks (default: per rank)')
     ap.add_argument('--workload', type=int, default=2, choices=sorted(WORKLOADS), help='diagnostics: other BASELINE configs')
     a = ap.parse_args()
     fh = _watchdog(900)
@@ -143,6 +144,8 @@ def main():
     net = build_model(device, a.workload)
     if world > 1:
         net.optimizer.set_distributed(world)
+        if a.sync_bn:
+            net.set_sync_batchnorm(world)
     g = torch.Generator(device=device).manual_seed(1234 + rank)
     x = torch.rand(a.batch, 3, side, side, device=device, generator=g)
     y = torch.randint(0, ncls, (a.batch,), device=device, generator=g)
@@ -174,7 +177,7 @@ def main():
                'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
                'config': {'workload': WORKLOADS[a.workload][0],
                           'global_batch': world * a.batch, 'parallelism': f'dp{world}',
-                          'bn_statistics': 'per-rank (local)'},
+                          'bn_statistics': 'synchronised over ranks' if (a.sync_bn and world > 1) else 'per-rank (local)'},
                'step_mfma_frac': value / world * WORKLOADS[a.workload][1] / MFMA_F32_PEAK,
                'final_loss': float(losses['total'].detach().mean())}
         out['roofline'] = dominant_kernel_roofline(device)

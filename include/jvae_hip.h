@@ -89,6 +89,28 @@ int jvae_bn_bwd_f32(const float* dy, const float* x, const float* gamma, const f
                     float* dx, float* dgamma, float* dbeta, int accumulate,
                     int N, int C, int P, int relu, void* ws, size_t ws_bytes, void* stream);
 
+/* Synchronised BatchNorm for data-parallel ranks (no counterpart in the single-process reference, it
+ * reproduces what the reference's BatchNorm2d computes on the WHOLE global batch).  Forward: jvae_bn_sums_f32 ->
+ * all-reduce(SUM) of the (C,2) sums by the host -> jvae_bn_fwd_sync_f32.  Backward: jvae_bn_bwd_sums_f32 ->
+ * all-reduce(SUM) -> jvae_bn_bwd_sync_f32 (dx from the global means, dgamma/dbeta from the local sums).
+ * pivot: (C) floats identical on all ranks (the running mean before the update). */
+int jvae_bn_sums_f32(const float* x, const float* pivot, float* sums, int N, int C, int P,
+                     void* ws, size_t ws_bytes, void* stream);
+int jvae_bn_fwd_sync_f32(const float* x, const float* gamma, const float* beta,
+                         float* running_mean, float* running_var, long long* num_batches_tracked,
+                         float* y, float* save_mean, float* save_invstd,
+                         int N, int C, int P, float momentum, float eps, int relu,
+                         const float* global_sums, const float* pivot, int world,
+                         void* ws, size_t ws_bytes, void* stream);
+int jvae_bn_bwd_sums_f32(const float* dy, const float* x, const float* gamma, const float* beta,
+                         const float* save_mean, const float* save_invstd, float* local_sums,
+                         int N, int C, int P, int relu, void* ws, size_t ws_bytes, void* stream);
+int jvae_bn_bwd_sync_f32(const float* dy, const float* x, const float* gamma, const float* beta,
+                         const float* save_mean, const float* save_invstd,
+                         const float* local_sums, const float* global_sums, int world,
+                         float* dx, float* dgamma, float* dbeta, int accumulate,
+                         int N, int C, int P, int relu, void* stream);
+
 /* ---- activations (kind 0 identity, 1 ReLU, 2 sigmoid); backward takes the forward OUTPUT ---------- */
 int jvae_act_fwd_f32(const float* x, float* y, long n, int kind, void* stream);
 int jvae_act_bwd_f32(const float* dy, const float* y, float* dx, long n, int kind, void* stream);

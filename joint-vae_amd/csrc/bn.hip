@@ -22,10 +22,10 @@ __device__ __forceinline__ void bn_coef(float g, float b, float mean, float invs
 
 // partial[c][s] = (sum(x-p), sum((x-p)^2)) over the images of split s;  p = x[0][c][0]
 __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, float* __restrict__ partial,
-                                                       int N, int C, int P, int nsplit) {
+                                                       int N, int C, int P, int nsplit, const float* __restrict__ pv) {
     __shared__ float red[17];
     const int c = blockIdx.x, s = blockIdx.y;
-    const float pivot = x[(long)c * P];
+    const float pivot = pv ? pv[c] : x[(long)c * P];
     const int per = (N + nsplit - 1) / nsplit;
     const int nb = s * per, ne = min(N, nb + per);
     float s1 = 0.f, s2 = 0.f;
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
                                                        float* running_mean, float* running_var, long long* num_batches_tracked,
                                                        float* save_mean, float* save_invstd, float* __restrict__ y,
                                                        int N, int C, int P, int nsplit, int nchunk, float momentum, float eps,
-                                                       int training, int relu, int ext_pivot, const float* __restrict__ pivot) {
+                                                       int training, int relu, int ext_pivot, const float* __restrict__ pivot, int count_mult) {
     __shared__ float cs[2];
     __shared__ double dred[2][4];
     const int c = blockIdx.x, j = blockIdx.y;
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
         if (training) {
             s1 = dred[0][0] + dred[0][1] + dred[0][2] + dred[0][3];
             s2 = dred[1][0] + dred[1][1] + dred[1][2] + dred[1][3];
-            const double n = (double)N * P;
+            const double n = (double)N * P * count_mult;          // count_mult = ranks of a synchronised BatchNorm
             const double dm = s1 / n;
             double var = s2 / n - dm * dm;
             if (var < 0.) var = 0.;
@@ -188,7 +188,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
                                                            const float* __restrict__ partial, float* __restrict__ dx,
                                                            float* dgamma, float* dbeta, int accumulate,
-                                                           int N, int C, int P, int nsplit, int nchunk, int relu) {
+                                                           int N, int C, int P, int nsplit, int nchunk, int relu,
+                                                           const float* __restrict__ gsums, int count_mult) {
     __shared__ float ms[2];
     const int c = blockIdx.x, j = blockIdx.y;
     if (threadIdx.x == 0) {
@@ -197,9 +198,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
             s1 += (double)partial[((long)c * nsplit + s) * 2 + 0];
             s2 += (double)partial[((long)c * nsplit + s) * 2 + 1];
         }
-        const double M = (double)N * P;
-        ms[0] = (float)(s1 / M);
-        ms[1] = (float)(s2 / M);
+        const double M = (double)N * P * count_mult;
+        // synchronised BatchNorm: the means over ALL ranks come from gsums; dgamma / dbeta stay the LOCAL sums
+        ms[0] = (float)((gsums ? (double)gsums[2 * c] : s1) / M);
+        ms[1] = (float)((gsums ? (double)gsums[2 * c + 1] : s2) / M);
         if (j == 0) {
             if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s1;
             if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)s2;
@@ -243,6 +245,19 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     }
 }
 
+// sums[c] = sum over splits of partial[c][s] (fp64 accumulation, fixed order)
+__global__ void bn_fold_kernel(const float* __restrict__ partial, float* __restrict__ sums, int C, int nsplit) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0., s2 = 0.;
+    for (int s = 0; s < nsplit; ++s) {
+        s1 += (double)partial[((long)c * nsplit + s) * 2 + 0];
+        s2 += (double)partial[((long)c * nsplit + s) * 2 + 1];
+    }
+    sums[2 * c] = (float)s1;
+    sums[2 * c + 1] = (float)s2;
+}
+
 inline int pick_split(int N, int C, int P) {
     long work = (long)N * P;
     int s = (int)(work / 8192);
@@ -276,7 +291,7 @@ static int bn_fwd_impl(const float* x, const float* gamma, const float* beta,
                        float* running_mean, float* running_var, long long* num_batches_tracked,
                        float* y, float* save_mean, float* save_invstd,
                        int N, int C, int P, float momentum, float eps, int training, int relu,
-                       const float* ext_stats, int ext_nsplit, const float* ext_pivot,
+                       const float* ext_stats, int ext_nsplit, const float* ext_pivot, int count_mult,
                        void* ws, size_t ws_bytes, void* stream) {
     if (!x || !y || N < 0 || C <= 0 || P <= 0) return JVAE_EINVAL;
     if (ws_bytes < jvae_bn_workspace_bytes(C) || !ws) return JVAE_EWORKSPACE;
@@ -292,7 +307,7 @@ static int bn_fwd_impl(const float* x, const float* gamma, const float* beta,
     } else if (training) {
         if (!save_mean || !save_invstd) return JVAE_EINVAL;
         ns = pick_split(N, C, P);
-        hipLaunchKernelGGL(bn_stats_kernel, dim3(C, ns), dim3(256), 0, st, x, (float*)ws, N, C, P, ns);
+        hipLaunchKernelGGL(bn_stats_kernel, dim3(C, ns), dim3(256), 0, st, x, (float*)ws, N, C, P, ns, (const float*)nullptr);
         JVAE_LAUNCH_CHECK();
     } else if (!running_mean || !running_var) {
         return JVAE_EINVAL;
@@ -300,7 +315,7 @@ static int bn_fwd_impl(const float* x, const float* gamma, const float* beta,
     const int nc = pick_chunk(N, C, P);
     hipLaunchKernelGGL(bn_apply_kernel, dim3(C, nc), dim3(256), 0, st, x, partial, gamma, beta, running_mean, running_var,
                        num_batches_tracked, save_mean, save_invstd, y, N, C, P, ns, nc, momentum, eps, training, relu,
-                       ext ? 1 : 0, ext_pivot);
+                       ext ? 1 : 0, ext_pivot, count_mult > 0 ? count_mult : 1);
     JVAE_LAUNCH_CHECK();
     return 0;
 }
@@ -311,7 +326,7 @@ int jvae_bn_fwd_f32(const float* x, const float* gamma, const float* beta,
                     int N, int C, int P, float momentum, float eps, int training, int relu,
                     void* ws, size_t ws_bytes, void* stream) {
     return bn_fwd_impl(x, gamma, beta, running_mean, running_var, num_batches_tracked, y, save_mean, save_invstd,
-                       N, C, P, momentum, eps, training, relu, nullptr, 0, nullptr, ws, ws_bytes, stream);
+                       N, C, P, momentum, eps, training, relu, nullptr, 0, nullptr, 1, ws, ws_bytes, stream);
 }
 
 // Same, with the batch statistics supplied by the producing convolution (jvae_conv2d_fwd_stats_f32):
@@ -324,7 +339,7 @@ int jvae_bn_fwd_ext_f32(const float* x, const float* gamma, const float* beta,
                         const float* ext_stats, int ext_nsplit, const float* ext_pivot,
                         void* ws, size_t ws_bytes, void* stream) {
     return bn_fwd_impl(x, gamma, beta, running_mean, running_var, num_batches_tracked, y, save_mean, save_invstd,
-                       N, C, P, momentum, eps, training, relu, ext_stats, ext_nsplit, ext_pivot, ws, ws_bytes, stream);
+                       N, C, P, momentum, eps, training, relu, ext_stats, ext_nsplit, ext_pivot, 1, ws, ws_bytes, stream);
 }
 
 int jvae_bn_bwd_f32(const float* dy, const float* x, const float* gamma, const float* beta,
@@ -342,7 +357,79 @@ int jvae_bn_bwd_f32(const float* dy, const float* x, const float* gamma, const f
     JVAE_LAUNCH_CHECK();
     const int nc = pick_chunk(N, C, P);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(C, nc), dim3(256), 0, st, dy, x, gamma, beta, save_mean, save_invstd,
-                       partial, dx, dgamma, dbeta, accumulate, N, C, P, ns, nc, relu);
+                       partial, dx, dgamma, dbeta, accumulate, N, C, P, ns, nc, relu, (const float*)nullptr, 1);
+    JVAE_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- synchronised BatchNorm (data-parallel ranks share the batch statistics) --------------------------
+// The host all-reduces the (C,2) sums between the two calls of each direction.
+
+// sums[c] = (sum(x - pivot[c]), sum((x - pivot[c])^2)) over this rank's batch; pivot: (C) identical on every rank
+int jvae_bn_sums_f32(const float* x, const float* pivot, float* sums, int N, int C, int P,
+                     void* ws, size_t ws_bytes, void* stream) {
+    if (!x || !pivot || !sums || N < 0 || C <= 0 || P <= 0) return JVAE_EINVAL;
+    if (ws_bytes < jvae_bn_workspace_bytes(C) || !ws) return JVAE_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int ns = N > 0 ? pick_split(N, C, P) : 1;
+    if (N > 0) {
+        hipLaunchKernelGGL(bn_stats_kernel, dim3(C, ns), dim3(256), 0, st, x, (float*)ws, N, C, P, ns, pivot);
+        JVAE_LAUNCH_CHECK();
+    } else {
+        hipError_t e = hipMemsetAsync(ws, 0, sizeof(float) * 2 * (size_t)C, st);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(bn_fold_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, (const float*)ws, sums, C, ns);
+    JVAE_LAUNCH_CHECK();
+    return 0;
+}
+
+// forward apply from all-reduced sums: mean = pivot + S1/n, var = S2/n - (S1/n)^2 with n = N*P*world
+int jvae_bn_fwd_sync_f32(const float* x, const float* gamma, const float* beta,
+                         float* running_mean, float* running_var, long long* num_batches_tracked,
+                         float* y, float* save_mean, float* save_invstd,
+                         int N, int C, int P, float momentum, float eps, int relu,
+                         const float* global_sums, const float* pivot, int world,
+                         void* ws, size_t ws_bytes, void* stream) {
+    if (!global_sums || !pivot || world < 1) return JVAE_EINVAL;
+    return bn_fwd_impl(x, gamma, beta, running_mean, running_var, num_batches_tracked, y, save_mean, save_invstd,
+                       N, C, P, momentum, eps, 1, relu, global_sums, 1, pivot, world, ws, ws_bytes, stream);
+}
+
+// local_sums[c] = (sum g, sum g*xhat) of this rank (g = dy masked by the fused ReLU)
+int jvae_bn_bwd_sums_f32(const float* dy, const float* x, const float* gamma, const float* beta,
+                         const float* save_mean, const float* save_invstd, float* local_sums,
+                         int N, int C, int P, int relu, void* ws, size_t ws_bytes, void* stream) {
+    if (!dy || !x || !save_mean || !save_invstd || !local_sums || N < 0 || C <= 0 || P <= 0) return JVAE_EINVAL;
+    if (ws_bytes < jvae_bn_workspace_bytes(C) || !ws) return JVAE_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int ns = N > 0 ? pick_split(N, C, P) : 1;
+    if (N > 0) {
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C, ns), dim3(256), 0, st, dy, x, gamma, beta, save_mean, save_invstd,
+                           (float*)ws, N, C, P, ns, relu);
+        JVAE_LAUNCH_CHECK();
+    } else {
+        hipError_t e = hipMemsetAsync(ws, 0, sizeof(float) * 2 * (size_t)C, st);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(bn_fold_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, (const float*)ws, local_sums, C, ns);
+    JVAE_LAUNCH_CHECK();
+    return 0;
+}
+
+// dx from the GLOBAL means (global_sums / (N*P*world)); dgamma / dbeta (+)= the LOCAL sums (the gradient all-reduce
+// of the optimiser averages them afterwards, as DDP + SyncBatchNorm does)
+int jvae_bn_bwd_sync_f32(const float* dy, const float* x, const float* gamma, const float* beta,
+                         const float* save_mean, const float* save_invstd,
+                         const float* local_sums, const float* global_sums, int world,
+                         float* dx, float* dgamma, float* dbeta, int accumulate,
+                         int N, int C, int P, int relu, void* stream) {
+    if (!dy || !x || !save_mean || !save_invstd || !dx || !local_sums || !global_sums || world < 1) return JVAE_EINVAL;
+    if (N < 0 || C <= 0 || P <= 0) return JVAE_EINVAL;
+    if (N == 0) return 0;
+    const int nc = pick_chunk(N, C, P);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(C, nc), dim3(256), 0, (hipStream_t)stream, dy, x, gamma, beta, save_mean,
+                       save_invstd, local_sums, dx, dgamma, dbeta, accumulate, N, C, P, 1, nc, relu, global_sums, world);
     JVAE_LAUNCH_CHECK();
     return 0;
 }

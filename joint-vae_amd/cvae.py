@@ -351,6 +351,15 @@ class ClassificationVariationalNetwork(nn.Module):
     def nparams(self):
         return sum(p.nelement() for p in self.parameters())
 
+    def set_sync_batchnorm(self, world_size, process_group=None):
+        """Data-parallel option: BatchNorm statistics over ALL ranks, i.e. exactly what the single-process
+        reference computes on the global batch (default: per-rank statistics, as DistributedDataParallel does)."""
+        from module.vae_layers.conv import HipBatchNorm2d
+        for m in self.modules():
+            if isinstance(m, HipBatchNorm2d):
+                m.sync_world, m.sync_group = int(world_size), process_group
+        return self
+
     @property
     def max_batch_sizes(self):
         """The reference hard-wires {'train': 32, 'test': 32} (cvae.py:1145-1147); with 288 GB of

@@ -29,6 +29,10 @@ _SIGS = {
     'jvae_bn_workspace_bytes': (c_size_t, [c_int]),
     'jvae_bn_fwd_f32': (c_int, [P] * 9 + [c_int, c_int, c_int, c_float, c_float, c_int, c_int, P, c_size_t, P]),
     'jvae_bn_fwd_ext_f32': (c_int, [P] * 9 + [c_int, c_int, c_int, c_float, c_float, c_int, c_int, P, c_int, P, P, c_size_t, P]),
+    'jvae_bn_sums_f32': (c_int, [P, P, P, c_int, c_int, c_int, P, c_size_t, P]),
+    'jvae_bn_fwd_sync_f32': (c_int, [P] * 9 + [c_int, c_int, c_int, c_float, c_float, c_int, P, P, c_int, P, c_size_t, P]),
+    'jvae_bn_bwd_sums_f32': (c_int, [P] * 7 + [c_int, c_int, c_int, c_int, P, c_size_t, P]),
+    'jvae_bn_bwd_sync_f32': (c_int, [P] * 8 + [c_int, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     'jvae_bn_bwd_f32': (c_int, [P] * 9 + [c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),
     'jvae_act_fwd_f32': (c_int, [P, P, c_long, c_int, P]),
     'jvae_act_bwd_f32': (c_int, [P, P, P, c_long, c_int, P]),

@@ -321,6 +321,68 @@ def batchnorm_act(x, gamma, beta, running_mean, running_var, num_batches_tracked
                                momentum, eps, ext)
 
 
+class _SyncBatchNormAct(torch.autograd.Function):
+    """Train-mode BatchNorm2d (+ReLU) whose statistics span all data-parallel ranks (what the single-process reference
+    computes on the whole global batch): two (C,2) all-reduces per layer, one in forward, one in backward."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, rm, rv, nbt, relu, momentum, eps, world, group):
+        import torch.distributed as dist
+        x = _c(_f32(x, 'sync batchnorm'))
+        N, C = x.shape[0], x.shape[1]
+        P = x.numel() // max(N * C, 1)
+        lib = L.load()
+        ws = L.workspace(lib.jvae_bn_workspace_bytes(C), x.device)
+        pivot = rm.detach().clone()                       # identical on every rank; rm itself is updated by the kernel
+        sums = torch.empty((C, 2), device=x.device, dtype=torch.float32)
+        L.check(lib.jvae_bn_sums_f32(L.ptr(x), L.ptr(pivot), L.ptr(sums), N, C, P, L.ptr(ws), ws.numel(), L.stream_ptr()),
+                'jvae_bn_sums_f32')
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+        y = torch.empty_like(x)
+        mean = torch.empty(C, device=x.device, dtype=torch.float32)
+        invstd = torch.empty(C, device=x.device, dtype=torch.float32)
+        rc = lib.jvae_bn_fwd_sync_f32(L.ptr(x), L.ptr(gamma), L.ptr(beta), L.ptr(rm), L.ptr(rv), L.ptr(nbt), L.ptr(y),
+                                      L.ptr(mean), L.ptr(invstd), N, C, P, momentum, eps, int(relu), L.ptr(sums),
+                                      L.ptr(pivot), int(world), L.ptr(ws), ws.numel(), L.stream_ptr())
+        L.check(rc, 'jvae_bn_fwd_sync_f32')
+        ctx.save_for_backward(x, gamma, beta, mean, invstd)
+        ctx.cfg = (N, C, P, relu, int(world), group)
+        ctx.g_ref, ctx.b_ref = gamma, beta
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        import torch.distributed as dist
+        x, gamma, beta, mean, invstd = ctx.saved_tensors
+        N, C, P, relu, world, group = ctx.cfg
+        gy = _c(gy)
+        lib = L.load()
+        ws = L.workspace(lib.jvae_bn_workspace_bytes(C), x.device)
+        local = torch.empty((C, 2), device=x.device, dtype=torch.float32)
+        rc = lib.jvae_bn_bwd_sums_f32(L.ptr(gy), L.ptr(x), L.ptr(gamma), L.ptr(beta), L.ptr(mean), L.ptr(invstd),
+                                      L.ptr(local), N, C, P, int(relu), L.ptr(ws), ws.numel(), L.stream_ptr())
+        L.check(rc, 'jvae_bn_bwd_sums_f32')
+        glob = local.clone()
+        dist.all_reduce(glob, op=dist.ReduceOp.SUM, group=group)
+        gx = torch.empty_like(x)
+        sg, sb = _grad_slot(ctx.g_ref), _grad_slot(ctx.b_ref)
+        inplace = sg is not None and sb is not None
+        gg = sg if inplace else torch.empty(C, device=x.device, dtype=torch.float32)
+        gb = sb if inplace else torch.empty(C, device=x.device, dtype=torch.float32)
+        rc = lib.jvae_bn_bwd_sync_f32(L.ptr(gy), L.ptr(x), L.ptr(gamma), L.ptr(beta), L.ptr(mean), L.ptr(invstd),
+                                      L.ptr(local), L.ptr(glob), world, L.ptr(gx), L.ptr(gg), L.ptr(gb), int(inplace),
+                                      N, C, P, int(relu), L.stream_ptr())
+        L.check(rc, 'jvae_bn_bwd_sync_f32')
+        if inplace:
+            gg = gb = None
+        return gx, gg, gb, None, None, None, None, None, None, None, None
+
+
+def sync_batchnorm_act(x, gamma, beta, running_mean, running_var, num_batches_tracked, relu, momentum, eps, world, group=None):
+    return _SyncBatchNormAct.apply(x, gamma, beta, running_mean, running_var, num_batches_tracked, relu, momentum, eps,
+                                   world, group)
+
+
 class _Act(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, kind):

@@ -109,7 +109,14 @@ class HipConvTranspose2d(nn.ConvTranspose2d):
 class HipBatchNorm2d(nn.BatchNorm2d):
     """nn.BatchNorm2d state; forward = batch-statistics kernel (+ the following ReLU when fused by the stack)."""
 
+    sync_world = 1          # > 1: statistics over all data-parallel ranks (ClassificationVariationalNetwork.set_sync_batchnorm)
+    sync_group = None
+
     def forward(self, x, relu=False, ext=None):
+        if self.training and self.sync_world > 1:
+            return ops.sync_batchnorm_act(x, self.weight, self.bias, self.running_mean, self.running_var,
+                                          self.num_batches_tracked, relu, self.momentum, self.eps, self.sync_world,
+                                          self.sync_group)
         return ops.batchnorm_act(x, self.weight, self.bias, self.running_mean, self.running_var,
                                  self.num_batches_tracked, self.training, relu, self.momentum, self.eps, ext)
 
@@ -132,7 +139,7 @@ class HipConvStack(nn.Sequential):
                 continue
             if isinstance(m, (HipConv2d, HipConvTranspose2d)) and i + 1 < len(mods) \
                     and isinstance(mods[i + 1], HipBatchNorm2d) and mods[i + 1].training:
-                ext = {}
+                ext = {} if mods[i + 1].sync_world <= 1 else None      # synchronised BN reduces its own sums
                 # BatchNorm removes the channel mean: d(loss)/d(bias) == 0 exactly
                 x = m(x, dead_bias=True, stats_out=ext)
             else:
