@@ -1,8 +1,8 @@
 """Small stand-ins for the reference's `utils.*` helpers that the hot-path modules import.
 
-In *overlay* mode (our cvae.py + module/ copied over a reference checkout) the reference's own `utils`
-package is importable and is used; in *standalone* mode (this repository alone, e.g. on the GPU box) these
-minimal equivalents are used instead.  See INTEGRATION.md.
+The hot-path modules never import the reference's `utils` package (it pulls torchvision, pandas, ...): the one
+helper they need (`texify_str`, used by `__format__(..., 'x')` of Sigma / Optimizer) lives here, so overlay and
+standalone use behave the same.  See INTEGRATION.md.
 """
 import re
 
@@ -25,10 +25,3 @@ def texify_str(s, num=False, space=None, underscore=None, verbatim=False):
     if num:
         out = re.sub(r'[-+]?\d*\.\d+', lambda m: '\\num{' + m.group(0) + '}', out)
     return out
-
-
-try:                                   # overlay mode: defer to the reference's helper
-    from utils.print_log import texify_str as _ref_texify   # noqa: F401
-    texify_str = _ref_texify
-except Exception:                      # standalone mode
-    pass
