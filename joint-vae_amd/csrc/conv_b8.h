@@ -1,0 +1,14 @@
+// bf16 "B8" activation path: internal declarations (see conv_b8.hip for the layout).
+#pragma once
+#include "jvae_internal.h"
+
+// conv_b8.hip
+int jvae_b8_pack(const float* x, void* y, int N, int C, long HW, hipStream_t st);
+int jvae_b8_unpack(const void* y, float* x, int N, int C, long HW, int accumulate, hipStream_t st);
+bool jvae_conv5_b8_fwd_ok(int Cin, int H, int W, int Cout, int OH, int OW, int S, int P);
+size_t jvae_conv5_b8_pack_bytes(int Cin, int Cout);
+int jvae_conv5_b8_max_splits(int N, int OW);
+int jvae_conv5_b8_wpack(const float* w, void* wp, int C, int O, int swap, int flip, hipStream_t st);
+int jvae_conv5_b8_fwd(const void* in, const float* w, int swap, int flip, const float* bias, void* out, int out_f32,
+                      int N, int Cin, int H, int W, int Cout, int OW, int S, int P, void* ws, hipStream_t st,
+                      float* stats = nullptr, int* nsplit = nullptr);

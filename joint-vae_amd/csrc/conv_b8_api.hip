@@ -1,0 +1,133 @@
+// C-ABI entry points of the bf16 "B8" convolution path: geometry, kernel selection.  A direction without a native
+// bf16 kernel returns JVAE_ENOTSUP (jvae_conv2d_native_b8 tells in advance); the host then runs that layer through the
+// fp32 kernels between two layout conversions.
+#include "common.h"
+#include "jvae_internal.h"
+#include "conv_b8.h"
+
+namespace {
+
+bool make_geom(int N, int Cin, int H, int W, int Cout, int KH, int KW, int S, int P, int OP, int transposed,
+               ConvGeom* g, int* OH, int* OW) {
+    if (N < 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || KH <= 0 || KW <= 0 || S <= 0 || P < 0 || OP < 0)
+        return false;
+    g->N = N; g->KH = KH; g->KW = KW; g->S = S; g->P = P;
+    if (!transposed) {
+        if (OP != 0) return false;
+        *OH = (H + 2 * P - KH) / S + 1;
+        *OW = (W + 2 * P - KW) / S + 1;
+        g->Cb = Cin; g->Hb = H; g->Wb = W;
+        g->Cs = Cout; g->Hs = *OH; g->Ws = *OW;
+    } else {
+        if (OP >= S && OP != 0) return false;
+        *OH = (H - 1) * S - 2 * P + KH + OP;
+        *OW = (W - 1) * S - 2 * P + KW + OP;
+        g->Cs = Cin; g->Hs = H; g->Ws = W;
+        g->Cb = Cout; g->Hb = *OH; g->Wb = *OW;
+    }
+    return *OH > 0 && *OW > 0;
+}
+
+inline bool is5(const ConvGeom& g) { return g.KH == 5 && g.KW == 5; }
+// big --conv S,P--> small
+inline bool fold_fwd_fast(const ConvGeom& g) {
+    return is5(g) && jvae_conv5_b8_fwd_ok(g.Cb, g.Hb, g.Wb, g.Cs, g.Hs, g.Ws, g.S, g.P);
+}
+// small --conv 1, 4-P, flipped--> big
+inline bool fold_bwd_fast_s1(const ConvGeom& g) {
+    return is5(g) && g.S == 1 && g.P <= 4 && jvae_conv5_b8_fwd_ok(g.Cs, g.Hs, g.Ws, g.Cb, g.Hb, g.Wb, 1, 4 - g.P);
+}
+
+enum { DIR_FWD = 1, DIR_DGRAD = 2, DIR_WGRAD = 4 };
+
+int native_mask(const ConvGeom& g, int transposed) {
+    int m = 0;
+    if (!transposed) {
+        if (fold_fwd_fast(g)) m |= DIR_FWD;
+        if (fold_bwd_fast_s1(g)) m |= DIR_DGRAD;
+    } else {
+        if (fold_bwd_fast_s1(g)) m |= DIR_FWD;
+        if (fold_fwd_fast(g)) m |= DIR_DGRAD;
+    }
+    return m;
+}
+
+}  // namespace
+
+extern "C" {
+
+int jvae_b8_pack_f32(const float* x, void* y, int N, int C, long HW, void* stream) {
+    if (!x || !y || N < 0 || C <= 0 || HW <= 0) return JVAE_EINVAL;
+    return jvae_b8_pack(x, y, N, C, HW, (hipStream_t)stream);
+}
+
+int jvae_b8_unpack_f32(const void* y, float* x, int N, int C, long HW, int accumulate, void* stream) {
+    if (!x || !y || N < 0 || C <= 0 || HW <= 0) return JVAE_EINVAL;
+    return jvae_b8_unpack(y, x, N, C, HW, accumulate, (hipStream_t)stream);
+}
+
+int jvae_conv2d_native_b8(int N, int Cin, int H, int W, int Cout, int KH, int KW, int S, int P, int OP, int transposed) {
+    ConvGeom g; int oh, ow;
+    if (!make_geom(N, Cin, H, W, Cout, KH, KW, S, P, OP, transposed, &g, &oh, &ow)) return 0;
+    return native_mask(g, transposed);
+}
+
+size_t jvae_conv2d_workspace_bytes_b8(int N, int Cin, int H, int W, int Cout, int KH, int KW, int S, int P, int OP,
+                                      int transposed) {
+    ConvGeom g; int oh, ow;
+    if (!make_geom(N, Cin, H, W, Cout, KH, KW, S, P, OP, transposed, &g, &oh, &ow)) return 0;
+    if (!is5(g)) return 0;
+    size_t a = jvae_conv5_b8_pack_bytes(g.Cb, g.Cs), b = jvae_conv5_b8_pack_bytes(g.Cs, g.Cb);
+    return a > b ? a : b;
+}
+
+int jvae_conv2d_stats_splits_b8(int N, int Cin, int H, int W, int Cout, int KH, int KW, int S, int P, int OP, int transposed) {
+    ConvGeom g; int oh, ow;
+    if (!make_geom(N, Cin, H, W, Cout, KH, KW, S, P, OP, transposed, &g, &oh, &ow)) return 0;
+    if (!(native_mask(g, transposed) & DIR_FWD)) return 0;
+    return jvae_conv5_b8_max_splits(N, ow);
+}
+
+// x: B8; y: B8, or fp32 NCHW when y_f32.  stats (Cout, cap, 2) / nsplit as jvae_conv2d_fwd_stats_f32 (both may be NULL).
+int jvae_conv2d_fwd_b8(const void* x, const float* w, const float* bias, void* y, int y_f32, float* stats, int* nsplit,
+                       int N, int Cin, int H, int W, int Cout, int KH, int KW, int S, int P, int OP, int transposed,
+                       void* ws, size_t ws_bytes, void* stream) {
+    ConvGeom g; int oh, ow;
+    if (nsplit) *nsplit = 0;
+    if (!x || !w || !y) return JVAE_EINVAL;
+    if (stats && !nsplit) return JVAE_EINVAL;
+    if (!make_geom(N, Cin, H, W, Cout, KH, KW, S, P, OP, transposed, &g, &oh, &ow)) return JVAE_EINVAL;
+    if (N == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (!transposed) {
+        if (!fold_fwd_fast(g)) return JVAE_ENOTSUP;
+        if (ws_bytes < jvae_conv5_b8_pack_bytes(g.Cb, g.Cs) || !ws) return JVAE_EWORKSPACE;
+        return jvae_conv5_b8_fwd(x, w, 0, 0, bias, y, y_f32, g.N, g.Cb, g.Hb, g.Wb, g.Cs, g.Ws, g.S, g.P, ws, st, stats, nsplit);
+    }
+    if (fold_bwd_fast_s1(g)) {
+        if (ws_bytes < jvae_conv5_b8_pack_bytes(g.Cs, g.Cb) || !ws) return JVAE_EWORKSPACE;
+        return jvae_conv5_b8_fwd(x, w, 1, 1, bias, y, y_f32, g.N, g.Cs, g.Hs, g.Ws, g.Cb, g.Wb, 1, 4 - g.P, ws, st, stats, nsplit);
+    }
+    return JVAE_ENOTSUP;
+}
+
+// dy: B8 -> dx: B8
+int jvae_conv2d_dgrad_b8(const void* dy, const float* w, void* dx,
+                         int N, int Cin, int H, int W, int Cout, int KH, int KW, int S, int P, int OP, int transposed,
+                         void* ws, size_t ws_bytes, void* stream) {
+    ConvGeom g; int oh, ow;
+    if (!dy || !w || !dx) return JVAE_EINVAL;
+    if (!make_geom(N, Cin, H, W, Cout, KH, KW, S, P, OP, transposed, &g, &oh, &ow)) return JVAE_EINVAL;
+    if (N == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (!transposed) {
+        if (!fold_bwd_fast_s1(g)) return JVAE_ENOTSUP;
+        if (ws_bytes < jvae_conv5_b8_pack_bytes(g.Cs, g.Cb) || !ws) return JVAE_EWORKSPACE;
+        return jvae_conv5_b8_fwd(dy, w, 1, 1, nullptr, dx, 0, g.N, g.Cs, g.Hs, g.Ws, g.Cb, g.Wb, 1, 4 - g.P, ws, st);
+    }
+    if (!fold_fwd_fast(g)) return JVAE_ENOTSUP;
+    if (ws_bytes < jvae_conv5_b8_pack_bytes(g.Cb, g.Cs) || !ws) return JVAE_EWORKSPACE;
+    return jvae_conv5_b8_fwd(dy, w, 0, 0, nullptr, dx, 0, g.N, g.Cb, g.Hb, g.Wb, g.Cs, g.Ws, g.S, g.P, ws, st);
+}
+
+}  // extern "C"
