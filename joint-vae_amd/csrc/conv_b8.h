@@ -12,3 +12,8 @@ int jvae_conv5_b8_wpack(const float* w, void* wp, int C, int O, int swap, int fl
 int jvae_conv5_b8_fwd(const void* in, const float* w, int swap, int flip, const float* bias, void* out, int out_f32,
                       int N, int Cin, int H, int W, int Cout, int OW, int S, int P, void* ws, hipStream_t st,
                       float* stats = nullptr, int* nsplit = nullptr);
+
+// conv_t2_b8.hip: stride-2 transposed 5x5 (4-phase), small (C,WS,WS) -> big (O,2WS,2WS)
+bool jvae_convt2_b8_ok(int C, int HS, int WS, int O, int HB, int WB, int KH, int KW, int S, int P);
+int jvae_convt2_b8(const void* in, const float* w, const float* bias, void* out, int N, int C, int WS, int O,
+                   void* ws, hipStream_t st, float* stats = nullptr, int* nsplit = nullptr);

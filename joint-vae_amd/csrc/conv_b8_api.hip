@@ -38,15 +38,20 @@ inline bool fold_bwd_fast_s1(const ConvGeom& g) {
     return is5(g) && g.S == 1 && g.P <= 4 && jvae_conv5_b8_fwd_ok(g.Cs, g.Hs, g.Ws, g.Cb, g.Hb, g.Wb, 1, 4 - g.P);
 }
 
+// small -> big by the 4-phase kernel (stride-2 transposed forward / stride-2 conv dgrad)
+inline bool fold_bwd_fast_s2(const ConvGeom& g) {
+    return jvae_convt2_b8_ok(g.Cs, g.Hs, g.Ws, g.Cb, g.Hb, g.Wb, g.KH, g.KW, g.S, g.P);
+}
+
 enum { DIR_FWD = 1, DIR_DGRAD = 2, DIR_WGRAD = 4 };
 
 int native_mask(const ConvGeom& g, int transposed) {
     int m = 0;
     if (!transposed) {
         if (fold_fwd_fast(g)) m |= DIR_FWD;
-        if (fold_bwd_fast_s1(g)) m |= DIR_DGRAD;
+        if (fold_bwd_fast_s1(g) || fold_bwd_fast_s2(g)) m |= DIR_DGRAD;
     } else {
-        if (fold_bwd_fast_s1(g)) m |= DIR_FWD;
+        if (fold_bwd_fast_s1(g) || fold_bwd_fast_s2(g)) m |= DIR_FWD;
         if (fold_fwd_fast(g)) m |= DIR_DGRAD;
     }
     return m;
@@ -85,6 +90,7 @@ int jvae_conv2d_stats_splits_b8(int N, int Cin, int H, int W, int Cout, int KH, 
     ConvGeom g; int oh, ow;
     if (!make_geom(N, Cin, H, W, Cout, KH, KW, S, P, OP, transposed, &g, &oh, &ow)) return 0;
     if (!(native_mask(g, transposed) & DIR_FWD)) return 0;
+    if (transposed && fold_bwd_fast_s2(g)) return jvae_conv5_b8_max_splits(N, g.Ws);
     return jvae_conv5_b8_max_splits(N, ow);
 }
 
@@ -108,6 +114,10 @@ int jvae_conv2d_fwd_b8(const void* x, const float* w, const float* bias, void* y
         if (ws_bytes < jvae_conv5_b8_pack_bytes(g.Cs, g.Cb) || !ws) return JVAE_EWORKSPACE;
         return jvae_conv5_b8_fwd(x, w, 1, 1, bias, y, y_f32, g.N, g.Cs, g.Hs, g.Ws, g.Cb, g.Wb, 1, 4 - g.P, ws, st, stats, nsplit);
     }
+    if (fold_bwd_fast_s2(g) && !y_f32) {
+        if (ws_bytes < jvae_conv5_b8_pack_bytes(g.Cs, g.Cb) || !ws) return JVAE_EWORKSPACE;
+        return jvae_convt2_b8(x, w, bias, y, g.N, g.Cs, g.Ws, g.Cb, ws, st, stats, nsplit);
+    }
     return JVAE_ENOTSUP;
 }
 
@@ -121,6 +131,10 @@ int jvae_conv2d_dgrad_b8(const void* dy, const float* w, void* dx,
     if (N == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     if (!transposed) {
+        if (fold_bwd_fast_s2(g)) {
+            if (ws_bytes < jvae_conv5_b8_pack_bytes(g.Cs, g.Cb) || !ws) return JVAE_EWORKSPACE;
+            return jvae_convt2_b8(dy, w, nullptr, dx, g.N, g.Cs, g.Ws, g.Cb, ws, st);
+        }
         if (!fold_bwd_fast_s1(g)) return JVAE_ENOTSUP;
         if (ws_bytes < jvae_conv5_b8_pack_bytes(g.Cs, g.Cb) || !ws) return JVAE_EWORKSPACE;
         return jvae_conv5_b8_fwd(dy, w, 1, 1, nullptr, dx, 0, g.N, g.Cs, g.Hs, g.Ws, g.Cb, g.Wb, 1, 4 - g.P, ws, st);

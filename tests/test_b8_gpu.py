@@ -70,14 +70,18 @@ def test_b8_conv_native_directions(cin, cout, k, s, p, op, tr, H, N):
     xb = ops_b8.pack(x.to(DEV))
     wd, bd = w.to(DEV), b.to(DEV)
     if mask & ops_b8.FWD:
-        y32, st, ns = ops_b8.conv_fwd_raw(xb, wd, bd, spec, out_f32=True, want_stats=True)
-        assert rel(y32, yr) < 2e-5
+        f32_out = not (tr and s == 2)              # the 4-phase transposed kernel only writes B8 (always feeds a BatchNorm)
+        if f32_out:
+            y32, st, ns = ops_b8.conv_fwd_raw(xb, wd, bd, spec, out_f32=True, want_stats=True)
+            assert rel(y32, yr) < 2e-5
+        yb, st2, ns2 = ops_b8.conv_fwd_raw(xb, wd, bd, spec, want_stats=True)
+        if not f32_out:
+            st, ns = st2, ns2
         assert ns > 0
         part = st[:cout * ns * 2].view(cout, ns, 2).double().sum(1).cpu()      # layout (Cout, nsplit, 2)
         d = (yr.detach() - b.view(1, -1, 1, 1)).double()
         assert torch.allclose(part[:, 0], d.sum((0, 2, 3)), rtol=1e-4, atol=1e-3 * float(d.abs().sum((0, 2, 3)).max()))
         assert torch.allclose(part[:, 1], (d * d).sum((0, 2, 3)), rtol=1e-4)
-        yb, _, _ = ops_b8.conv_fwd_raw(xb, wd, bd, spec)
         assert yb.dtype == torch.bfloat16 and yb.shape == (N, (cout + 7) // 8, yr.shape[2], yr.shape[3], 8)
         assert rel(ops_b8.unpack(yb, cout), yr) < BF_TOL
         pad = yb.float().cpu().permute(0, 1, 4, 2, 3).reshape(N, -1, yr.shape[2], yr.shape[3])[:, cout:]
@@ -87,5 +91,5 @@ def test_b8_conv_native_directions(cin, cout, k, s, p, op, tr, H, N):
         yr.backward(gy)
         gx = ops_b8.conv_dgrad_raw(ops_b8.pack(gy.to(DEV)), wd, spec, N, H, H)
         assert rel(ops_b8.unpack(gx, cin), xr.grad) < BF_TOL
-    expected = {(False, 1): 3, (False, 2): 1, (True, 1): 3, (True, 2): 2}[(tr, s)]
+    expected = 3
     assert mask & expected == expected, (mask, expected)
