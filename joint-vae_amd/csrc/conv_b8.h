@@ -5,6 +5,7 @@
 // conv_b8.hip
 int jvae_b8_pack(const float* x, void* y, int N, int C, long HW, hipStream_t st);
 int jvae_b8_unpack(const void* y, float* x, int N, int C, long HW, int accumulate, hipStream_t st);
+int jvae_b8_channel_sum(const void* t, float* out, int N, int C, long HW, int accumulate, float* ws, hipStream_t st);
 bool jvae_conv5_b8_fwd_ok(int Cin, int H, int W, int Cout, int OH, int OW, int S, int P);
 size_t jvae_conv5_b8_pack_bytes(int Cin, int Cout);
 int jvae_conv5_b8_max_splits(int N, int OW);
@@ -17,3 +18,12 @@ int jvae_conv5_b8_fwd(const void* in, const float* w, int swap, int flip, const 
 bool jvae_convt2_b8_ok(int C, int HS, int WS, int O, int HB, int WB, int KH, int KW, int S, int P);
 int jvae_convt2_b8(const void* in, const float* w, const float* bias, void* out, int N, int C, int WS, int O,
                    void* ws, hipStream_t st, float* stats = nullptr, int* nsplit = nullptr);
+
+// conv_wgrad_mfma.hip
+int jvae_wgrad_slab_reduce(const float* slab, float* dw, int G, int Ca, int Cb, int accumulate, int swapflip, hipStream_t st);
+
+// conv_wgrad_b8.hip: dW[a][b][tap] = sum Ps[n][a][u][v] Q[n][b][u*S+kh-P][v*S+kw-P] from B8 tensors
+bool jvae_conv5_wgrad_b8_ok(int Ca, int HS, int WS, int Cb, int HB, int WB, int S, int P);
+size_t jvae_conv5_wgrad_b8_ws_floats(int N, int Ca, int Cb);
+int jvae_conv5_wgrad_b8(const void* ps, const void* q, float* dw, int accumulate, int swapflip,
+                        int N, int Ca, int WS, int Cb, int S, int P, float* ws, hipStream_t st);

@@ -65,6 +65,41 @@ __global__ __launch_bounds__(256) void b8_unpack_kernel(const bf16x8* __restrict
     }
 }
 
+// partial[cb*8+ci][s] = sum over the images of split s and all pixels of t[n][cb][q][ci]   (bias gradients)
+__global__ __launch_bounds__(256) void b8_channel_sum_kernel(const bf16x8* __restrict__ t, float* __restrict__ partial,
+                                                             int N, int CB, long HW, int nsplit) {
+    __shared__ float red[4][8];
+    const int cb = blockIdx.x, s = blockIdx.y;
+    const int per = (N + nsplit - 1) / nsplit;
+    const int nb = s * per, ne = min(N, nb + per);
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const long cnt = (long)(ne - nb) * HW;
+    for (long i = threadIdx.x; i < cnt; i += blockDim.x) {
+        const long n = nb + i / HW, q = i % HW;
+        const bf16x8 v = t[(n * CB + cb) * HW + q];
+#pragma unroll
+        for (int ci = 0; ci < 8; ++ci) acc[ci] += (float)v[ci];
+    }
+#pragma unroll
+    for (int ci = 0; ci < 8; ++ci) {
+        const float w = wave_sum(acc[ci]);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][ci] = w;
+    }
+    __syncthreads();
+    if (threadIdx.x < 8)
+        partial[((long)cb * 8 + threadIdx.x) * nsplit + s] =
+            (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+__global__ void b8_channel_fold_kernel(const float* __restrict__ partial, float* __restrict__ out, int C, int nsplit,
+                                       int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int k = 0; k < nsplit; ++k) s += partial[(long)c * nsplit + k];
+    out[c] = (accumulate ? out[c] : 0.f) + s;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // weights: Wp[kb][tap][half][o][ci] = bf16( W[o][c = kb*16 + half*8 + ci][tap] )   (o < OP, zero padding)
 // swap: source is [c][o][tap] (ConvTranspose2d layout / role swap), flip: tap -> 24 - tap
@@ -347,6 +382,20 @@ int jvae_b8_unpack(const void* y, float* x, int N, int C, long HW, int accumulat
     if (total == 0) return 0;
     const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
     hipLaunchKernelGGL(b8_unpack_kernel, dim3(blocks), dim3(256), 0, st, (const bf16x8*)y, x, N, C, CB, HW, accumulate);
+    JVAE_LAUNCH_CHECK();
+    return 0;
+}
+
+// out[c] (+)= sum_{n,q} t[n][c][q]; ws: ceil(C/8)*8*64 floats
+int jvae_b8_channel_sum(const void* t, float* out, int N, int C, long HW, int accumulate, float* ws, hipStream_t st) {
+    const int CB = (C + 7) / 8;
+    int ns = (int)((long)N * HW / 4096);
+    if (ns < 1) ns = 1;
+    if (ns > 64) ns = 64;
+    if (ns > N) ns = N > 0 ? N : 1;
+    hipLaunchKernelGGL(b8_channel_sum_kernel, dim3(CB, ns), dim3(256), 0, st, (const bf16x8*)t, ws, N, CB, HW, ns);
+    JVAE_LAUNCH_CHECK();
+    hipLaunchKernelGGL(b8_channel_fold_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, (const float*)ws, out, C, ns, accumulate);
     JVAE_LAUNCH_CHECK();
     return 0;
 }

@@ -43,6 +43,19 @@ inline bool fold_bwd_fast_s2(const ConvGeom& g) {
     return jvae_convt2_b8_ok(g.Cs, g.Hs, g.Ws, g.Cb, g.Hb, g.Wb, g.KH, g.KW, g.S, g.P);
 }
 
+// wgrad: role swap when the folded side has <= 8 channels (Conv 32 -> 3): the 8-channel side becomes `b` (MODE 1)
+inline bool wgrad_swap(const ConvGeom& g) { return g.S == 1 && g.Cs <= 8 && g.Cb > 8 && g.Hs == g.Hb; }
+inline bool wgrad_fast(const ConvGeom& g) {
+    if (!is5(g)) return false;
+    if (wgrad_swap(g)) return jvae_conv5_wgrad_b8_ok(g.Cb, g.Hb, g.Wb, g.Cs, g.Hs, g.Ws, 1, 4 - g.P);
+    return jvae_conv5_wgrad_b8_ok(g.Cs, g.Hs, g.Ws, g.Cb, g.Hb, g.Wb, g.S, g.P);
+}
+inline size_t wgrad_ws_bytes(const ConvGeom& g) {
+    size_t slab = 4 * (wgrad_swap(g) ? jvae_conv5_wgrad_b8_ws_floats(g.N, g.Cb, g.Cs) : jvae_conv5_wgrad_b8_ws_floats(g.N, g.Cs, g.Cb));
+    return slab;
+}
+inline size_t chsum_ws_bytes(int C) { return (size_t)((C + 7) / 8) * 8 * 64 * 4; }
+
 enum { DIR_FWD = 1, DIR_DGRAD = 2, DIR_WGRAD = 4 };
 
 int native_mask(const ConvGeom& g, int transposed) {
@@ -54,6 +67,7 @@ int native_mask(const ConvGeom& g, int transposed) {
         if (fold_bwd_fast_s1(g) || fold_bwd_fast_s2(g)) m |= DIR_FWD;
         if (fold_fwd_fast(g)) m |= DIR_DGRAD;
     }
+    if (wgrad_fast(g)) m |= DIR_WGRAD;
     return m;
 }
 
@@ -83,7 +97,12 @@ size_t jvae_conv2d_workspace_bytes_b8(int N, int Cin, int H, int W, int Cout, in
     if (!make_geom(N, Cin, H, W, Cout, KH, KW, S, P, OP, transposed, &g, &oh, &ow)) return 0;
     if (!is5(g)) return 0;
     size_t a = jvae_conv5_b8_pack_bytes(g.Cb, g.Cs), b = jvae_conv5_b8_pack_bytes(g.Cs, g.Cb);
-    return a > b ? a : b;
+    if (b > a) a = b;
+    if (wgrad_fast(g)) {
+        b = wgrad_ws_bytes(g) + chsum_ws_bytes(Cout);
+        if (b > a) a = b;
+    }
+    return a;
 }
 
 int jvae_conv2d_stats_splits_b8(int N, int Cin, int H, int W, int Cout, int KH, int KW, int S, int P, int OP, int transposed) {
@@ -142,6 +161,34 @@ int jvae_conv2d_dgrad_b8(const void* dy, const float* w, void* dx,
     if (!fold_fwd_fast(g)) return JVAE_ENOTSUP;
     if (ws_bytes < jvae_conv5_b8_pack_bytes(g.Cb, g.Cs) || !ws) return JVAE_EWORKSPACE;
     return jvae_conv5_b8_fwd(dy, w, 0, 0, nullptr, dx, 0, g.N, g.Cb, g.Hb, g.Wb, g.Cs, g.Ws, g.S, g.P, ws, st);
+}
+
+// x, dy: B8 (layer input / gradient of the layer output); dw fp32 in the layer's own layout; dbias may be NULL
+int jvae_conv2d_wgrad_b8(const void* x, const void* dy, float* dw, float* dbias, int accumulate,
+                         int N, int Cin, int H, int W, int Cout, int KH, int KW, int S, int P, int OP, int transposed,
+                         void* ws, size_t ws_bytes, void* stream) {
+    ConvGeom g; int oh, ow;
+    if (!x || !dy || !dw) return JVAE_EINVAL;
+    if (!make_geom(N, Cin, H, W, Cout, KH, KW, S, P, OP, transposed, &g, &oh, &ow)) return JVAE_EINVAL;
+    if (!wgrad_fast(g)) return JVAE_ENOTSUP;
+    if (!ws || ws_bytes < wgrad_ws_bytes(g) + (dbias ? chsum_ws_bytes(Cout) : 0)) return JVAE_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    if (!accumulate) {
+        hipError_t e = hipMemsetAsync(dw, 0, sizeof(float) * (size_t)Cin * Cout * 25, st);
+        if (e != hipSuccess) return (int)e;
+        if (dbias && (e = hipMemsetAsync(dbias, 0, sizeof(float) * (size_t)Cout, st)) != hipSuccess) return (int)e;
+    }
+    if (N == 0) return 0;
+    const void* big = transposed ? dy : x;
+    const void* small = transposed ? x : dy;
+    int rc;
+    if (wgrad_swap(g))
+        rc = jvae_conv5_wgrad_b8(big, small, dw, 1, 1, g.N, g.Cb, g.Wb, g.Cs, 1, 4 - g.P, (float*)ws, st);
+    else
+        rc = jvae_conv5_wgrad_b8(small, big, dw, 1, 0, g.N, g.Cs, g.Ws, g.Cb, g.S, g.P, (float*)ws, st);
+    if (rc) return rc;
+    if (dbias) rc = jvae_b8_channel_sum(dy, dbias, N, Cout, (long)oh * ow, 1, (float*)((char*)ws + wgrad_ws_bytes(g)), st);
+    return rc;
 }
 
 }  // extern "C"

@@ -225,6 +225,14 @@ inline int pick_cb(int S, int WS, int Cb) {
 
 }  // namespace
 
+// dw (+)= sum over the G slabs (a, b, tap) in a fixed order; shared with the bf16 path (conv_wgrad_b8.hip)
+int jvae_wgrad_slab_reduce(const float* slab, float* dw, int G, int Ca, int Cb, int accumulate, int swapflip, hipStream_t st) {
+    const int total = Ca * Cb * 25;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 64)), dim3(256), 0, st, slab, dw, G, Ca, Cb, accumulate, swapflip);
+    JVAE_LAUNCH_CHECK();
+    return 0;
+}
+
 bool jvae_conv5_wgrad_ok(int Ca, int HS, int WS, int Cb, int HB, int WB, int S, int P) {
     if (S != 1 && S != 2) return false;
     if (HS != WS || HB != WB || WB != WS * S) return false;
@@ -288,9 +296,5 @@ int jvae_conv5_wgrad(const float* ps, const float* q, float* dw, int accumulate,
         }
     }
     if (rc) return rc;
-    const int total = Ca * Cb * 25;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 64)), dim3(256), 0, st, ws, dw, p.G, Ca, Cb, accumulate,
-                       swapflip);
-    JVAE_LAUNCH_CHECK();
-    return 0;
+    return jvae_wgrad_slab_reduce(ws, dw, p.G, Ca, Cb, accumulate, swapflip, st);
 }

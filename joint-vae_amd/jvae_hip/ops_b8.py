@@ -80,3 +80,19 @@ def conv_dgrad_raw(gy, w, spec, N, H, W):
     rc = L.load().jvae_conv2d_dgrad_b8(L.ptr(gy), L.ptr(w), L.ptr(gx), *geom, L.ptr(ws), nb, L.stream_ptr())
     L.check(rc, 'jvae_conv2d_dgrad_b8')
     return gx
+
+
+def conv_wgrad_raw(x, gy, spec, wshape, want_bias, w_slot=None, b_slot=None):
+    """x, gy: B8.  -> (gw, gb) fp32; with slots the result is ADDED into them (see ops.conv_wgrad_raw)."""
+    N, _, H, W, _ = x.shape
+    inplace = w_slot is not None and (b_slot is not None or not want_bias)
+    gw = w_slot if inplace else torch.empty(wshape, device=x.device, dtype=torch.float32)
+    gb = None
+    if want_bias:
+        gb = b_slot if inplace else torch.empty(spec.cout, device=x.device, dtype=torch.float32)
+    geom = spec.geom(N, H, W)
+    ws, nb = _ws(geom, x.device)
+    rc = L.load().jvae_conv2d_wgrad_b8(L.ptr(x), L.ptr(gy), L.ptr(gw), L.ptr(gb), int(inplace), *geom, L.ptr(ws), nb,
+                                       L.stream_ptr())
+    L.check(rc, 'jvae_conv2d_wgrad_b8')
+    return (None, None) if inplace else (gw, gb)

@@ -86,10 +86,21 @@ def test_b8_conv_native_directions(cin, cout, k, s, p, op, tr, H, N):
         assert rel(ops_b8.unpack(yb, cout), yr) < BF_TOL
         pad = yb.float().cpu().permute(0, 1, 4, 2, 3).reshape(N, -1, yr.shape[2], yr.shape[3])[:, cout:]
         assert float(pad.abs().max()) == 0. if pad.numel() else True      # padding channels stay exactly zero
+    gy = rbf(torch.randn(yr.shape, generator=g))
+    wr_ = wr.clone().requires_grad_(True)
+    br_ = b.clone().requires_grad_(True)
+    conv(x, wr_, br_).backward(gy)
+    if mask & ops_b8.WGRAD:
+        gyb = ops_b8.pack(gy.to(DEV))
+        gw, gb = ops_b8.conv_wgrad_raw(xb, gyb, spec, wshape, True)
+        assert rel(gw, wr_.grad) < 3e-5
+        assert rel(gb, br_.grad) < 3e-5
+        slot_w, slot_b = torch.ones(wshape, device=DEV), torch.ones(cout, device=DEV)
+        ops_b8.conv_wgrad_raw(xb, gyb, spec, wshape, True, slot_w, slot_b)       # accumulate in place
+        assert rel(slot_w - 1, wr_.grad) < 3e-5 and rel(slot_b - 1, br_.grad) < 3e-5
     if mask & ops_b8.DGRAD:
-        gy = rbf(torch.randn(yr.shape, generator=g))
         yr.backward(gy)
         gx = ops_b8.conv_dgrad_raw(ops_b8.pack(gy.to(DEV)), wd, spec, N, H, H)
         assert rel(ops_b8.unpack(gx, cin), xr.grad) < BF_TOL
-    expected = 3
+    expected = 7
     assert mask & expected == expected, (mask, expected)
