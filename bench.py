@@ -25,6 +25,7 @@ import torch  # noqa: E402
 
 FLOP_PER_IMAGE = 923.2e6          # conv/linear MACs*2, fwd + bwd, L=1 (decoder runs on 2N latents)
 MFMA_F32_PEAK = 157.3e12          # MI355X dense fp32 MFMA, MI355X_MICROARCH.md
+MFMA_BF16_PEAK = 2.5e15           # dense bf16 MFMA (same guide); only used for the --dtype bf16 diagnostic line
 BATCH_PER_GPU = 512
 
 
@@ -33,8 +34,9 @@ WORKLOADS = {   # id -> (description, FLOP per image fwd+bwd)   (BASELINE.json c
         'learned sigma, L=1), bs=512 per GPU, fp32, fwd+bwd+clip+Adam', 923.2e6),
     3: ('BASELINE configs[2]: CIFAR-100 3x32x32 conv CVAE, class-conditional gaussian prior C=100, bs=512 per GPU, fp32',
         923.2e6),
-    5: ('BASELINE configs[4] geometry in fp32 (no bf16 path yet): 3x64x64 conv32+/deconv32+, latent_dim=200, C=20, '
-        'bs=256 per GPU', 5105e6),
+    5: ('BASELINE configs[4]: ImageNet-20-shaped 3x64x64 conv CVAE (conv32+/deconv32+, latent_dim=200, C=20), '
+        'bs=256 per GPU; --dtype bf16 = bf16 activations + bf16 MFMA from fp32 master weights, f32 = same geometry in fp32',
+        5105e6),
 }
 
 
@@ -116,6 +118,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--batch', type=int, default=None, help='diagnostics only: per-GPU batch (the metric is defined at 512)')
     ap.add_argument('--sync-bn', action='store_true', help='BatchNorm statistics over all ranks (default: per rank)')
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'], help='bf16: the mixed-precision mode of BASELINE configs[4]')
     ap.add_argument('--workload', type=int, default=2, choices=sorted(WORKLOADS), help='diagnostics: other BASELINE configs')
     a = ap.parse_args()
     fh = _watchdog(900)
@@ -142,6 +145,8 @@ def main():
     torch.cuda.set_device(device)
 
     net = build_model(device, a.workload)
+    if a.dtype == 'bf16':
+        net.set_compute_dtype('bf16')
     if world > 1:
         net.optimizer.set_distributed(world)
         if a.sync_bn:
@@ -174,14 +179,15 @@ def main():
     if rank == 0:
         out = {'metric': 'training_images_per_sec', 'value': value, 'unit': 'images/s', 'n_gpus': world,
                'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': dt / a.steps * 1e3, 'higher_is_better': True,
-               'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+               'scaling': 'weak', 'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
                'config': {'workload': WORKLOADS[a.workload][0],
                           'global_batch': world * a.batch, 'parallelism': f'dp{world}',
                           'bn_statistics': 'synchronised over ranks' if (a.sync_bn and world > 1) else 'per-rank (local)'},
-               'step_mfma_frac': value / world * WORKLOADS[a.workload][1] / MFMA_F32_PEAK,
+               'step_mfma_frac': value / world * WORKLOADS[a.workload][1] / (MFMA_F32_PEAK if a.dtype == 'f32' else MFMA_BF16_PEAK),
                'final_loss': float(losses['total'].detach().mean())}
-        out['roofline'] = dominant_kernel_roofline(device)
-        if world == 1 and not a.no_cpu_baseline:
+        if a.workload == 2 and a.dtype == 'f32':      # the roofline probe and the CPU baseline belong to the headline config
+            out['roofline'] = dominant_kernel_roofline(device)
+        if world == 1 and not a.no_cpu_baseline and a.workload == 2 and a.dtype == 'f32':
             out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out))
     if dist is not None:

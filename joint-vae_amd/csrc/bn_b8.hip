@@ -1,0 +1,353 @@
+// BatchNorm2d (+ fused ReLU) on bf16 "B8" activations (layout: conv_b8.hip): forward (train / eval), backward.
+// Statistics, coefficients, parameter gradients and running statistics are fp32 (partials folded in fp64); only the
+// activation tensors are bf16.  HBM-bound: each pass streams the tensor once in 16-byte units (8 channels of a pixel),
+// a block owns one channel block (8 channels) x a chunk of images.
+// Reference: nn.BatchNorm2d + ReLU after every (de)conv (module/vae_layers/conv.py:214-220).
+#include "common.h"
+#include "jvae_internal.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int MAX_SPLIT = 64;
+
+__device__ __forceinline__ void bn_coef(float g, float b, float mean, float invstd, float* sc, float* sh) {
+    *sc = g * invstd;
+    *sh = b - mean * (g * invstd);
+}
+
+// reduce 8 per-thread values over the block (256 threads): result[ci] valid in thread 0
+__device__ __forceinline__ void block_sum8(float (&v)[8], float (*red)[8]) {
+#pragma unroll
+    for (int ci = 0; ci < 8; ++ci) {
+        const float w = wave_sum(v[ci]);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][ci] = w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ci = 0; ci < 8; ++ci) v[ci] = (red[0][ci] + red[1][ci]) + (red[2][ci] + red[3][ci]);
+    __syncthreads();
+}
+
+// partial[c][s] = (sum(x - p), sum((x - p)^2)) over the images of split s;  p = x[0][c][0]
+__global__ __launch_bounds__(256) void bn8_stats_kernel(const bf16x8* __restrict__ x, float* __restrict__ partial,
+                                                        int N, int C, int CB, long HW, int nsplit) {
+    __shared__ float red[4][8];
+    const int cb = blockIdx.x, s = blockIdx.y;
+    const bf16x8 pv = x[(long)cb * HW];
+    const int per = (N + nsplit - 1) / nsplit;
+    const int nb = s * per, ne = min(N, nb + per);
+    float s1[8], s2[8];
+#pragma unroll
+    for (int ci = 0; ci < 8; ++ci) s1[ci] = s2[ci] = 0.f;
+    const long cnt = (long)(ne - nb) * HW;
+    for (long i = threadIdx.x; i < cnt; i += blockDim.x) {
+        const long n = nb + i / HW, q = i % HW;
+        const bf16x8 v = x[(n * CB + cb) * HW + q];
+#pragma unroll
+        for (int ci = 0; ci < 8; ++ci) { const float d = (float)v[ci] - (float)pv[ci]; s1[ci] += d; s2[ci] += d * d; }
+    }
+    block_sum8(s1, red);
+    block_sum8(s2, red);
+    if (threadIdx.x == 0)
+#pragma unroll
+        for (int ci = 0; ci < 8; ++ci) {
+            const int c = cb * 8 + ci;
+            if (c < C) { partial[((long)c * nsplit + s) * 2 + 0] = s1[ci]; partial[((long)c * nsplit + s) * 2 + 1] = s2[ci]; }
+        }
+}
+
+// forward apply: block (cb, chunk j) folds the partial sums of its 8 channels (32 threads per channel, fp64), chunk 0
+// publishes mean / invstd and updates the running statistics; then y = [relu](x*scale + shift) in bf16.
+__global__ __launch_bounds__(256) void bn8_apply_kernel(const bf16x8* __restrict__ x, const float* __restrict__ partial,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        float* running_mean, float* running_var, long long* num_batches_tracked,
+                                                        float* save_mean, float* save_invstd, bf16x8* __restrict__ y,
+                                                        int N, int C, int CB, long HW, int nsplit, int nchunk, float momentum,
+                                                        float eps, int training, int relu, int ext_pivot,
+                                                        const float* __restrict__ pivot) {
+    __shared__ float cs[2][8];
+    const int cb = blockIdx.x, j = blockIdx.y;
+    const int ci_t = threadIdx.x >> 5, l = threadIdx.x & 31;      // 8 groups of 32 threads: one channel each
+    const int c_t = cb * 8 + ci_t;
+    if (training) {
+        double s1 = 0., s2 = 0.;
+        if (c_t < C)
+            for (int s = l; s < nsplit; s += 32) {
+                s1 += (double)partial[((long)c_t * nsplit + s) * 2 + 0];
+                s2 += (double)partial[((long)c_t * nsplit + s) * 2 + 1];
+            }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+        if (l == 0) {
+            float sc = 0.f, sh = 0.f;
+            if (c_t < C) {
+                const float g = gamma ? gamma[c_t] : 1.f, b = beta ? beta[c_t] : 0.f;
+                const double n = (double)N * HW;
+                const double dm = s1 / n;
+                double var = s2 / n - dm * dm;
+                if (var < 0.) var = 0.;
+                const double pv = ext_pivot ? (pivot ? (double)pivot[c_t] : 0.) : (double)(float)x[(long)cb * HW][ci_t];
+                const float mean = (float)(pv + dm);
+                const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+                if (j == 0) {
+                    save_mean[c_t] = mean;
+                    save_invstd[c_t] = invstd;
+                    if (running_mean) running_mean[c_t] = (1.f - momentum) * running_mean[c_t] + momentum * mean;
+                    if (running_var) {
+                        const float unbiased = (float)(n > 1. ? var * n / (n - 1.) : var);
+                        running_var[c_t] = (1.f - momentum) * running_var[c_t] + momentum * unbiased;
+                    }
+                    if (c_t == 0 && num_batches_tracked) *num_batches_tracked += 1;
+                }
+                bn_coef(g, b, mean, invstd, &sc, &sh);
+            }
+            cs[0][ci_t] = sc; cs[1][ci_t] = sh;
+        }
+    } else if (l == 0) {
+        float sc = 0.f, sh = 0.f;
+        if (c_t < C) {
+            const float g = gamma ? gamma[c_t] : 1.f, b = beta ? beta[c_t] : 0.f;
+            bn_coef(g, b, running_mean[c_t], rsqrtf(running_var[c_t] + eps), &sc, &sh);
+        }
+        cs[0][ci_t] = sc; cs[1][ci_t] = sh;
+    }
+    __syncthreads();
+    float sc[8], sh[8];
+#pragma unroll
+    for (int ci = 0; ci < 8; ++ci) { sc[ci] = cs[0][ci]; sh[ci] = cs[1][ci]; }
+    const int per = (N + nchunk - 1) / nchunk;
+    const int nb = j * per, ne = min(N, nb + per);
+    const long cnt = (long)(ne - nb) * HW;
+    for (long i = threadIdx.x; i < cnt; i += blockDim.x) {
+        const long n = nb + i / HW, q = i % HW;
+        const long off = (n * CB + cb) * HW + q;
+        const bf16x8 v = x[off];
+        bf16x8 o;
+#pragma unroll
+        for (int ci = 0; ci < 8; ++ci) {
+            const float t = fmaf((float)v[ci], sc[ci], sh[ci]);          // padding channels: sc = sh = 0 -> stay 0
+            o[ci] = (__bf16)(relu ? fmaxf(t, 0.f) : t);
+        }
+        y[off] = o;
+    }
+}
+
+// partial[c][s] = (sum g, sum g*xhat), g = dy masked by the recomputed ReLU
+__global__ __launch_bounds__(256) void bn8_bwd_reduce_kernel(const bf16x8* __restrict__ dy, const bf16x8* __restrict__ x,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                             float* __restrict__ partial, int N, int C, int CB, long HW,
+                                                             int nsplit, int relu) {
+    __shared__ float red[4][8];
+    const int cb = blockIdx.x, s = blockIdx.y;
+    float mu[8], is[8], sc[8], sh[8];
+#pragma unroll
+    for (int ci = 0; ci < 8; ++ci) {
+        const int c = cb * 8 + ci;
+        mu[ci] = c < C ? mean[c] : 0.f;
+        is[ci] = c < C ? invstd[c] : 0.f;
+        bn_coef(c < C && gamma ? gamma[c] : (c < C ? 1.f : 0.f), c < C && beta ? beta[c] : 0.f, mu[ci], is[ci], &sc[ci], &sh[ci]);
+    }
+    const int per = (N + nsplit - 1) / nsplit;
+    const int nb = s * per, ne = min(N, nb + per);
+    float s1[8], s2[8];
+#pragma unroll
+    for (int ci = 0; ci < 8; ++ci) s1[ci] = s2[ci] = 0.f;
+    const long cnt = (long)(ne - nb) * HW;
+    for (long i = threadIdx.x; i < cnt; i += blockDim.x) {
+        const long n = nb + i / HW, q = i % HW;
+        const long off = (n * CB + cb) * HW + q;
+        const bf16x8 xv = x[off], gv = dy[off];
+#pragma unroll
+        for (int ci = 0; ci < 8; ++ci) {
+            const float xf = (float)xv[ci];
+            float g = (float)gv[ci];
+            if (relu && !(fmaf(xf, sc[ci], sh[ci]) > 0.f)) g = 0.f;
+            s1[ci] += g; s2[ci] += g * ((xf - mu[ci]) * is[ci]);
+        }
+    }
+    block_sum8(s1, red);
+    block_sum8(s2, red);
+    if (threadIdx.x == 0)
+#pragma unroll
+        for (int ci = 0; ci < 8; ++ci) {
+            const int c = cb * 8 + ci;
+            if (c < C) { partial[((long)c * nsplit + s) * 2 + 0] = s1[ci]; partial[((long)c * nsplit + s) * 2 + 1] = s2[ci]; }
+        }
+}
+
+__global__ __launch_bounds__(256) void bn8_bwd_apply_kernel(const bf16x8* __restrict__ dy, const bf16x8* __restrict__ x,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                            const float* __restrict__ partial, bf16x8* __restrict__ dx,
+                                                            float* dgamma, float* dbeta, int accumulate,
+                                                            int N, int C, int CB, long HW, int nsplit, int nchunk, int relu) {
+    __shared__ float ms[2][8];
+    const int cb = blockIdx.x, j = blockIdx.y;
+    if (threadIdx.x < 8) {
+        const int c = cb * 8 + threadIdx.x;
+        double s1 = 0., s2 = 0.;
+        if (c < C)
+            for (int s = 0; s < nsplit; ++s) {
+                s1 += (double)partial[((long)c * nsplit + s) * 2 + 0];
+                s2 += (double)partial[((long)c * nsplit + s) * 2 + 1];
+            }
+        const double M = (double)N * HW;
+        ms[0][threadIdx.x] = (float)(s1 / M);
+        ms[1][threadIdx.x] = (float)(s2 / M);
+        if (j == 0 && c < C) {
+            if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s1;
+            if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)s2;
+        }
+    }
+    __syncthreads();
+    float mu[8], is[8], sc[8], sh[8], k[8], m1[8], m2[8];
+#pragma unroll
+    for (int ci = 0; ci < 8; ++ci) {
+        const int c = cb * 8 + ci;
+        const float g_ = c < C ? (gamma ? gamma[c] : 1.f) : 0.f;
+        mu[ci] = c < C ? mean[c] : 0.f;
+        is[ci] = c < C ? invstd[c] : 0.f;
+        bn_coef(g_, c < C && beta ? beta[c] : 0.f, mu[ci], is[ci], &sc[ci], &sh[ci]);
+        k[ci] = g_ * is[ci];
+        m1[ci] = ms[0][ci]; m2[ci] = ms[1][ci];
+    }
+    const int per = (N + nchunk - 1) / nchunk;
+    const int nb = j * per, ne = min(N, nb + per);
+    const long cnt = (long)(ne - nb) * HW;
+    for (long i = threadIdx.x; i < cnt; i += blockDim.x) {
+        const long n = nb + i / HW, q = i % HW;
+        const long off = (n * CB + cb) * HW + q;
+        const bf16x8 xv = x[off], gv = dy[off];
+        bf16x8 o;
+#pragma unroll
+        for (int ci = 0; ci < 8; ++ci) {
+            const float xf = (float)xv[ci];
+            float g = (float)gv[ci];
+            if (relu && !(fmaf(xf, sc[ci], sh[ci]) > 0.f)) g = 0.f;
+            o[ci] = (__bf16)(k[ci] * (g - m1[ci] - ((xf - mu[ci]) * is[ci]) * m2[ci]));   // k = 0 on padding channels
+        }
+        dx[off] = o;
+    }
+}
+
+// y = relu(x) / dx = dy * [y > 0] on B8 tensors (layers without BatchNorm)
+__global__ __launch_bounds__(256) void relu8_fwd_kernel(const bf16x8* __restrict__ x, bf16x8* __restrict__ y, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const bf16x8 v = x[i];
+        bf16x8 o;
+#pragma unroll
+        for (int ci = 0; ci < 8; ++ci) o[ci] = (float)v[ci] > 0.f ? v[ci] : (__bf16)0.f;
+        y[i] = o;
+    }
+}
+__global__ __launch_bounds__(256) void relu8_bwd_kernel(const bf16x8* __restrict__ dy, const bf16x8* __restrict__ y,
+                                                        bf16x8* __restrict__ dx, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const bf16x8 g = dy[i], v = y[i];
+        bf16x8 o;
+#pragma unroll
+        for (int ci = 0; ci < 8; ++ci) o[ci] = (float)v[ci] > 0.f ? g[ci] : (__bf16)0.f;
+        dx[i] = o;
+    }
+}
+
+inline int pick_split(int N, int CB, long HW) {
+    long s = (long)N * HW / 4096;
+    if (s < 1) s = 1;
+    long cap = (2048 + CB - 1) / CB;
+    if (s > cap) s = cap;
+    if (s > MAX_SPLIT) s = MAX_SPLIT;
+    if (s > N) s = N;
+    return (int)(s < 1 ? 1 : s);
+}
+inline int pick_chunk(int N, int CB, long HW) {
+    long s = (long)N * HW / 8192;
+    if (s < 1) s = 1;
+    long cap = (4096 + CB - 1) / CB;
+    if (s > cap) s = cap;
+    if (s > N) s = N;
+    return (int)(s < 1 ? 1 : s);
+}
+
+}  // namespace
+
+extern "C" {
+
+// x, y: B8 (N, ceil(C/8), HW, 8).  Workspace: jvae_bn_workspace_bytes(C).  ext_stats as in jvae_bn_fwd_ext_f32
+// (ext_nsplit == 0: the statistics kernel runs here).
+int jvae_bn_fwd_b8(const void* x, const float* gamma, const float* beta,
+                   float* running_mean, float* running_var, long long* num_batches_tracked,
+                   void* y, float* save_mean, float* save_invstd,
+                   int N, int C, long HW, float momentum, float eps, int training, int relu,
+                   const float* ext_stats, int ext_nsplit, const float* ext_pivot,
+                   void* ws, size_t ws_bytes, void* stream) {
+    if (!x || !y || N < 0 || C <= 0 || HW <= 0) return JVAE_EINVAL;
+    if (ws_bytes < sizeof(float) * ((size_t)2 * C * MAX_SPLIT + (size_t)2 * C) || !ws) return JVAE_EWORKSPACE;
+    if (N == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const int CB = (C + 7) / 8;
+    const float* partial = (const float*)ws;
+    int ns = 1;
+    const bool ext = training && ext_stats && ext_nsplit > 0;
+    if (training && (!save_mean || !save_invstd)) return JVAE_EINVAL;
+    if (ext) {
+        partial = ext_stats;
+        ns = ext_nsplit;
+    } else if (training) {
+        ns = pick_split(N, CB, HW);
+        hipLaunchKernelGGL(bn8_stats_kernel, dim3(CB, ns), dim3(256), 0, st, (const bf16x8*)x, (float*)ws, N, C, CB, HW, ns);
+        JVAE_LAUNCH_CHECK();
+    } else if (!running_mean || !running_var) {
+        return JVAE_EINVAL;
+    }
+    const int nc = pick_chunk(N, CB, HW);
+    hipLaunchKernelGGL(bn8_apply_kernel, dim3(CB, nc), dim3(256), 0, st, (const bf16x8*)x, partial, gamma, beta,
+                       running_mean, running_var, num_batches_tracked, save_mean, save_invstd, (bf16x8*)y,
+                       N, C, CB, HW, ns, nc, momentum, eps, training, relu, ext ? 1 : 0, ext_pivot);
+    JVAE_LAUNCH_CHECK();
+    return 0;
+}
+
+int jvae_bn_bwd_b8(const void* dy, const void* x, const float* gamma, const float* beta,
+                   const float* save_mean, const float* save_invstd,
+                   void* dx, float* dgamma, float* dbeta, int accumulate,
+                   int N, int C, long HW, int relu, void* ws, size_t ws_bytes, void* stream) {
+    if (!dy || !x || !save_mean || !save_invstd || !dx || N < 0 || C <= 0 || HW <= 0) return JVAE_EINVAL;
+    if (ws_bytes < sizeof(float) * ((size_t)2 * C * MAX_SPLIT + (size_t)2 * C) || !ws) return JVAE_EWORKSPACE;
+    if (N == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const int CB = (C + 7) / 8;
+    float* partial = (float*)ws;
+    const int ns = pick_split(N, CB, HW);
+    hipLaunchKernelGGL(bn8_bwd_reduce_kernel, dim3(CB, ns), dim3(256), 0, st, (const bf16x8*)dy, (const bf16x8*)x, gamma, beta,
+                       save_mean, save_invstd, partial, N, C, CB, HW, ns, relu);
+    JVAE_LAUNCH_CHECK();
+    const int nc = pick_chunk(N, CB, HW);
+    hipLaunchKernelGGL(bn8_bwd_apply_kernel, dim3(CB, nc), dim3(256), 0, st, (const bf16x8*)dy, (const bf16x8*)x, gamma, beta,
+                       save_mean, save_invstd, partial, (bf16x8*)dx, dgamma, dbeta, accumulate, N, C, CB, HW, ns, nc, relu);
+    JVAE_LAUNCH_CHECK();
+    return 0;
+}
+
+// ReLU on B8 tensors of `units` 16-byte units (backward takes the forward OUTPUT)
+int jvae_relu_fwd_b8(const void* x, void* y, long units, void* stream) {
+    if (!x || !y || units < 0) return JVAE_EINVAL;
+    if (units == 0) return 0;
+    const int blocks = (int)((units + 255) / 256 > 8192 ? 8192 : (units + 255) / 256);
+    hipLaunchKernelGGL(relu8_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16x8*)x, (bf16x8*)y, units);
+    JVAE_LAUNCH_CHECK();
+    return 0;
+}
+int jvae_relu_bwd_b8(const void* dy, const void* y, void* dx, long units, void* stream) {
+    if (!dy || !y || !dx || units < 0) return JVAE_EINVAL;
+    if (units == 0) return 0;
+    const int blocks = (int)((units + 255) / 256 > 8192 ? 8192 : (units + 255) / 256);
+    hipLaunchKernelGGL(relu8_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16x8*)dy, (const bf16x8*)y,
+                       (bf16x8*)dx, units);
+    JVAE_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

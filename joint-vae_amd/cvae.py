@@ -360,6 +360,19 @@ class ClassificationVariationalNetwork(nn.Module):
                 m.sync_world, m.sync_group = int(world_size), process_group
         return self
 
+    def set_compute_dtype(self, dtype):
+        """'fp32' (the reference's arithmetic; default) or 'bf16' (config 5 of BASELINE.json): bf16 activations between the
+        layers of the conv stacks and bf16 matrix-core convolutions from the fp32 master weights; BatchNorm statistics,
+        the dense heads, the latent / loss math, gradients of parameters and Adam stay fp32."""
+        from module.vae_layers.conv import HipConvStack
+        if dtype not in ('fp32', 'bf16'):
+            raise ValueError(dtype)
+        for m in self.modules():
+            if isinstance(m, HipConvStack):
+                m.compute_dtype = dtype
+        self.compute_dtype = dtype
+        return self
+
     @property
     def max_batch_sizes(self):
         """The reference hard-wires {'train': 32, 'test': 32} (cvae.py:1145-1147); with 288 GB of

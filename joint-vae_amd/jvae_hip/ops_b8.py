@@ -96,3 +96,202 @@ def conv_wgrad_raw(x, gy, spec, wshape, want_bias, w_slot=None, b_slot=None):
                                        L.stream_ptr())
     L.check(rc, 'jvae_conv2d_wgrad_b8')
     return (None, None) if inplace else (gw, gb)
+
+
+# ----------------------------------------------------------------------------------------- autograd layer
+def is_b8(t):
+    return t.dtype == torch.bfloat16 and t.dim() == 5 and t.shape[-1] == 8
+
+
+class _Pack(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.C = x.shape[1]
+        return pack(x)
+
+    @staticmethod
+    def backward(ctx, gy):
+        return unpack(O._c(gy), ctx.C)
+
+
+class _Unpack(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xb, C):
+        return unpack(xb, C)
+
+    @staticmethod
+    def backward(ctx, gy):
+        return pack(gy), None
+
+
+def to_b8(x):
+    return _Pack.apply(x)
+
+
+def from_b8(xb, C):
+    return _Unpack.apply(xb, C)
+
+
+class _ConvB8(torch.autograd.Function):
+    """nn.Conv2d / nn.ConvTranspose2d on a B8 input.  Output: B8, or fp32 NCHW with out_f32 (the last layer of a stack).
+    Directions without a native bf16 kernel take the fp32 kernels between two layout conversions."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, spec, dead_bias, stats_out, out_f32):
+        N, _, H, W, _ = x.shape
+        mask = native_mask(spec, N, H, W)
+        ctx.w_ref, ctx.b_ref = w, b
+        w = O._c(w)
+        want_stats = stats_out is not None
+        if mask & FWD and not (out_f32 and spec.transposed and spec.s == 2):
+            y, st, ns = conv_fwd_raw(x, w, b, spec, out_f32=out_f32, want_stats=want_stats)
+        else:
+            x32 = unpack(x, spec.cin)
+            if want_stats:
+                y32, st, ns = O.conv_fwd_stats_raw(x32, w, b, spec)
+            else:
+                y32, st, ns = O.conv_fwd_raw(x32, w, b, spec), None, 0
+            y = y32 if out_f32 else pack(y32)
+        if want_stats:
+            stats_out['stats'], stats_out['nsplit'], stats_out['pivot'] = st, ns, b
+        ctx.save_for_backward(x, w)
+        ctx.spec, ctx.mask, ctx.out_f32 = spec, mask, out_f32
+        ctx.has_bias = b is not None
+        ctx.dead_bias = dead_bias
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        spec, mask = ctx.spec, ctx.mask
+        N, _, H, W, _ = x.shape
+        gy = O._c(gy)
+        cache = {'b8': None if ctx.out_f32 else gy, 'f32': gy if ctx.out_f32 else None}
+
+        def g_b8():
+            if cache['b8'] is None:
+                cache['b8'] = pack(cache['f32'])
+            return cache['b8']
+
+        def g_f32():
+            if cache['f32'] is None:
+                cache['f32'] = unpack(cache['b8'], spec.cout)
+            return cache['f32']
+
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            if mask & DGRAD:
+                gx = conv_dgrad_raw(g_b8(), w, spec, N, H, W)
+            else:
+                gx = pack(O.conv_dgrad_raw(g_f32(), w, spec, (N, spec.cin, H, W)))
+        want_b = ctx.has_bias and ctx.needs_input_grad[2] and not ctx.dead_bias
+        if ctx.needs_input_grad[1] or want_b:
+            w_slot = O._grad_slot(ctx.w_ref)
+            b_slot = O._grad_slot(ctx.b_ref) if want_b else None
+            native = bool(mask & WGRAD)
+            if native:
+                gyw = g_b8()
+                run = lambda ws_, bs_: conv_wgrad_raw(x, gyw, spec, w.shape, want_b, ws_, bs_)
+            else:
+                gyw = g_f32()
+                x32 = unpack(x, spec.cin)
+                run = lambda ws_, bs_: O.conv_wgrad_raw(x32, gyw, spec, w.shape, want_b, ws_, bs_)
+            if O.OVERLAP_WGRAD and w_slot is not None and (b_slot is not None or not want_b):
+                main = torch.cuda.current_stream(x.device)
+                side = L.side_stream(x.device)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    run(w_slot, b_slot)
+                x.record_stream(side)
+                gyw.record_stream(side)
+                if not native:
+                    x32.record_stream(side)
+                O._join_after_backward()
+            else:
+                gw, gb = run(w_slot, b_slot)
+        if ctx.dead_bias and ctx.has_bias and ctx.needs_input_grad[2] and O._grad_slot(ctx.b_ref) is None:
+            gb = torch.zeros_like(ctx.b_ref)
+        return gx, gw, gb, None, None, None, None
+
+
+def conv2d(x, w, b, spec, dead_bias=False, stats_out=None, out_f32=False):
+    return _ConvB8.apply(x, w, b, spec, dead_bias, stats_out, out_f32)
+
+
+class _BatchNormActB8(torch.autograd.Function):
+    """nn.BatchNorm2d (train or eval) + optional ReLU on a B8 tensor; statistics and parameters fp32."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, rm, rv, nbt, training, relu, momentum, eps, ext, C):
+        x = O._c(x)
+        N, CB, H, W, _ = x.shape
+        HW = H * W
+        lib = L.load()
+        y = torch.empty_like(x)
+        mean = torch.empty(C, device=x.device, dtype=torch.float32)
+        invstd = torch.empty(C, device=x.device, dtype=torch.float32)
+        ws = L.workspace(lib.jvae_bn_workspace_bytes(C), x.device)
+        use_ext = ext is not None and ext.get('stats') is not None and training
+        rc = lib.jvae_bn_fwd_b8(L.ptr(x), L.ptr(gamma), L.ptr(beta), L.ptr(rm), L.ptr(rv), L.ptr(nbt), L.ptr(y),
+                                L.ptr(mean), L.ptr(invstd), N, C, HW, momentum, eps, int(training), int(relu),
+                                L.ptr(ext['stats']) if use_ext else None, int(ext['nsplit']) if use_ext else 0,
+                                L.ptr(ext.get('pivot')) if use_ext else None, L.ptr(ws), ws.numel(), L.stream_ptr())
+        L.check(rc, 'jvae_bn_fwd_b8')
+        if training:
+            ctx.save_for_backward(x, gamma, beta, mean, invstd)
+            ctx.relu = relu
+            ctx.dims = (N, C, HW)
+            ctx.g_ref, ctx.b_ref = gamma, beta
+        else:
+            ctx.dims = None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        if ctx.dims is None:
+            raise L.JvaeHipError('backward through eval-mode BatchNorm is not part of the training step')
+        x, gamma, beta, mean, invstd = ctx.saved_tensors
+        N, C, HW = ctx.dims
+        gy = O._c(gy)
+        lib = L.load()
+        gx = torch.empty_like(x)
+        sg, sb = O._grad_slot(ctx.g_ref), O._grad_slot(ctx.b_ref)
+        inplace = sg is not None and sb is not None
+        gg = sg if inplace else torch.empty(C, device=x.device, dtype=torch.float32)
+        gb = sb if inplace else torch.empty(C, device=x.device, dtype=torch.float32)
+        ws = L.workspace(lib.jvae_bn_workspace_bytes(C), x.device)
+        rc = lib.jvae_bn_bwd_b8(L.ptr(gy), L.ptr(x), L.ptr(gamma), L.ptr(beta), L.ptr(mean), L.ptr(invstd), L.ptr(gx),
+                                L.ptr(gg), L.ptr(gb), int(inplace), N, C, HW, int(ctx.relu), L.ptr(ws), ws.numel(),
+                                L.stream_ptr())
+        L.check(rc, 'jvae_bn_bwd_b8')
+        if inplace:
+            gg = gb = None
+        return gx, gg, gb, None, None, None, None, None, None, None, None, None
+
+
+def batchnorm_act(x, C, gamma, beta, running_mean, running_var, num_batches_tracked, training, relu,
+                  momentum=0.1, eps=1e-5, ext=None):
+    return _BatchNormActB8.apply(x, gamma, beta, running_mean, running_var, num_batches_tracked, training, relu,
+                                 momentum, eps, ext, C)
+
+
+class _ReluB8(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = O._c(x)
+        y = torch.empty_like(x)
+        L.check(L.load().jvae_relu_fwd_b8(L.ptr(x), L.ptr(y), x.numel() // 8, L.stream_ptr()), 'jvae_relu_fwd_b8')
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        y, = ctx.saved_tensors
+        gy = O._c(gy)
+        gx = torch.empty_like(gy)
+        L.check(L.load().jvae_relu_bwd_b8(L.ptr(gy), L.ptr(y), L.ptr(gx), y.numel() // 8, L.stream_ptr()), 'jvae_relu_bwd_b8')
+        return gx
+
+
+def relu(x):
+    return _ReluB8.apply(x)

@@ -18,7 +18,7 @@ import re
 
 from torch import nn
 
-from jvae_hip import ops
+from jvae_hip import ops, ops_b8
 from .misc import activation_layers, Reshape, ACT_OF_MODULE
 
 _ini = configparser.ConfigParser()
@@ -123,9 +123,18 @@ class HipBatchNorm2d(nn.BatchNorm2d):
 
 class HipConvStack(nn.Sequential):
     """nn.Sequential whose forward fuses BatchNorm2d with the activation that follows it and lets the producing
-    convolution's epilogue compute the batch statistics."""
+    convolution's epilogue compute the batch statistics.
+
+    compute_dtype 'bf16' (config 5 of BASELINE.json; no counterpart in the fp32 reference): activations between the
+    layers are bf16 in the B8 layout (jvae_hip/ops_b8.py), convolutions run on the bf16 matrix cores with fp32
+    accumulation from the fp32 master weights; the stack still takes and returns fp32 NCHW tensors.  Layers whose
+    geometry has no bf16 kernel at all (the 3x3 / 4x4 / 7x7 / 8x8 heads) stay on the fp32 kernels."""
+
+    compute_dtype = 'fp32'
 
     def forward(self, x):
+        if self.compute_dtype == 'bf16':
+            return self._forward_b8(x)
         mods = list(self)
         i = 0
         ext = None
@@ -146,6 +155,68 @@ class HipConvStack(nn.Sequential):
                 ext = None
                 x = m(x)
             i += 1
+        return x
+
+    def _forward_b8(self, x):
+        mods = list(self)
+        convs = [k for k, m in enumerate(mods) if isinstance(m, (HipConv2d, HipConvTranspose2d))]
+        i = 0
+        ext = None
+        channels = x.shape[1]
+        while i < len(mods):
+            m = mods[i]
+            b8 = ops_b8.is_b8(x)
+            if isinstance(m, (HipConv2d, HipConvTranspose2d)):
+                spec = m._spec()
+                N = x.shape[0]
+                H, W = (x.shape[2], x.shape[3])
+                native = ops_b8.native_mask(spec, N, H, W) != 0
+                bn_next = i + 1 < len(mods) and isinstance(mods[i + 1], HipBatchNorm2d)
+                fused = bn_next and mods[i + 1].training and mods[i + 1].sync_world <= 1
+                ext = {} if fused else None
+                dead = bn_next and mods[i + 1].training
+                if native:
+                    if not b8:
+                        x = ops_b8.to_b8(x)
+                    # the last convolution of the stack writes fp32 NCHW directly (it feeds the loss / the dense heads)
+                    last = i == convs[-1] and not bn_next and not (spec.transposed and spec.s == 2)
+                    x = ops_b8.conv2d(x, m.weight, m.bias, spec, dead, ext, out_f32=last)
+                else:
+                    if b8:
+                        x = ops_b8.from_b8(x, channels)
+                    x = ops.conv2d(x, m.weight, m.bias, spec, dead, ext)
+                channels = spec.cout
+                i += 1
+                continue
+            if isinstance(m, HipBatchNorm2d):
+                relu = False
+                step = 1
+                if i + 1 < len(mods) and type(mods[i + 1]) in ACT_OF_MODULE \
+                        and ACT_OF_MODULE[type(mods[i + 1])] in (ops.RELU, ops.IDENT):
+                    relu = ACT_OF_MODULE[type(mods[i + 1])] == ops.RELU
+                    step = 2
+                if b8 and not (m.training and m.sync_world > 1):
+                    x = ops_b8.batchnorm_act(x, channels, m.weight, m.bias, m.running_mean, m.running_var,
+                                             m.num_batches_tracked, m.training, relu, m.momentum, m.eps, ext)
+                else:
+                    if b8:
+                        x = ops_b8.from_b8(x, channels)
+                    x = m(x, relu=relu, ext=ext)
+                ext = None
+                i += step
+                continue
+            ext = None
+            if b8 and type(m) in ACT_OF_MODULE and ACT_OF_MODULE[type(m)] == ops.RELU:
+                x = ops_b8.relu(x)
+            elif b8 and type(m) in ACT_OF_MODULE and ACT_OF_MODULE[type(m)] == ops.IDENT:
+                pass
+            else:
+                if b8:
+                    x = ops_b8.from_b8(x, channels)
+                x = m(x)
+            i += 1
+        if ops_b8.is_b8(x):
+            x = ops_b8.from_b8(x, channels)
         return x
 
 
