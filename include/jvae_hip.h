@@ -37,6 +37,11 @@ int jvae_gemm_f32(int M, int N, int K, int batch,
                   float* C, long sCm, long sCn, long sCb,
                   const float* bias, int bias_mode, int flags, int splitk, void* stream);
 
+/* y[i] = [relu](bias[i % N] + sum_{s<S} part[s][i]), i < MN: deterministic fold of a split-K product whose K slices were
+ * computed by one batched jvae_gemm_f32 launch (used by the dense heads when M*N gives too few tiles, e.g. 256 x 200
+ * with K = 7200 in the 64x64 model). */
+int jvae_splitk_fold_f32(const float* part, const float* bias, float* y, int S, long MN, int N, int relu, void* stream);
+
 /* ---- (transposed) convolution ---------------------------------------------------------------------
  * x: (N,Cin,H,W) layer input; y: (N,Cout,OH,OW) layer output; w in the PyTorch layout of the layer kind
  * ((Cout,Cin,KH,KW) for Conv2d, (Cin,Cout,KH,KW) for ConvTranspose2d); S stride, P padding,
@@ -110,6 +115,48 @@ int jvae_bn_bwd_sync_f32(const float* dy, const float* x, const float* gamma, co
                          const float* local_sums, const float* global_sums, int world,
                          float* dx, float* dgamma, float* dbeta, int accumulate,
                          int N, int C, int P, int relu, void* stream);
+
+/* ---- bf16 activation path ("B8" layout) --------------------------------------------------------------
+ * BASELINE.json configs[4] ("bf16 ... 64x64 deeper conv CVAE"): no counterpart in the fp32 reference.  An activation
+ * tensor (N, C, H, W) is stored as (N, ceil(C/8), H, W, 8) bf16: the 8 channels of a pixel are one 16-byte unit, which is
+ * one lane's operand of v_mfma_f32_32x32x16_bf16; padding channels are 0.  Master weights (PyTorch layouts, as in the
+ * fp32 entry points), biases, BatchNorm statistics / parameters and every gradient of a parameter stay fp32; products
+ * are bf16 x bf16 accumulated in fp32.  Geometry arguments as in the *_f32 convolution entry points.
+ * jvae_conv2d_native_b8 -> bit mask of the directions that have a bf16 kernel (1 forward, 2 dgrad, 4 wgrad: the 5x5
+ * stride-1/2 "same"/"half"/"double" layers of conv32(+) / deconv32(+)); the other entry points return -2 (not
+ * supported) for the rest and the host runs those layers on the fp32 kernels between two conversions. */
+int jvae_b8_pack_f32(const float* x, void* y, int N, int C, long HW, void* stream);            /* fp32 NCHW -> B8 */
+int jvae_b8_unpack_f32(const void* y, float* x, int N, int C, long HW, int accumulate, void* stream);
+int jvae_conv2d_native_b8(int N, int Cin, int H, int W, int Cout, int KH, int KW, int S, int P, int OP, int transposed);
+size_t jvae_conv2d_workspace_bytes_b8(int N, int Cin, int H, int W, int Cout, int KH, int KW, int S, int P, int OP,
+                                      int transposed);
+int jvae_conv2d_stats_splits_b8(int N, int Cin, int H, int W, int Cout, int KH, int KW, int S, int P, int OP, int transposed);
+/* y: B8, or fp32 NCHW when y_f32 (last layer of a stack).  stats / nsplit (both may be NULL): BatchNorm partial sums
+ * of (y - bias) taken from the fp32 accumulators, laid out (Cout, *nsplit, 2) as in jvae_conv2d_fwd_stats_f32. */
+int jvae_conv2d_fwd_b8(const void* x, const float* w, const float* bias, void* y, int y_f32, float* stats, int* nsplit,
+                       int N, int Cin, int H, int W, int Cout, int KH, int KW, int S, int P, int OP, int transposed,
+                       void* ws, size_t ws_bytes, void* stream);
+int jvae_conv2d_dgrad_b8(const void* dy, const float* w, void* dx,
+                         int N, int Cin, int H, int W, int Cout, int KH, int KW, int S, int P, int OP, int transposed,
+                         void* ws, size_t ws_bytes, void* stream);
+/* dw / dbias fp32 (dbias may be NULL); accumulate: add onto their current contents. */
+int jvae_conv2d_wgrad_b8(const void* x, const void* dy, float* dw, float* dbias, int accumulate,
+                         int N, int Cin, int H, int W, int Cout, int KH, int KW, int S, int P, int OP, int transposed,
+                         void* ws, size_t ws_bytes, void* stream);
+/* BatchNorm2d (+ReLU) on B8 tensors; arguments as jvae_bn_fwd_ext_f32 / jvae_bn_bwd_f32 with HW = pixels per image. */
+size_t jvae_bn_workspace_bytes_b8(int C);
+int jvae_bn_fwd_b8(const void* x, const float* gamma, const float* beta,
+                   float* running_mean, float* running_var, long long* num_batches_tracked,
+                   void* y, float* save_mean, float* save_invstd,
+                   int N, int C, long HW, float momentum, float eps, int training, int relu,
+                   const float* ext_stats, int ext_nsplit, const float* ext_pivot,
+                   void* ws, size_t ws_bytes, void* stream);
+int jvae_bn_bwd_b8(const void* dy, const void* x, const float* gamma, const float* beta,
+                   const float* save_mean, const float* save_invstd,
+                   void* dx, float* dgamma, float* dbeta, int accumulate,
+                   int N, int C, long HW, int relu, void* ws, size_t ws_bytes, void* stream);
+int jvae_relu_fwd_b8(const void* x, void* y, long units, void* stream);                /* units of 8 bf16 */
+int jvae_relu_bwd_b8(const void* dy, const void* y, void* dx, long units, void* stream);
 
 /* ---- activations (kind 0 identity, 1 ReLU, 2 sigmoid); backward takes the forward OUTPUT ---------- */
 int jvae_act_fwd_f32(const float* x, float* y, long n, int kind, void* stream);

@@ -9,7 +9,25 @@
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-constexpr int MAX_SPLIT = 64;
+constexpr int MAX_SPLIT = 512;     // partial sums per channel (few channel blocks -> many image splits to fill the chip)
+
+// unit offset of flat index i (image-major inside this block's image range) without 64-bit division
+struct UnitIdx {
+    unsigned hw; int sh; long stride, base;     // sh >= 0: HW is a power of two
+    __device__ __forceinline__ long operator()(unsigned i) const {
+        unsigned n, q;
+        if (sh >= 0) { n = i >> sh; q = i & (hw - 1); } else { n = i / hw; q = i - n * hw; }
+        return base + (long)n * stride + q;
+    }
+};
+__device__ __forceinline__ UnitIdx unit_idx(int nb, int CB, int cb, long HW) {
+    UnitIdx u;
+    u.hw = (unsigned)HW;
+    u.sh = (HW & (HW - 1)) == 0 ? __ffsll((long long)HW) - 1 : -1;
+    u.stride = (long)CB * HW;
+    u.base = ((long)nb * CB + cb) * HW;
+    return u;
+}
 
 __device__ __forceinline__ void bn_coef(float g, float b, float mean, float invstd, float* sc, float* sh) {
     *sc = g * invstd;
@@ -40,10 +58,11 @@ __global__ __launch_bounds__(256) void bn8_stats_kernel(const bf16x8* __restrict
     float s1[8], s2[8];
 #pragma unroll
     for (int ci = 0; ci < 8; ++ci) s1[ci] = s2[ci] = 0.f;
-    const long cnt = (long)(ne - nb) * HW;
-    for (long i = threadIdx.x; i < cnt; i += blockDim.x) {
-        const long n = nb + i / HW, q = i % HW;
-        const bf16x8 v = x[(n * CB + cb) * HW + q];
+    const unsigned cnt = (unsigned)((long)(ne - nb) * HW);
+    const UnitIdx ui = unit_idx(nb, CB, cb, HW);
+#pragma unroll 2
+    for (unsigned i = threadIdx.x; i < cnt; i += 256) {
+        const bf16x8 v = x[ui(i)];
 #pragma unroll
         for (int ci = 0; ci < 8; ++ci) { const float d = (float)v[ci] - (float)pv[ci]; s1[ci] += d; s2[ci] += d * d; }
     }
@@ -118,10 +137,11 @@ __global__ __launch_bounds__(256) void bn8_apply_kernel(const bf16x8* __restrict
     for (int ci = 0; ci < 8; ++ci) { sc[ci] = cs[0][ci]; sh[ci] = cs[1][ci]; }
     const int per = (N + nchunk - 1) / nchunk;
     const int nb = j * per, ne = min(N, nb + per);
-    const long cnt = (long)(ne - nb) * HW;
-    for (long i = threadIdx.x; i < cnt; i += blockDim.x) {
-        const long n = nb + i / HW, q = i % HW;
-        const long off = (n * CB + cb) * HW + q;
+    const unsigned cnt = (unsigned)((long)(ne - nb) * HW);
+    const UnitIdx ui = unit_idx(nb, CB, cb, HW);
+#pragma unroll 2
+    for (unsigned i = threadIdx.x; i < cnt; i += 256) {
+        const long off = ui(i);
         const bf16x8 v = x[off];
         bf16x8 o;
 #pragma unroll
@@ -154,10 +174,11 @@ __global__ __launch_bounds__(256) void bn8_bwd_reduce_kernel(const bf16x8* __res
     float s1[8], s2[8];
 #pragma unroll
     for (int ci = 0; ci < 8; ++ci) s1[ci] = s2[ci] = 0.f;
-    const long cnt = (long)(ne - nb) * HW;
-    for (long i = threadIdx.x; i < cnt; i += blockDim.x) {
-        const long n = nb + i / HW, q = i % HW;
-        const long off = (n * CB + cb) * HW + q;
+    const unsigned cnt = (unsigned)((long)(ne - nb) * HW);
+    const UnitIdx ui = unit_idx(nb, CB, cb, HW);
+#pragma unroll 2
+    for (unsigned i = threadIdx.x; i < cnt; i += 256) {
+        const long off = ui(i);
         const bf16x8 xv = x[off], gv = dy[off];
 #pragma unroll
         for (int ci = 0; ci < 8; ++ci) {
@@ -185,20 +206,25 @@ __global__ __launch_bounds__(256) void bn8_bwd_apply_kernel(const bf16x8* __rest
                                                             int N, int C, int CB, long HW, int nsplit, int nchunk, int relu) {
     __shared__ float ms[2][8];
     const int cb = blockIdx.x, j = blockIdx.y;
-    if (threadIdx.x < 8) {
-        const int c = cb * 8 + threadIdx.x;
+    {
+        const int ci_t = threadIdx.x >> 5, l = threadIdx.x & 31;      // 32 threads fold one channel (fixed order, fp64)
+        const int c = cb * 8 + ci_t;
         double s1 = 0., s2 = 0.;
         if (c < C)
-            for (int s = 0; s < nsplit; ++s) {
+            for (int s = l; s < nsplit; s += 32) {
                 s1 += (double)partial[((long)c * nsplit + s) * 2 + 0];
                 s2 += (double)partial[((long)c * nsplit + s) * 2 + 1];
             }
-        const double M = (double)N * HW;
-        ms[0][threadIdx.x] = (float)(s1 / M);
-        ms[1][threadIdx.x] = (float)(s2 / M);
-        if (j == 0 && c < C) {
-            if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s1;
-            if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)s2;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+        if (l == 0) {
+            const double M = (double)N * HW;
+            ms[0][ci_t] = (float)(s1 / M);
+            ms[1][ci_t] = (float)(s2 / M);
+            if (j == 0 && c < C) {
+                if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s1;
+                if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)s2;
+            }
         }
     }
     __syncthreads();
@@ -215,10 +241,11 @@ __global__ __launch_bounds__(256) void bn8_bwd_apply_kernel(const bf16x8* __rest
     }
     const int per = (N + nchunk - 1) / nchunk;
     const int nb = j * per, ne = min(N, nb + per);
-    const long cnt = (long)(ne - nb) * HW;
-    for (long i = threadIdx.x; i < cnt; i += blockDim.x) {
-        const long n = nb + i / HW, q = i % HW;
-        const long off = (n * CB + cb) * HW + q;
+    const unsigned cnt = (unsigned)((long)(ne - nb) * HW);
+    const UnitIdx ui = unit_idx(nb, CB, cb, HW);
+#pragma unroll 2
+    for (unsigned i = threadIdx.x; i < cnt; i += 256) {
+        const long off = ui(i);
         const bf16x8 xv = x[off], gv = dy[off];
         bf16x8 o;
 #pragma unroll
@@ -254,7 +281,7 @@ __global__ __launch_bounds__(256) void relu8_bwd_kernel(const bf16x8* __restrict
 }
 
 inline int pick_split(int N, int CB, long HW) {
-    long s = (long)N * HW / 4096;
+    long s = (long)N * HW / 2048;
     if (s < 1) s = 1;
     long cap = (2048 + CB - 1) / CB;
     if (s > cap) s = cap;
@@ -263,7 +290,7 @@ inline int pick_split(int N, int CB, long HW) {
     return (int)(s < 1 ? 1 : s);
 }
 inline int pick_chunk(int N, int CB, long HW) {
-    long s = (long)N * HW / 8192;
+    long s = (long)N * HW / 4096;
     if (s < 1) s = 1;
     long cap = (4096 + CB - 1) / CB;
     if (s > cap) s = cap;
@@ -275,7 +302,9 @@ inline int pick_chunk(int N, int CB, long HW) {
 
 extern "C" {
 
-// x, y: B8 (N, ceil(C/8), HW, 8).  Workspace: jvae_bn_workspace_bytes(C).  ext_stats as in jvae_bn_fwd_ext_f32
+size_t jvae_bn_workspace_bytes_b8(int C) { return sizeof(float) * ((size_t)2 * ((C + 7) / 8 * 8) * MAX_SPLIT + (size_t)2 * C); }
+
+// x, y: B8 (N, ceil(C/8), HW, 8).  Workspace: jvae_bn_workspace_bytes_b8(C).  ext_stats as in jvae_bn_fwd_ext_f32
 // (ext_nsplit == 0: the statistics kernel runs here).
 int jvae_bn_fwd_b8(const void* x, const float* gamma, const float* beta,
                    float* running_mean, float* running_var, long long* num_batches_tracked,
@@ -284,7 +313,7 @@ int jvae_bn_fwd_b8(const void* x, const float* gamma, const float* beta,
                    const float* ext_stats, int ext_nsplit, const float* ext_pivot,
                    void* ws, size_t ws_bytes, void* stream) {
     if (!x || !y || N < 0 || C <= 0 || HW <= 0) return JVAE_EINVAL;
-    if (ws_bytes < sizeof(float) * ((size_t)2 * C * MAX_SPLIT + (size_t)2 * C) || !ws) return JVAE_EWORKSPACE;
+    if (ws_bytes < jvae_bn_workspace_bytes_b8(C) || !ws) return JVAE_EWORKSPACE;
     if (N == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     const int CB = (C + 7) / 8;
@@ -315,7 +344,7 @@ int jvae_bn_bwd_b8(const void* dy, const void* x, const float* gamma, const floa
                    void* dx, float* dgamma, float* dbeta, int accumulate,
                    int N, int C, long HW, int relu, void* ws, size_t ws_bytes, void* stream) {
     if (!dy || !x || !save_mean || !save_invstd || !dx || N < 0 || C <= 0 || HW <= 0) return JVAE_EINVAL;
-    if (ws_bytes < sizeof(float) * ((size_t)2 * C * MAX_SPLIT + (size_t)2 * C) || !ws) return JVAE_EWORKSPACE;
+    if (ws_bytes < jvae_bn_workspace_bytes_b8(C) || !ws) return JVAE_EWORKSPACE;
     if (N == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     const int CB = (C + 7) / 8;

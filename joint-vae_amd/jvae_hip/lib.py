@@ -18,6 +18,7 @@ P = c_void_p
 _SIGS = {
     'jvae_version': (c_char_p, []),
     'jvae_gemm_f32': (c_int, [c_int] * 4 + [P, c_long, c_long, c_long] * 3 + [P, c_int, c_int, c_int, P]),
+    'jvae_splitk_fold_f32': (c_int, [P, P, P, c_int, c_long, c_int, c_int, P]),
     'jvae_conv2d_workspace_bytes': (c_size_t, [c_int] * 11),
     'jvae_conv2d_out_shape': (c_int, [c_int] * 8 + [POINTER(c_int), POINTER(c_int)]),
     'jvae_conv2d_fwd_f32': (c_int, [P, P, P, P] + [c_int] * 11 + [P, c_size_t, P]),
@@ -33,6 +34,7 @@ _SIGS = {
     'jvae_conv2d_fwd_b8': (c_int, [P, P, P, P, c_int, P, POINTER(c_int)] + [c_int] * 11 + [P, c_size_t, P]),
     'jvae_conv2d_dgrad_b8': (c_int, [P, P, P] + [c_int] * 11 + [P, c_size_t, P]),
     'jvae_conv2d_wgrad_b8': (c_int, [P, P, P, P, c_int] + [c_int] * 11 + [P, c_size_t, P]),
+    'jvae_bn_workspace_bytes_b8': (c_size_t, [c_int]),
     'jvae_bn_fwd_b8': (c_int, [P] * 9 + [c_int, c_int, c_long, c_float, c_float, c_int, c_int, P, c_int, P, P, c_size_t, P]),
     'jvae_bn_bwd_b8': (c_int, [P] * 9 + [c_int, c_int, c_int, c_long, c_int, P, c_size_t, P]),
     'jvae_relu_fwd_b8': (c_int, [P, P, c_long, P]),

@@ -63,6 +63,17 @@ def channel_sum(t, N, C, P, out=None, accumulate=False):
     return out
 
 
+def _linear_split(R, O, I):
+    """K slices for y = x W^T when the (R, O) output alone cannot fill the chip (64x64 tiles, 256 CUs)."""
+    tiles = ((R + 63) // 64) * ((O + 63) // 64)
+    if tiles >= 128 or I < 2048:
+        return 1
+    for S in (32, 16, 8, 4, 2):
+        if tiles * S <= 1024 and I % S == 0 and I // S >= 128:
+            return S
+    return 1
+
+
 class _Linear(torch.autograd.Function):
     """y = x W^T + b (+ReLU / sigmoid).  nn.Linear + activation, layers.py:283-296, cvae.py:291-301."""
 
@@ -74,8 +85,17 @@ class _Linear(torch.autograd.Function):
         R, I = x2.shape
         O = w.shape[0]
         y = torch.empty((R, O), device=x.device, dtype=torch.float32)
-        gemm(R, O, I, x2, (I, 1, 0), w, (1, I, 0), y, (O, 1, 0), bias=b, bias_mode=1 if b is not None else 0,
-             flags=2 if act == RELU else 0)
+        S = _linear_split(R, O, I)
+        if S > 1:
+            # few output tiles, long K: K slices as the batch of one launch, then a fixed-order fold (+bias, ReLU)
+            part = torch.empty((S, R, O), device=x.device, dtype=torch.float32)
+            Ks = I // S
+            gemm(R, O, Ks, x2, (I, 1, Ks), w, (1, I, Ks), part, (O, 1, R * O), batch=S)
+            L.check(L.load().jvae_splitk_fold_f32(L.ptr(part), L.ptr(b), L.ptr(y), S, R * O, O, int(act == RELU),
+                                                  L.stream_ptr()), 'jvae_splitk_fold_f32')
+        else:
+            gemm(R, O, I, x2, (I, 1, 0), w, (1, I, 0), y, (O, 1, 0), bias=b, bias_mode=1 if b is not None else 0,
+                 flags=2 if act == RELU else 0)
         if act == SIGMOID:
             L.check(L.load().jvae_act_fwd_f32(L.ptr(y), L.ptr(y), y.numel(), SIGMOID, L.stream_ptr()), 'act_fwd')
         ctx.save_for_backward(x2, w, y if act != IDENT else None)

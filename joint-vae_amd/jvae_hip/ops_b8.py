@@ -230,7 +230,7 @@ class _BatchNormActB8(torch.autograd.Function):
         y = torch.empty_like(x)
         mean = torch.empty(C, device=x.device, dtype=torch.float32)
         invstd = torch.empty(C, device=x.device, dtype=torch.float32)
-        ws = L.workspace(lib.jvae_bn_workspace_bytes(C), x.device)
+        ws = L.workspace(lib.jvae_bn_workspace_bytes_b8(C), x.device)
         use_ext = ext is not None and ext.get('stats') is not None and training
         rc = lib.jvae_bn_fwd_b8(L.ptr(x), L.ptr(gamma), L.ptr(beta), L.ptr(rm), L.ptr(rv), L.ptr(nbt), L.ptr(y),
                                 L.ptr(mean), L.ptr(invstd), N, C, HW, momentum, eps, int(training), int(relu),
@@ -259,7 +259,7 @@ class _BatchNormActB8(torch.autograd.Function):
         inplace = sg is not None and sb is not None
         gg = sg if inplace else torch.empty(C, device=x.device, dtype=torch.float32)
         gb = sb if inplace else torch.empty(C, device=x.device, dtype=torch.float32)
-        ws = L.workspace(lib.jvae_bn_workspace_bytes(C), x.device)
+        ws = L.workspace(lib.jvae_bn_workspace_bytes_b8(C), x.device)
         rc = lib.jvae_bn_bwd_b8(L.ptr(gy), L.ptr(x), L.ptr(gamma), L.ptr(beta), L.ptr(mean), L.ptr(invstd), L.ptr(gx),
                                 L.ptr(gg), L.ptr(gb), int(inplace), N, C, HW, int(ctx.relu), L.ptr(ws), ws.numel(),
                                 L.stream_ptr())

@@ -130,6 +130,25 @@ def test_linear(act):
     assert rel(xd.grad, xr.grad) < 2e-5 and rel(wd.grad, wr.grad) < 2e-5 and rel(bd.grad, br.grad) < 2e-5
 
 
+@pytest.mark.parametrize('act', [0, 1])
+def test_linear_split_k(act):
+    """Dense head of the 64x64 model (256 x 7200 -> 200): too few output tiles, so K is sliced over the batch dimension
+    of one GEMM launch and folded in a fixed order; must agree with the plain product and be run-to-run identical."""
+    from jvae_hip import ops
+    assert ops._linear_split(256, 200, 7200) > 1 and ops._linear_split(512, 64, 800) == 1
+    g = torch.Generator().manual_seed(5 + act)
+    x = torch.randn(256, 7200, generator=g)
+    w = torch.randn(200, 7200, generator=g) / 85
+    b = torch.randn(200, generator=g)
+    yr = F.linear(x, w, b)
+    yr = torch.relu(yr) if act else yr
+    xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
+    y1 = ops.linear(xd, wd, bd, act)
+    y2 = ops.linear(xd, wd, bd, act)
+    assert rel(y1, yr) < 2e-5
+    assert torch.equal(y1, y2)
+
+
 @pytest.mark.parametrize('prior,var_dim', [('gaussian', 'scalar'), ('gaussian', 'diag'), ('gaussian', 'full'),
                                            ('tilted', 'scalar'), ('uniform', 'scalar')])
 @pytest.mark.parametrize('K,L', [(64, 1), (200, 2), (16, 1)])
