@@ -119,7 +119,30 @@ inline int grid_for(long total) {
 }
 
 // Small folded grids (E4 of conv32: 2x2) make per-image products degenerate: batch over positions instead.
-inline bool pixel_batched(const ConvGeom& g) { return g.Hs * g.Ws < 32; }
+// (also the 6x6 / 5x5 grids of conv32+ / deconv32+: 36 / 25 positions)
+inline bool pixel_batched(const ConvGeom& g) { return g.Hs * g.Ws <= 48; }
+
+// pixel-batched wgrad as ONE product over (position, image) with S deterministic K slices (grids of more than 4 positions)
+inline bool wgrad_joint(const ConvGeom& g) { return pixel_batched(g) && g.Hs * g.Ws > 4; }
+inline int wgrad_slices(const ConvGeom& g) {
+    const long Kd = (long)g.Cb * g.KH * g.KW, K = (long)g.Hs * g.Ws * g.N;
+    const long tiles = (long)cdiv(g.Cs, 64) * cdiv(Kd, 64);
+    for (int S = 16; S > 1; S >>= 1)
+        if (tiles * S <= 2048 && K % S == 0 && K / S >= 256) return S;
+    return 1;
+}
+
+// Yt[q][n][cs] = Ys[n][cs][q]
+__global__ __launch_bounds__(256) void small_transpose_kernel(const float* __restrict__ ys, float* __restrict__ yt,
+                                                              int N, int Cs, int Ps) {
+    const long total = (long)N * Cs * Ps;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cs = (int)(i % Cs);
+        const long r = i / Cs;
+        const int n = (int)(r % N), q = (int)(r / N);
+        yt[i] = ys[((long)n * Cs + cs) * Ps + q];
+    }
+}
 
 inline long col_floats_per_image(const ConvGeom& g) { return (long)g.Cb * g.KH * g.KW * g.Hs * g.Ws; }
 
@@ -132,7 +155,10 @@ size_t jvae_conv_generic_ws(const ConvGeom& g) {
     if (imgs < 1) imgs = 1;
     if (imgs > g.N) imgs = g.N;
     if (pixel_batched(g)) imgs = g.N;            // [q][n][k] layout is not chunked (tiny grids only)
-    return (size_t)(imgs * per);
+    size_t bytes = (size_t)(imgs * per);
+    if (wgrad_joint(g))                          // + transposed Ys + the K-slice partial products
+        bytes += 4 * ((size_t)g.N * g.Cs * g.Hs * g.Ws + (size_t)wgrad_slices(g) * g.Cs * g.Cb * g.KH * g.KW);
+    return bytes;
 }
 
 static int chunk_images(const ConvGeom& g, size_t ws_bytes) {
@@ -215,6 +241,22 @@ int jvae_fold_wgrad(const ConvGeom& g, const float* xb, const float* ys, float* 
         hipLaunchKernelGGL(unfold_kernel, dim3(grid_for((long)g.N * Kd * Ps)), dim3(256), 0, st, xb, ws, g, 0, g.N,
                            (long)Kd, 1L, (long)g.N * Kd, 1);
         JVAE_LAUNCH_CHECK();
+        if (wgrad_joint(g)) {
+            // dW[cs][k] += sum_{(q,n)} Yt[(q,n)][cs] col[(q,n)][k]: one product, K = Ps*N sliced over the batch
+            // dimension into S partial results, folded in a fixed order
+            const int S = wgrad_slices(g);
+            const long colf = (long)col_floats_per_image(g) * g.N, ytf = (long)g.N * g.Cs * Ps;
+            if (ws_bytes < 4 * (size_t)(colf + ytf + (long)S * g.Cs * Kd)) return JVAE_EWORKSPACE;
+            float* yt = ws + colf;
+            float* part = yt + ytf;
+            hipLaunchKernelGGL(small_transpose_kernel, dim3(grid_for(ytf)), dim3(256), 0, st, ys, yt, g.N, g.Cs, Ps);
+            JVAE_LAUNCH_CHECK();
+            const long Ks = (long)Ps * g.N / S;
+            int rc = jvae_gemm_launch(g.Cs, Kd, (int)Ks, S, yt, 1, g.Cs, Ks * g.Cs, ws, Kd, 1, Ks * Kd,
+                                      part, Kd, 1, (long)g.Cs * Kd, nullptr, 0, 0, 1, st);
+            if (rc) return rc;
+            return jvae_splitk_fold(part, nullptr, dw, S, (long)g.Cs * Kd, Kd, 0, 1, st);
+        }
         // dW[cs][k] += sum_q sum_n Ys[n][cs][q] col_q[n][k]: one accumulating product per folded position, in order
         // (deterministic: no float atomics)
         for (int q = 0; q < Ps; ++q) {

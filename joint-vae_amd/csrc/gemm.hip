@@ -248,22 +248,29 @@ int jvae_gemm_launch_ex(int M, int N, int K, int batch,
 // y[i] = [relu](bias[i % N] + sum_s part[s][i]) in a fixed order: the deterministic second half of a split-K product
 // whose S partial products were written side by side by a batched launch (batch = K slices).
 __global__ __launch_bounds__(256) void splitk_fold_kernel(const float* __restrict__ part, const float* __restrict__ bias,
-                                                          float* __restrict__ y, int S, long MN, int N, int relu) {
+                                                          float* __restrict__ y, int S, long MN, int N, int relu,
+                                                          int accumulate) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < MN; i += (long)gridDim.x * blockDim.x) {
         float v = bias ? bias[i % N] : 0.f;
         for (int s = 0; s < S; ++s) v += part[(long)s * MN + i];
+        if (accumulate) v += y[i];
         y[i] = relu ? fmaxf(v, 0.f) : v;
     }
+}
+
+int jvae_splitk_fold(const float* part, const float* bias, float* y, int S, long MN, int N, int relu, int accumulate,
+                     hipStream_t st) {
+    if (MN == 0) return 0;
+    const int blocks = (int)((MN + 255) / 256 > 4096 ? 4096 : (MN + 255) / 256);
+    hipLaunchKernelGGL(splitk_fold_kernel, dim3(blocks), dim3(256), 0, st, part, bias, y, S, MN, N, relu, accumulate);
+    JVAE_LAUNCH_CHECK();
+    return 0;
 }
 
 extern "C" int jvae_splitk_fold_f32(const float* part, const float* bias, float* y, int S, long MN, int N, int relu,
                                     void* stream) {
     if (!part || !y || S < 1 || MN < 0 || N < 1) return JVAE_EINVAL;
-    if (MN == 0) return 0;
-    const int blocks = (int)((MN + 255) / 256 > 4096 ? 4096 : (MN + 255) / 256);
-    hipLaunchKernelGGL(splitk_fold_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, part, bias, y, S, MN, N, relu);
-    JVAE_LAUNCH_CHECK();
-    return 0;
+    return jvae_splitk_fold(part, bias, y, S, MN, N, relu, 0, (hipStream_t)stream);
 }
 
 extern "C" int jvae_gemm_f32(int M, int N, int K, int batch,

@@ -17,6 +17,10 @@ int jvae_gemm_launch_ex(int M, int N, int K, int batch,
                         float* C, long sCm, long sCn, long sCb,
                         const float* bias, int bias_mode, int bias_div, int flags, int splitk, hipStream_t st);
 
+// y[i] = [relu]([y[i] +] bias[i % N] + sum_s part[s][i]): fixed-order fold of S partial products (gemm.hip)
+int jvae_splitk_fold(const float* part, const float* bias, float* y, int S, long MN, int N, int relu, int accumulate,
+                     hipStream_t st);
+
 // Geometry of one (transposed) convolution.  "big" side = the tensor that is unfolded (conv input /
 // transposed-conv output), "small" side = the tensor on the folded grid (conv output / transposed-conv input).
 struct ConvGeom {

@@ -130,6 +130,28 @@ def test_linear(act):
     assert rel(xd.grad, xr.grad) < 2e-5 and rel(wd.grad, wr.grad) < 2e-5 and rel(bd.grad, br.grad) < 2e-5
 
 
+@pytest.mark.parametrize('cin,cout,k,s,p,op,tr,H', [(128, 200, 3, 1, 0, 0, False, 8), (8, 128, 4, 1, 0, 0, True, 5)])
+def test_small_grid_wgrad_joint_product(cin, cout, k, s, p, op, tr, H):
+    """6x6 / 5x5 folded grids (heads of conv32+ / deconv32+) at a batch where the weight gradient runs as one product
+    over (position, image) with deterministic K slices: against PyTorch, and run-to-run identical."""
+    from jvae_hip import ops
+    N = 64
+    g = torch.Generator().manual_seed(cin + cout)
+    x = torch.randn(N, cin, H, H, generator=g)
+    wshape = (cin, cout, k, k) if tr else (cout, cin, k, k)
+    w = (torch.randn(wshape, generator=g) / math.sqrt(cin * k * k)).requires_grad_(True)
+    b = torch.randn(cout, generator=g).requires_grad_(True)
+    yr = F.conv_transpose2d(x, w, b, stride=s, padding=p, output_padding=op) if tr else F.conv2d(x, w, b, stride=s, padding=p)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    spec = ops.ConvSpec(cin, cout, k, s, p, op, tr)
+    gw1, gb1 = ops.conv_wgrad_raw(x.to(DEV), gy.to(DEV), spec, wshape, True)
+    gw2, _ = ops.conv_wgrad_raw(x.to(DEV), gy.to(DEV), spec, wshape, True)
+    assert rel(gw1, w.grad) < 3e-5 and rel(gb1, b.grad) < 3e-5
+    assert torch.equal(gw1, gw2)
+    assert rel(ops.conv_fwd_raw(x.to(DEV), w.detach().to(DEV), b.detach().to(DEV), spec), yr) < 3e-5
+
+
 @pytest.mark.parametrize('act', [0, 1])
 def test_linear_split_k(act):
     """Dense head of the 64x64 model (256 x 7200 -> 200): too few output tiles, so K is sliced over the batch dimension
