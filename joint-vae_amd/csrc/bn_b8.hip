@@ -76,65 +76,59 @@ __global__ __launch_bounds__(256) void bn8_stats_kernel(const bf16x8* __restrict
         }
 }
 
-// forward apply: block (cb, chunk j) folds the partial sums of its 8 channels (32 threads per channel, fp64), chunk 0
-// publishes mean / invstd and updates the running statistics; then y = [relu](x*scale + shift) in bf16.
-__global__ __launch_bounds__(256) void bn8_apply_kernel(const bf16x8* __restrict__ x, const float* __restrict__ partial,
-                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                        float* running_mean, float* running_var, long long* num_batches_tracked,
-                                                        float* save_mean, float* save_invstd, bf16x8* __restrict__ y,
-                                                        int N, int C, int CB, long HW, int nsplit, int nchunk, float momentum,
-                                                        float eps, int training, int relu, int ext_pivot,
-                                                        const float* __restrict__ pivot) {
-    __shared__ float cs[2][8];
-    const int cb = blockIdx.x, j = blockIdx.y;
-    const int ci_t = threadIdx.x >> 5, l = threadIdx.x & 31;      // 8 groups of 32 threads: one channel each
-    const int c_t = cb * 8 + ci_t;
-    if (training) {
-        double s1 = 0., s2 = 0.;
-        if (c_t < C)
-            for (int s = l; s < nsplit; s += 32) {
-                s1 += (double)partial[((long)c_t * nsplit + s) * 2 + 0];
-                s2 += (double)partial[((long)c_t * nsplit + s) * 2 + 1];
+// coefficients of one channel per block: folds the partial sums (fp64, fixed order), publishes mean / invstd, updates
+// the running statistics and writes coef[c] = scale, coef[C8 + c] = shift (0 for padding channels)
+__global__ __launch_bounds__(64) void bn8_finalize_kernel(const bf16x8* __restrict__ x, const float* __restrict__ partial,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float* running_mean, float* running_var, long long* num_batches_tracked,
+                                                          float* save_mean, float* save_invstd, float* __restrict__ coef,
+                                                          int N, int C, int C8, long HW, int nsplit, float momentum, float eps,
+                                                          int training, int ext_pivot, const float* __restrict__ pivot) {
+    const int c = blockIdx.x, l = threadIdx.x;
+    float sc = 0.f, sh = 0.f;
+    if (c < C) {
+        const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+        if (training) {
+            double s1 = 0., s2 = 0.;
+            for (int s = l; s < nsplit; s += 64) {
+                s1 += (double)partial[((long)c * nsplit + s) * 2 + 0];
+                s2 += (double)partial[((long)c * nsplit + s) * 2 + 1];
             }
 #pragma unroll
-        for (int o = 16; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
-        if (l == 0) {
-            float sc = 0.f, sh = 0.f;
-            if (c_t < C) {
-                const float g = gamma ? gamma[c_t] : 1.f, b = beta ? beta[c_t] : 0.f;
-                const double n = (double)N * HW;
-                const double dm = s1 / n;
-                double var = s2 / n - dm * dm;
-                if (var < 0.) var = 0.;
-                const double pv = ext_pivot ? (pivot ? (double)pivot[c_t] : 0.) : (double)(float)x[(long)cb * HW][ci_t];
-                const float mean = (float)(pv + dm);
-                const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-                if (j == 0) {
-                    save_mean[c_t] = mean;
-                    save_invstd[c_t] = invstd;
-                    if (running_mean) running_mean[c_t] = (1.f - momentum) * running_mean[c_t] + momentum * mean;
-                    if (running_var) {
-                        const float unbiased = (float)(n > 1. ? var * n / (n - 1.) : var);
-                        running_var[c_t] = (1.f - momentum) * running_var[c_t] + momentum * unbiased;
-                    }
-                    if (c_t == 0 && num_batches_tracked) *num_batches_tracked += 1;
+            for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+            const double n = (double)N * HW;
+            const double dm = s1 / n;
+            double var = s2 / n - dm * dm;
+            if (var < 0.) var = 0.;
+            const double pv = ext_pivot ? (pivot ? (double)pivot[c] : 0.) : (double)(float)x[(long)(c >> 3) * HW][c & 7];
+            const float mean = (float)(pv + dm);
+            const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+            if (l == 0) {
+                save_mean[c] = mean;
+                save_invstd[c] = invstd;
+                if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+                if (running_var) {
+                    const float unbiased = (float)(n > 1. ? var * n / (n - 1.) : var);
+                    running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
                 }
-                bn_coef(g, b, mean, invstd, &sc, &sh);
+                if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;
             }
-            cs[0][ci_t] = sc; cs[1][ci_t] = sh;
+            bn_coef(g, b, mean, invstd, &sc, &sh);
+        } else {
+            bn_coef(g, b, running_mean[c], rsqrtf(running_var[c] + eps), &sc, &sh);
         }
-    } else if (l == 0) {
-        float sc = 0.f, sh = 0.f;
-        if (c_t < C) {
-            const float g = gamma ? gamma[c_t] : 1.f, b = beta ? beta[c_t] : 0.f;
-            bn_coef(g, b, running_mean[c_t], rsqrtf(running_var[c_t] + eps), &sc, &sh);
-        }
-        cs[0][ci_t] = sc; cs[1][ci_t] = sh;
     }
-    __syncthreads();
+    if (l == 0) { coef[c] = sc; coef[C8 + c] = sh; }
+}
+
+// y = [relu](x*scale + shift) in bf16; block (cb, chunk j)
+__global__ __launch_bounds__(256) void bn8_apply_kernel(const bf16x8* __restrict__ x, const float* __restrict__ coef,
+                                                        bf16x8* __restrict__ y, int N, int CB, long HW, int nchunk, int relu) {
+    const int cb = blockIdx.x, j = blockIdx.y;
+    const int C8 = CB * 8;
     float sc[8], sh[8];
 #pragma unroll
-    for (int ci = 0; ci < 8; ++ci) { sc[ci] = cs[0][ci]; sh[ci] = cs[1][ci]; }
+    for (int ci = 0; ci < 8; ++ci) { sc[ci] = coef[cb * 8 + ci]; sh[ci] = coef[C8 + cb * 8 + ci]; }
     const int per = (N + nchunk - 1) / nchunk;
     const int nb = j * per, ne = min(N, nb + per);
     const unsigned cnt = (unsigned)((long)(ne - nb) * HW);
@@ -198,36 +192,38 @@ __global__ __launch_bounds__(256) void bn8_bwd_reduce_kernel(const bf16x8* __res
         }
 }
 
+// per channel: means of (g, g*xhat) over the batch -> coef[c], coef[C8 + c]; dgamma / dbeta (+)= the sums
+__global__ __launch_bounds__(64) void bn8_bwd_finalize_kernel(const float* __restrict__ partial, float* __restrict__ coef,
+                                                              float* dgamma, float* dbeta, int accumulate,
+                                                              int N, int C, int C8, long HW, int nsplit) {
+    const int c = blockIdx.x, l = threadIdx.x;
+    double s1 = 0., s2 = 0.;
+    if (c < C)
+        for (int s = l; s < nsplit; s += 64) {
+            s1 += (double)partial[((long)c * nsplit + s) * 2 + 0];
+            s2 += (double)partial[((long)c * nsplit + s) * 2 + 1];
+        }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+    if (l == 0) {
+        const double M = (double)N * HW;
+        coef[c] = (float)(s1 / M);
+        coef[C8 + c] = (float)(s2 / M);
+        if (c < C) {
+            if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s1;
+            if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)s2;
+        }
+    }
+}
+
+// dx = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)) in bf16
 __global__ __launch_bounds__(256) void bn8_bwd_apply_kernel(const bf16x8* __restrict__ dy, const bf16x8* __restrict__ x,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                            const float* __restrict__ partial, bf16x8* __restrict__ dx,
-                                                            float* dgamma, float* dbeta, int accumulate,
-                                                            int N, int C, int CB, long HW, int nsplit, int nchunk, int relu) {
-    __shared__ float ms[2][8];
+                                                            const float* __restrict__ coef, bf16x8* __restrict__ dx,
+                                                            int N, int C, int CB, long HW, int nchunk, int relu) {
     const int cb = blockIdx.x, j = blockIdx.y;
-    {
-        const int ci_t = threadIdx.x >> 5, l = threadIdx.x & 31;      // 32 threads fold one channel (fixed order, fp64)
-        const int c = cb * 8 + ci_t;
-        double s1 = 0., s2 = 0.;
-        if (c < C)
-            for (int s = l; s < nsplit; s += 32) {
-                s1 += (double)partial[((long)c * nsplit + s) * 2 + 0];
-                s2 += (double)partial[((long)c * nsplit + s) * 2 + 1];
-            }
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
-        if (l == 0) {
-            const double M = (double)N * HW;
-            ms[0][ci_t] = (float)(s1 / M);
-            ms[1][ci_t] = (float)(s2 / M);
-            if (j == 0 && c < C) {
-                if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s1;
-                if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)s2;
-            }
-        }
-    }
-    __syncthreads();
+    const int C8 = CB * 8;
     float mu[8], is[8], sc[8], sh[8], k[8], m1[8], m2[8];
 #pragma unroll
     for (int ci = 0; ci < 8; ++ci) {
@@ -237,7 +233,7 @@ __global__ __launch_bounds__(256) void bn8_bwd_apply_kernel(const bf16x8* __rest
         is[ci] = c < C ? invstd[c] : 0.f;
         bn_coef(g_, c < C && beta ? beta[c] : 0.f, mu[ci], is[ci], &sc[ci], &sh[ci]);
         k[ci] = g_ * is[ci];
-        m1[ci] = ms[0][ci]; m2[ci] = ms[1][ci];
+        m1[ci] = coef[c]; m2[ci] = coef[C8 + c];
     }
     const int per = (N + nchunk - 1) / nchunk;
     const int nb = j * per, ne = min(N, nb + per);
@@ -302,7 +298,8 @@ inline int pick_chunk(int N, int CB, long HW) {
 
 extern "C" {
 
-size_t jvae_bn_workspace_bytes_b8(int C) { return sizeof(float) * ((size_t)2 * ((C + 7) / 8 * 8) * MAX_SPLIT + (size_t)2 * C); }
+// partial sums (2 * C8 * MAX_SPLIT floats) followed by 2 * C8 per-channel coefficients
+size_t jvae_bn_workspace_bytes_b8(int C) { return sizeof(float) * ((size_t)2 * ((C + 7) / 8 * 8) * (MAX_SPLIT + 1)); }
 
 // x, y: B8 (N, ceil(C/8), HW, 8).  Workspace: jvae_bn_workspace_bytes_b8(C).  ext_stats as in jvae_bn_fwd_ext_f32
 // (ext_nsplit == 0: the statistics kernel runs here).
@@ -331,10 +328,14 @@ int jvae_bn_fwd_b8(const void* x, const float* gamma, const float* beta,
     } else if (!running_mean || !running_var) {
         return JVAE_EINVAL;
     }
+    float* coef = (float*)ws + (size_t)2 * CB * 8 * MAX_SPLIT;
+    hipLaunchKernelGGL(bn8_finalize_kernel, dim3(CB * 8), dim3(64), 0, st, (const bf16x8*)x, partial, gamma, beta,
+                       running_mean, running_var, num_batches_tracked, save_mean, save_invstd, coef, N, C, CB * 8, HW, ns,
+                       momentum, eps, training, ext ? 1 : 0, ext_pivot);
+    JVAE_LAUNCH_CHECK();
     const int nc = pick_chunk(N, CB, HW);
-    hipLaunchKernelGGL(bn8_apply_kernel, dim3(CB, nc), dim3(256), 0, st, (const bf16x8*)x, partial, gamma, beta,
-                       running_mean, running_var, num_batches_tracked, save_mean, save_invstd, (bf16x8*)y,
-                       N, C, CB, HW, ns, nc, momentum, eps, training, relu, ext ? 1 : 0, ext_pivot);
+    hipLaunchKernelGGL(bn8_apply_kernel, dim3(CB, nc), dim3(256), 0, st, (const bf16x8*)x, (const float*)coef, (bf16x8*)y,
+                       N, CB, HW, nc, relu);
     JVAE_LAUNCH_CHECK();
     return 0;
 }
@@ -353,9 +354,13 @@ int jvae_bn_bwd_b8(const void* dy, const void* x, const float* gamma, const floa
     hipLaunchKernelGGL(bn8_bwd_reduce_kernel, dim3(CB, ns), dim3(256), 0, st, (const bf16x8*)dy, (const bf16x8*)x, gamma, beta,
                        save_mean, save_invstd, partial, N, C, CB, HW, ns, relu);
     JVAE_LAUNCH_CHECK();
+    float* coef = partial + (size_t)2 * CB * 8 * MAX_SPLIT;
+    hipLaunchKernelGGL(bn8_bwd_finalize_kernel, dim3(CB * 8), dim3(64), 0, st, (const float*)partial, coef, dgamma, dbeta,
+                       accumulate, N, C, CB * 8, HW, ns);
+    JVAE_LAUNCH_CHECK();
     const int nc = pick_chunk(N, CB, HW);
     hipLaunchKernelGGL(bn8_bwd_apply_kernel, dim3(CB, nc), dim3(256), 0, st, (const bf16x8*)dy, (const bf16x8*)x, gamma, beta,
-                       save_mean, save_invstd, partial, (bf16x8*)dx, dgamma, dbeta, accumulate, N, C, CB, HW, ns, nc, relu);
+                       save_mean, save_invstd, (const float*)coef, (bf16x8*)dx, N, C, CB, HW, nc, relu);
     JVAE_LAUNCH_CHECK();
     return 0;
 }
