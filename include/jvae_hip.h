@@ -37,10 +37,11 @@ int jvae_gemm_f32(int M, int N, int K, int batch,
                   float* C, long sCm, long sCn, long sCb,
                   const float* bias, int bias_mode, int flags, int splitk, void* stream);
 
-/* y[i] = [relu](bias[i % N] + sum_{s<S} part[s][i]), i < MN: deterministic fold of a split-K product whose K slices were
+/* y[i] = [relu]([y[i] +] bias[i % N] + sum_{s<S} part[s][i]), i < MN (bias may be NULL): deterministic fold of a split-K product whose K slices were
  * computed by one batched jvae_gemm_f32 launch (used by the dense heads when M*N gives too few tiles, e.g. 256 x 200
  * with K = 7200 in the 64x64 model). */
-int jvae_splitk_fold_f32(const float* part, const float* bias, float* y, int S, long MN, int N, int relu, void* stream);
+int jvae_splitk_fold_f32(const float* part, const float* bias, float* y, int S, long MN, int N, int relu, int accumulate,
+                         void* stream);
 
 /* ---- (transposed) convolution ---------------------------------------------------------------------
  * x: (N,Cin,H,W) layer input; y: (N,Cout,OH,OW) layer output; w in the PyTorch layout of the layer kind

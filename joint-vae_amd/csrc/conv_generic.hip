@@ -122,8 +122,8 @@ inline int grid_for(long total) {
 // (also the 6x6 / 5x5 grids of conv32+ / deconv32+: 36 / 25 positions)
 inline bool pixel_batched(const ConvGeom& g) { return g.Hs * g.Ws <= 48; }
 
-// pixel-batched wgrad as ONE product over (position, image) with S deterministic K slices (grids of more than 4 positions)
-inline bool wgrad_joint(const ConvGeom& g) { return pixel_batched(g) && g.Hs * g.Ws > 4; }
+// pixel-batched wgrad as ONE product over (position, image) with S deterministic K slices
+inline bool wgrad_joint(const ConvGeom& g) { return pixel_batched(g) && g.Hs * g.Ws > 1; }
 inline int wgrad_slices(const ConvGeom& g) {
     const long Kd = (long)g.Cb * g.KH * g.KW, K = (long)g.Hs * g.Ws * g.N;
     const long tiles = (long)cdiv(g.Cs, 64) * cdiv(Kd, 64);

@@ -268,9 +268,9 @@ int jvae_splitk_fold(const float* part, const float* bias, float* y, int S, long
 }
 
 extern "C" int jvae_splitk_fold_f32(const float* part, const float* bias, float* y, int S, long MN, int N, int relu,
-                                    void* stream) {
+                                    int accumulate, void* stream) {
     if (!part || !y || S < 1 || MN < 0 || N < 1) return JVAE_EINVAL;
-    return jvae_splitk_fold(part, bias, y, S, MN, N, relu, 0, (hipStream_t)stream);
+    return jvae_splitk_fold(part, bias, y, S, MN, N, relu, accumulate, (hipStream_t)stream);
 }
 
 extern "C" int jvae_gemm_f32(int M, int N, int K, int batch,

@@ -66,7 +66,7 @@ def channel_sum(t, N, C, P, out=None, accumulate=False):
 def _linear_split(R, O, I):
     """K slices for y = x W^T when the (R, O) output alone cannot fill the chip (64x64 tiles, 256 CUs)."""
     tiles = ((R + 63) // 64) * ((O + 63) // 64)
-    if tiles >= 128 or I < 2048:
+    if tiles >= 128 or I < 512:
         return 1
     for S in (32, 16, 8, 4, 2):
         if tiles * S <= 1024 and I % S == 0 and I // S >= 128:
@@ -91,7 +91,7 @@ class _Linear(torch.autograd.Function):
             part = torch.empty((S, R, O), device=x.device, dtype=torch.float32)
             Ks = I // S
             gemm(R, O, Ks, x2, (I, 1, Ks), w, (1, I, Ks), part, (O, 1, R * O), batch=S)
-            L.check(L.load().jvae_splitk_fold_f32(L.ptr(part), L.ptr(b), L.ptr(y), S, R * O, O, int(act == RELU),
+            L.check(L.load().jvae_splitk_fold_f32(L.ptr(part), L.ptr(b), L.ptr(y), S, R * O, O, int(act == RELU), 0,
                                                   L.stream_ptr()), 'jvae_splitk_fold_f32')
         else:
             gemm(R, O, I, x2, (I, 1, 0), w, (1, I, 0), y, (O, 1, 0), bias=b, bias_mode=1 if b is not None else 0,
@@ -124,7 +124,15 @@ class _Linear(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             slot = _grad_slot(ctx.w_ref)
             gw = slot if slot is not None else torch.zeros((O, I), device=gy.device, dtype=torch.float32)
-            gemm(O, I, R, gy, (1, O, 0), x2, (I, 1, 0), gw, (I, 1, 0), flags=1)      # no split-K: deterministic
+            S = _linear_split(O, I, R)
+            if S > 1:           # few (O, I) tiles: batch rows sliced over the launch's batch dimension, fixed-order fold
+                part = torch.empty((S, O, I), device=gy.device, dtype=torch.float32)
+                Rs = R // S
+                gemm(O, I, Rs, gy, (1, O, Rs * O), x2, (I, 1, Rs * I), part, (I, 1, O * I), batch=S)
+                L.check(lib.jvae_splitk_fold_f32(L.ptr(part), None, L.ptr(gw), S, O * I, I, 0, 1, L.stream_ptr()),
+                        'jvae_splitk_fold_f32')
+            else:
+                gemm(O, I, R, gy, (1, O, 0), x2, (I, 1, 0), gw, (I, 1, 0), flags=1)      # no atomics: deterministic
             if slot is not None:
                 gw = None
         if ctx.has_bias and ctx.needs_input_grad[2]:

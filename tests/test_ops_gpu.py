@@ -157,7 +157,7 @@ def test_linear_split_k(act):
     """Dense head of the 64x64 model (256 x 7200 -> 200): too few output tiles, so K is sliced over the batch dimension
     of one GEMM launch and folded in a fixed order; must agree with the plain product and be run-to-run identical."""
     from jvae_hip import ops
-    assert ops._linear_split(256, 200, 7200) > 1 and ops._linear_split(512, 64, 800) == 1
+    assert ops._linear_split(256, 200, 7200) > 1 and ops._linear_split(512, 64, 64) == 1
     g = torch.Generator().manual_seed(5 + act)
     x = torch.randn(256, 7200, generator=g)
     w = torch.randn(200, 7200, generator=g) / 85
@@ -169,6 +169,15 @@ def test_linear_split_k(act):
     y2 = ops.linear(xd, wd, bd, act)
     assert rel(y1, yr) < 2e-5
     assert torch.equal(y1, y2)
+    # backward through the sliced products (weight gradient: K = rows)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr2 = F.linear(xr, wr, b)
+    yr2 = torch.relu(yr2) if act else yr2
+    gy = torch.randn(yr2.shape, generator=g)
+    yr2.backward(gy)
+    xd2, wd2 = xd.clone().requires_grad_(True), wd.clone().requires_grad_(True)
+    ops.linear(xd2, wd2, bd, act).backward(gy.to(DEV))
+    assert rel(xd2.grad, xr.grad) < 2e-5 and rel(wd2.grad, wr.grad) < 2e-5
 
 
 @pytest.mark.parametrize('prior,var_dim', [('gaussian', 'scalar'), ('gaussian', 'diag'), ('gaussian', 'full'),
