@@ -148,22 +148,29 @@ __global__ __launch_bounds__(256, 2) void conv5_fwd_kernel(FwdP p) {
         lstore();
         __syncthreads();
         if (c0 + CC < p.Cin) gload(c0 + CC);
+        // operand fragments of step j+1 are read from LDS before the MFMAs of step j are issued (explicit one-deep
+        // software pipeline: the LDS latency hides under MT*NT MFMAs instead of stalling in front of them)
+        constexpr int STEPS = (CC / 2) * 25;
+        float a[2][NT], b[2][MT];
+        auto frag = [&](int j, float (&fa)[NT], float (&fb)[MT]) {
+            const int cp = j / 25, tap = j % 25;
+            const int kh = tap / 5, kw = tap % 5;
 #pragma unroll
-        for (int cp = 0; cp < CC / 2; ++cp) {
+            for (int nt = 0; nt < NT; ++nt) fa[nt] = Ws[((cp * 2 + half) * 25 + tap) * G::WCOLS + nt * 32 + l31];
 #pragma unroll
-            for (int tap = 0; tap < 25; ++tap) {
-                const int kh = tap / 5, kw = tap % 5;
-                float a[NT], b[MT];
+            for (int mt = 0; mt < MT; ++mt) fb[mt] = Xs[pixoff[mt] + (cp * 2) * G::CH + kh * G::WP + kw];
+        };
+        frag(0, a[0], b[0]);
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) a[nt] = Ws[((cp * 2 + half) * 25 + tap) * G::WCOLS + nt * 32 + l31];
+        for (int j = 0; j < STEPS; ++j) {
+            if (j + 1 < STEPS) frag(j + 1, a[(j + 1) & 1], b[(j + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);                 // keep the reads of step j+1 ahead of the MFMAs of step j
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) b[mt] = Xs[pixoff[mt] + (cp * 2) * G::CH + kh * G::WP + kw];
+            for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-                        acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[nt], b[mt], acc[nt][mt], 0, 0, 0);
-            }
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j & 1][nt], b[j & 1][mt], acc[nt][mt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 
