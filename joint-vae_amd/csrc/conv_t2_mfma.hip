@@ -125,27 +125,38 @@ __global__ __launch_bounds__(256, 2) void convt2_kernel(T2P p) {
         }
         __syncthreads();
         if (c0 + CC < p.C) gload(c0 + CC);
-#pragma unroll
-        for (int cp = 0; cp < CC / 2; ++cp) {
-            float nb[3][3];                                       // 3x3 neighbourhood of this lane's pixel
+        // one-deep software pipeline: the weight fragment of step j+1 (and, mid-way through a channel pair, the 3x3
+        // neighbourhood of the next pair) is read from LDS before the MFMA of step j is issued
+        constexpr int STEPS = (CC / 2) * 25;
+        float nb[2][3][3], wa[2][NT];
+        auto load_nb = [&](int cp, float (&d)[3][3]) {
 #pragma unroll
             for (int dh = -1; dh <= 1; ++dh)
 #pragma unroll
                 for (int dw = -1; dw <= 1; ++dw)
-                    nb[dh + 1][dw + 1] = Xs[pixoff + (cp * 2) * G::CH + dh * G::WP + dw];
+                    d[dh + 1][dw + 1] = Xs[pixoff + (cp * 2) * G::CH + dh * G::WP + dw];
+        };
+        auto load_w = [&](int j, float (&d)[NT]) {
+            const int cp = j / 25, tap = j % 25;
 #pragma unroll
-            for (int kh = 0; kh < 5; ++kh)
+            for (int t = 0; t < NT; ++t) d[t] = Ws[((cp * 2 + half) * 25 + tap) * G::WCOLS + t * 32 + l31];
+        };
+        load_nb(0, nb[0]);
+        load_w(0, wa[0]);
 #pragma unroll
-                for (int kw = 0; kw < 5; ++kw) {
-                    const int r = kh & 1, q = kw & 1;
-                    const int dh = (r + 2 - kh) / 2, dw = (q + 2 - kw) / 2;
-                    const float b = nb[dh + 1][dw + 1];
+        for (int j = 0; j < STEPS; ++j) {
+            const int cp = j / 25, tap = j % 25;
+            const int kh = tap / 5, kw = tap % 5;
+            if (j + 1 < STEPS) load_w(j + 1, wa[(j + 1) & 1]);
+            if (tap == 12 && cp + 1 < CC / 2) load_nb(cp + 1, nb[(cp + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            const int r = kh & 1, q = kw & 1;
+            const int dh = (r + 2 - kh) / 2, dw = (q + 2 - kw) / 2;
+            const float b = nb[cp & 1][dh + 1][dw + 1];
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) {
-                        const float a = Ws[((cp * 2 + half) * 25 + kh * 5 + kw) * G::WCOLS + t * 32 + l31];
-                        acc[r][q][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[r][q][t], 0, 0, 0);
-                    }
-                }
+            for (int t = 0; t < NT; ++t)
+                acc[r][q][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[j & 1][t], b, acc[r][q][t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 
