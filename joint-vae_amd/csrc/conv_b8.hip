@@ -242,21 +242,29 @@ __global__ __launch_bounds__(256, 2) void conv5_b8_kernel(B8FwdP p) {
         lstore();
         __syncthreads();
         if (kb + 1 < KB) gload(kb + 1);
+        // one-deep software pipeline: the fragments of tap t+1 are read from LDS before the MFMAs of tap t are issued
+        // (a 32-cycle bf16 MFMA leaves no slack for an LDS round trip in front of it)
+        u32x4 fa[2][NT], fb[2][MT];
+        auto frag = [&](int tap, u32x4 (&a)[NT], u32x4 (&b)[MT]) {
+            const int kh = tap / 5, kw = tap % 5;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) a[nt] = Ws[(tap * 2 + half) * G::WCOLS + nt * 32 + l31];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) b[mt] = Xs[pixoff[mt] + kh * G::WP + kw];
+        };
+        frag(0, fa[0], fb[0]);
 #pragma unroll
         for (int tap = 0; tap < 25; ++tap) {
-            const int kh = tap / 5, kw = tap % 5;
-            bf16x8 a[NT], b[MT];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-                a[nt] = __builtin_bit_cast(bf16x8, Ws[(tap * 2 + half) * G::WCOLS + nt * 32 + l31]);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-                b[mt] = __builtin_bit_cast(bf16x8, Xs[pixoff[mt] + kh * G::WP + kw]);
+            if (tap + 1 < 25) frag(tap + 1, fa[(tap + 1) & 1], fb[(tap + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
-                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[nt], b[mt], acc[nt][mt], 0, 0, 0);
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[tap & 1][nt]),
+                                                                          __builtin_bit_cast(bf16x8, fb[tap & 1][mt]),
+                                                                          acc[nt][mt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 

@@ -128,15 +128,21 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void convt2_b8_kernel(T2B
 #pragma unroll
             for (int dw = -1; dw <= 1; ++dw)
                 nb[dh + 1][dw + 1] = __builtin_bit_cast(bf16x8, Xs[pixoff + dh * G::WP + dw]);
+        // weight fragments two taps ahead of the MFMA that consumes them (32-cycle MFMAs: an LDS round trip is ~2 of them)
+        u32x4 wa[3];
+        wa[0] = Ws[(0 * 2 + half) * 32 + l31];
+        wa[1] = Ws[(1 * 2 + half) * 32 + l31];
 #pragma unroll
-        for (int kh = 0; kh < 5; ++kh)
-#pragma unroll
-            for (int kw = 0; kw < 5; ++kw) {
-                const int r = kh & 1, q = kw & 1;
-                const int dh = (r + 2 - kh) / 2, dw = (q + 2 - kw) / 2;
-                const bf16x8 a = __builtin_bit_cast(bf16x8, Ws[((kh * 5 + kw) * 2 + half) * 32 + l31]);
-                acc[r][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, nb[dh + 1][dw + 1], acc[r][q], 0, 0, 0);
-            }
+        for (int tap = 0; tap < 25; ++tap) {
+            const int kh = tap / 5, kw = tap % 5;
+            if (tap + 2 < 25) wa[(tap + 2) % 3] = Ws[((tap + 2) * 2 + half) * 32 + l31];
+            __builtin_amdgcn_sched_barrier(0);
+            const int r = kh & 1, q = kw & 1;
+            const int dh = (r + 2 - kh) / 2, dw = (q + 2 - kw) / 2;
+            acc[r][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wa[tap % 3]), nb[dh + 1][dw + 1],
+                                                                acc[r][q], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 
     if (p.stats) {
