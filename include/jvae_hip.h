@@ -95,6 +95,28 @@ int jvae_bn_bwd_f32(const float* dy, const float* x, const float* gamma, const f
                     float* dx, float* dgamma, float* dbeta, int accumulate,
                     int N, int C, int P, int relu, void* ws, size_t ws_bytes, void* stream);
 
+/* Deferred BatchNorm: statistics + per-channel coefficients only (scale, shift: C floats each, y = fmaf(x, scale, shift));
+ * the normalisation (+ReLU) itself is applied by the CONSUMING convolution while it stages its input
+ * (jvae_conv2d_fwd_aff_f32 / jvae_conv2d_wgrad_aff_f32), so the normalised activation is never written to HBM.  Backward
+ * is the ordinary jvae_bn_bwd_f32.  Statistics arguments as jvae_bn_fwd_ext_f32 (ext_nsplit == 0: own statistics pass). */
+int jvae_bn_finalize_f32(const float* x, const float* gamma, const float* beta,
+                         float* running_mean, float* running_var, long long* num_batches_tracked,
+                         float* save_mean, float* save_invstd, float* scale, float* shift,
+                         int N, int C, int P, float momentum, float eps, int training,
+                         const float* ext_stats, int ext_nsplit, const float* ext_pivot,
+                         void* ws, size_t ws_bytes, void* stream);
+/* 1 when both the forward and the weight gradient of this geometry can apply in_scale / in_shift / in_relu to the layer
+ * input (the implicit 5x5 kernels); the *_aff entry points return -2 otherwise. */
+int jvae_conv2d_affine_ok(int N, int Cin, int H, int W, int Cout, int KH, int KW, int S, int P, int OP, int transposed);
+int jvae_conv2d_fwd_aff_f32(const float* x, const float* w, const float* bias, float* y, float* stats, int* nsplit,
+                            const float* in_scale, const float* in_shift, int in_relu,
+                            int N, int Cin, int H, int W, int Cout, int KH, int KW, int S, int P, int OP, int transposed,
+                            void* ws, size_t ws_bytes, void* stream);
+int jvae_conv2d_wgrad_aff_f32(const float* x, const float* dy, float* dw, float* dbias, int accumulate,
+                              const float* in_scale, const float* in_shift, int in_relu,
+                              int N, int Cin, int H, int W, int Cout, int KH, int KW, int S, int P, int OP, int transposed,
+                              void* ws, size_t ws_bytes, void* stream);
+
 /* Synchronised BatchNorm for data-parallel ranks (no counterpart in the single-process reference, it
  * reproduces what the reference's BatchNorm2d computes on the WHOLE global batch).  Forward: jvae_bn_sums_f32 ->
  * all-reduce(SUM) of the (C,2) sums by the host -> jvae_bn_fwd_sync_f32.  Backward: jvae_bn_bwd_sums_f32 ->

@@ -132,6 +132,56 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
     }
 }
 
+// One block per channel: folds the partial sums (fp64, fixed order), publishes mean / invstd, updates the running
+// statistics and writes the coefficients of y = fmaf(x, scale, shift) - the BatchNorm itself is then applied by the
+// consuming convolution while it stages its input (InAff), so the normalised tensor never exists in HBM.
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ x, const float* __restrict__ partial,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         float* running_mean, float* running_var, long long* num_batches_tracked,
+                                                         float* save_mean, float* save_invstd,
+                                                         float* __restrict__ scale, float* __restrict__ shift,
+                                                         int N, int C, int P, int nsplit, float momentum, float eps,
+                                                         int training, int ext_pivot, const float* __restrict__ pivot) {
+    __shared__ double dred[2][4];
+    const int c = blockIdx.x, l = threadIdx.x;
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    float mean, invstd;
+    if (training) {
+        double s1 = 0., s2 = 0.;
+        for (int s = l; s < nsplit; s += 256) {
+            s1 += (double)partial[((long)c * nsplit + s) * 2 + 0];
+            s2 += (double)partial[((long)c * nsplit + s) * 2 + 1];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+        if ((l & 63) == 0) { dred[0][l >> 6] = s1; dred[1][l >> 6] = s2; }
+        __syncthreads();
+        s1 = (dred[0][0] + dred[0][1]) + (dred[0][2] + dred[0][3]);
+        s2 = (dred[1][0] + dred[1][1]) + (dred[1][2] + dred[1][3]);
+        const double n = (double)N * P;
+        const double dm = s1 / n;
+        double var = s2 / n - dm * dm;
+        if (var < 0.) var = 0.;
+        const double pv = ext_pivot ? (pivot ? (double)pivot[c] : 0.) : (double)x[(long)c * P];
+        mean = (float)(pv + dm);
+        invstd = (float)(1.0 / sqrt(var + (double)eps));
+        if (l == 0) {
+            save_mean[c] = mean;
+            save_invstd[c] = invstd;
+            if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+            if (running_var) {
+                const float unbiased = (float)(n > 1. ? var * n / (n - 1.) : var);
+                running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+            }
+            if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;
+        }
+    } else {
+        mean = running_mean[c];
+        invstd = rsqrtf(running_var[c] + eps);
+    }
+    if (l == 0) bn_coef(g, b, mean, invstd, &scale[c], &shift[c]);
+}
+
 // partial[c][s] = (sum g, sum g*xhat) with g = dy * [y > 0 if relu], xhat = (x - mean)*invstd
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -340,6 +390,39 @@ int jvae_bn_fwd_ext_f32(const float* x, const float* gamma, const float* beta,
                         void* ws, size_t ws_bytes, void* stream) {
     return bn_fwd_impl(x, gamma, beta, running_mean, running_var, num_batches_tracked, y, save_mean, save_invstd,
                        N, C, P, momentum, eps, training, relu, ext_stats, ext_nsplit, ext_pivot, 1, ws, ws_bytes, stream);
+}
+
+// Statistics + coefficients only (see bn_finalize_kernel): scale / shift (C floats each) are what the consuming
+// convolution applies to x while loading it (jvae_conv2d_fwd_aff_f32 / jvae_conv2d_wgrad_aff_f32).  The backward pass is
+// the ordinary jvae_bn_bwd_f32 on (dy = gradient w.r.t. the normalised activation, x).
+int jvae_bn_finalize_f32(const float* x, const float* gamma, const float* beta,
+                         float* running_mean, float* running_var, long long* num_batches_tracked,
+                         float* save_mean, float* save_invstd, float* scale, float* shift,
+                         int N, int C, int P, float momentum, float eps, int training,
+                         const float* ext_stats, int ext_nsplit, const float* ext_pivot,
+                         void* ws, size_t ws_bytes, void* stream) {
+    if (!x || !scale || !shift || N <= 0 || C <= 0 || P <= 0) return JVAE_EINVAL;
+    if (ws_bytes < jvae_bn_workspace_bytes(C) || !ws) return JVAE_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const float* partial = (const float*)ws;
+    int ns = 1;
+    const bool ext = training && ext_stats && ext_nsplit > 0;
+    if (training && (!save_mean || !save_invstd)) return JVAE_EINVAL;
+    if (ext) {
+        partial = ext_stats;
+        ns = ext_nsplit;
+    } else if (training) {
+        ns = pick_split(N, C, P);
+        hipLaunchKernelGGL(bn_stats_kernel, dim3(C, ns), dim3(256), 0, st, x, (float*)ws, N, C, P, ns, (const float*)nullptr);
+        JVAE_LAUNCH_CHECK();
+    } else if (!running_mean || !running_var) {
+        return JVAE_EINVAL;
+    }
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, st, x, partial, gamma, beta, running_mean, running_var,
+                       num_batches_tracked, save_mean, save_invstd, scale, shift, N, C, P, ns, momentum, eps, training,
+                       ext ? 1 : 0, ext_pivot);
+    JVAE_LAUNCH_CHECK();
+    return 0;
 }
 
 int jvae_bn_bwd_f32(const float* dy, const float* x, const float* gamma, const float* beta,

@@ -49,3 +49,11 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
     __syncthreads();
     return red[16];
 }
+
+// a = [relu](v*s + t) on a float4 (deferred BatchNorm of a convolution input; the same fmaf as bn_coef / bn_apply_kernel,
+// so the ReLU mask BatchNorm-backward recomputes is the one applied here)
+__device__ __forceinline__ f32x4 aff4(f32x4 v, float s, float t, int relu) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const float x = fmaf(v[j], s, t); v[j] = relu ? fmaxf(x, 0.f) : x; }
+    return v;
+}

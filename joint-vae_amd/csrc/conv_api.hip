@@ -76,6 +76,56 @@ int jvae_conv2d_fwd_stats_f32(const float* x, const float* w, const float* bias,
     return jvae_conv_fwd(g, transposed, x, w, bias, y, (float*)ws, ws_bytes, (hipStream_t)stream, stats, nsplit);
 }
 
+// ---- deferred BatchNorm on the layer input (DESIGN.md "Streams, fusion"): a = [relu](x*in_scale[c] + in_shift[c]) is
+// applied while the kernel stages x, for the layers whose forward AND weight gradient run on the implicit kernels.
+int jvae_conv2d_affine_ok(int N, int Cin, int H, int W, int Cout, int KH, int KW, int S, int P, int OP, int transposed) {
+    ConvGeom g; int oh, ow;
+    if (!make_geom(N, Cin, H, W, Cout, KH, KW, S, P, OP, transposed, &g, &oh, &ow)) return 0;
+    return jvae_conv_affine_ok(g, transposed) ? 1 : 0;
+}
+
+int jvae_conv2d_fwd_aff_f32(const float* x, const float* w, const float* bias, float* y, float* stats, int* nsplit,
+                            const float* in_scale, const float* in_shift, int in_relu,
+                            int N, int Cin, int H, int W, int Cout, int KH, int KW, int S, int P, int OP, int transposed,
+                            void* ws, size_t ws_bytes, void* stream) {
+    ConvGeom g; int oh, ow;
+    if (!x || !w || !y || !in_scale || !in_shift) return JVAE_EINVAL;
+    if (stats && !nsplit) return JVAE_EINVAL;
+    if (nsplit) *nsplit = 0;
+    if (!make_geom(N, Cin, H, W, Cout, KH, KW, S, P, OP, transposed, &g, &oh, &ow)) return JVAE_EINVAL;
+    if (!jvae_conv_affine_ok(g, transposed)) return JVAE_ENOTSUP;
+    if (N == 0) return 0;
+    const InAff aff{in_scale, in_shift, in_relu};
+    return jvae_conv_fwd(g, transposed, x, w, bias, y, (float*)ws, ws_bytes, (hipStream_t)stream, stats, nsplit, &aff);
+}
+
+int jvae_conv2d_wgrad_aff_f32(const float* x, const float* dy, float* dw, float* dbias, int accumulate,
+                              const float* in_scale, const float* in_shift, int in_relu,
+                              int N, int Cin, int H, int W, int Cout, int KH, int KW, int S, int P, int OP, int transposed,
+                              void* ws, size_t ws_bytes, void* stream) {
+    ConvGeom g; int oh, ow;
+    if (!x || !dy || !dw || !in_scale || !in_shift) return JVAE_EINVAL;
+    if (!make_geom(N, Cin, H, W, Cout, KH, KW, S, P, OP, transposed, &g, &oh, &ow)) return JVAE_EINVAL;
+    if (!jvae_conv_affine_ok(g, transposed)) return JVAE_ENOTSUP;
+    hipStream_t st = (hipStream_t)stream;
+    if (!accumulate) {
+        hipError_t e = hipMemsetAsync(dw, 0, sizeof(float) * (size_t)Cin * Cout * KH * KW, st);
+        if (e != hipSuccess) return (int)e;
+    }
+    if (N == 0) {
+        if (dbias && !accumulate) {
+            hipError_t e = hipMemsetAsync(dbias, 0, sizeof(float) * (size_t)Cout, st);
+            if (e != hipSuccess) return (int)e;
+        }
+        return 0;
+    }
+    const InAff aff{in_scale, in_shift, in_relu};
+    int rc = jvae_conv_wgrad(g, transposed, x, dy, dw, (float*)ws, ws_bytes, st, &aff);
+    if (rc) return rc;
+    if (dbias) rc = jvae_channel_sum(dy, dbias, N, Cout, oh * ow, accumulate, st);
+    return rc;
+}
+
 int jvae_conv2d_dgrad_f32(const float* dy, const float* w, float* dx,
                           int N, int Cin, int H, int W, int Cout, int KH, int KW, int S, int P, int OP, int transposed,
                           void* ws, size_t ws_bytes, void* stream) {

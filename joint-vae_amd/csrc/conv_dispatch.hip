@@ -70,28 +70,39 @@ int jvae_conv_stats_splits(const ConvGeom& g, int transposed) {
     return 0;
 }
 
+// Forward AND weight gradient of this layer can apply a deferred BatchNorm to the layer input while staging it.
+bool jvae_conv_affine_ok(const ConvGeom& g, int transposed) {
+    if (!wgrad_fast(g)) return false;
+    if (!transposed) return jvae_conv5_smallco_ok(g.Cb, g.Hb, g.Wb, g.Cs, g.KH, g.KW, g.S, g.P) || fold_fwd_fast(g);
+    if (point_input(g)) return false;
+    return fold_bwd_fast_s1(g) || fold_bwd_fast_s2(g);
+}
+
 int jvae_conv_fwd(const ConvGeom& g, int transposed, const float* x, const float* w, const float* bias, float* y,
-                  float* ws, size_t ws_bytes, hipStream_t st, float* stats, int* nsplit) {
+                  float* ws, size_t ws_bytes, hipStream_t st, float* stats, int* nsplit, const InAff* aff) {
     if (nsplit) *nsplit = 0;
     if (!transposed) {
         if (jvae_conv5_smallco_ok(g.Cb, g.Hb, g.Wb, g.Cs, g.KH, g.KW, g.S, g.P))
-            return jvae_conv5_smallco(x, w, bias, y, g.N, g.Cb, g.Wb, g.Cs, st);
+            return jvae_conv5_smallco(x, w, bias, y, g.N, g.Cb, g.Wb, g.Cs, st, aff);
         if (fold_fwd_fast(g) && ws_bytes >= 4 * jvae_conv5_pack_floats(g.Cb, g.Cs))
-            return jvae_conv5_fwd(x, w, 0, 0, bias, y, g.N, g.Cb, g.Hb, g.Wb, g.Cs, g.Ws, g.S, g.P, ws, st, stats, nsplit);
+            return jvae_conv5_fwd(x, w, 0, 0, bias, y, g.N, g.Cb, g.Hb, g.Wb, g.Cs, g.Ws, g.S, g.P, ws, st, stats, nsplit, aff);
+        if (aff) return JVAE_ENOTSUP;
         return jvae_fold_fwd(g, x, w, bias, y, ws, ws_bytes, st);
     }
+    if (aff && point_input(g)) return JVAE_ENOTSUP;
     if (point_input(g)) {
         const int cols = g.Cb * g.KH * g.KW;
         return jvae_gemm_launch_ex(g.N, cols, g.Cs, 1, x, g.Cs, 1, 0, w, cols, 1, 0, y, cols, 1, 0,
                                    bias, bias ? 1 : 0, g.KH * g.KW, 0, 1, st);
     }
     if (fold_bwd_fast_s1(g) && ws_bytes >= 4 * jvae_conv5_pack_floats(g.Cs, g.Cb))
-        return jvae_conv5_fwd(x, w, 1, 1, bias, y, g.N, g.Cs, g.Hs, g.Ws, g.Cb, g.Wb, 1, 4 - g.P, ws, st, stats, nsplit);
+        return jvae_conv5_fwd(x, w, 1, 1, bias, y, g.N, g.Cs, g.Hs, g.Ws, g.Cb, g.Wb, 1, 4 - g.P, ws, st, stats, nsplit, aff);
     if (fold_bwd_fast_s2(g) && ws_bytes >= 4 * jvae_conv5_pack_floats(g.Cs, g.Cb)) {
         int rc = jvae_conv5_pack(w, ws, g.Cs, g.Cb, 1, 0, st);
         if (rc) return rc;
-        return jvae_convt2(x, ws, bias, y, g.N, g.Cs, g.Ws, g.Cb, st, stats, nsplit);
+        return jvae_convt2(x, ws, bias, y, g.N, g.Cs, g.Ws, g.Cb, st, stats, nsplit, aff);
     }
+    if (aff) return JVAE_ENOTSUP;
     return jvae_fold_bwd(g, x, w, bias, y, ws, ws_bytes, st);
 }
 
@@ -116,14 +127,18 @@ int jvae_conv_dgrad(const ConvGeom& g, int transposed, const float* dy, const fl
 }
 
 int jvae_conv_wgrad(const ConvGeom& g, int transposed, const float* x, const float* dy, float* dw,
-                    float* ws, size_t ws_bytes, hipStream_t st) {
+                    float* ws, size_t ws_bytes, hipStream_t st, const InAff* aff) {
     const float* big = transposed ? dy : x;       // unfolded side
     const float* small = transposed ? x : dy;     // folded side
+    // the deferred BatchNorm belongs to the layer INPUT x: the big side of a convolution, the small side of a transposed one
+    const InAff* aff_big = transposed ? nullptr : aff;
+    const InAff* aff_small = transposed ? aff : nullptr;
     if (wgrad_fast(g) && ws_bytes >= 4 * wgrad_ws_floats(g)) {
         // the generic entry point zeroed dw (or holds the value to accumulate onto): always accumulate here
-        if (wgrad_swap(g))
-            return jvae_conv5_wgrad(big, small, dw, 1, 1, g.N, g.Cb, g.Wb, g.Cs, 1, 4 - g.P, ws, st);
-        return jvae_conv5_wgrad(small, big, dw, 1, 0, g.N, g.Cs, g.Ws, g.Cb, g.S, g.P, ws, st);
+        if (wgrad_swap(g))      // roles swapped: ps = big, q = small
+            return jvae_conv5_wgrad(big, small, dw, 1, 1, g.N, g.Cb, g.Wb, g.Cs, 1, 4 - g.P, ws, st, aff_big, aff_small);
+        return jvae_conv5_wgrad(small, big, dw, 1, 0, g.N, g.Cs, g.Ws, g.Cb, g.S, g.P, ws, st, aff_small, aff_big);
     }
+    if (aff) return JVAE_ENOTSUP;
     return jvae_fold_wgrad(g, big, small, dw, ws, ws_bytes, st);
 }

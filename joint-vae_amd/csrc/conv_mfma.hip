@@ -34,6 +34,7 @@ struct FwdP {
     int N, Cin, H, W, Cout, P;   // Cout: padded to a multiple of 32 (packed weights), CoutReal: channels of `out`
     int CoutReal;
     float* stats;        // optional (CoutReal, gridDim.x, 2): per-workgroup sum / sum of squares of (out - bias)
+    InAff aff;           // deferred BatchNorm(+ReLU) of the input (sc == nullptr: none)
 };
 
 template <int S, int OW, int MT, int NT, int CC>
@@ -54,7 +55,7 @@ struct FwdGeom {
     static constexpr int WS = CC * 25 * WCOLS;
 };
 
-template <int S, int OW, int MT, int NT, int CC>
+template <int S, int OW, int MT, int NT, int CC, bool AFF>
 __global__ __launch_bounds__(256, 2) void conv5_fwd_kernel(FwdP p) {
     using G = FwdGeom<S, OW, MT, NT, CC>;
     __shared__ __attribute__((aligned(16))) float lds[G::XS + G::WS];
@@ -98,6 +99,8 @@ __global__ __launch_bounds__(256, 2) void conv5_fwd_kernel(FwdP p) {
     // registers; they are written to LDS after the barrier that retires chunk c's fragment reads.
     constexpr int XU = (XUNITS + 255) / 256, WU = (WUNITS + 255) / 256;
     f32x4 rx[XU], rw[WU];
+    float rsc[AFF ? XU : 1], rsh[AFF ? XU : 1];   // deferred-BatchNorm coefficients of the prefetched units (applied in
+                                                  // lstore, i.e. after the MFMAs that hide the global-load latency)
     auto gload = [&](int c0) {
 #pragma unroll
         for (int k = 0; k < XU; ++k) {
@@ -108,9 +111,13 @@ __global__ __launch_bounds__(256, 2) void conv5_fwd_kernel(FwdP p) {
             const int c = t % CC, im = t / CC;
             const int ir = in_row0 + lr, n = img0 + im, ch = c0 + c;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (u < XUNITS && ir >= 0 && ir < p.H && n < p.N && ch < p.Cin)
+            float sc = 0.f, sh = 0.f;                        // padding cells: 0*0 + 0 stays an exact zero
+            if (u < XUNITS && ir >= 0 && ir < p.H && n < p.N && ch < p.Cin) {
                 v = *reinterpret_cast<const f32x4*>(p.in + (((long)n * p.Cin + ch) * p.H + ir) * p.W + x4 * 4);
+                if (AFF) { sc = p.aff.sc[ch]; sh = p.aff.sh[ch]; }
+            }
             rx[k] = v;
+            if (AFF) { rsc[k] = sc; rsh[k] = sh; }
         }
 #pragma unroll
         for (int k = 0; k < WU; ++k) {
@@ -132,7 +139,8 @@ __global__ __launch_bounds__(256, 2) void conv5_fwd_kernel(FwdP p) {
                 int t = u / W4;
                 const int lr = t % G::ROWS; t /= G::ROWS;
                 const int c = t % CC, im = t / CC;
-                *reinterpret_cast<f32x4*>(&Xs[(im * CC + c) * G::CH + lr * G::WP + 4 + x4 * 4]) = rx[k];
+                *reinterpret_cast<f32x4*>(&Xs[(im * CC + c) * G::CH + lr * G::WP + 4 + x4 * 4]) =
+                    AFF ? aff4(rx[k], rsc[AFF ? k : 0], rsh[AFF ? k : 0], p.aff.relu) : rx[k];
             }
         }
 #pragma unroll
@@ -242,13 +250,15 @@ thread_local int g_last_splits = 0;     // grid.x of the last forward-type launc
 
 template <int S, int OW, int MT, int NT, int CC>
 int launch_fwd(const FwdP& p, hipStream_t st) {
+    // two instantiations: the deferred-BatchNorm input transform costs registers only where it is used
     using G = FwdGeom<S, OW, MT, NT, CC>;
     static_assert((G::XS + G::WS) * 4 <= 160 * 1024, "LDS budget");
     const long pixels = (long)p.N * G::OHW;
     dim3 grid((unsigned)((pixels + G::PIX - 1) / G::PIX), (unsigned)(p.Cout / G::WCOLS));
     if (G::OHW < G::PIX) grid.x = (unsigned)((p.N + G::NIMG - 1) / G::NIMG);
     g_last_splits = (int)grid.x;
-    hipLaunchKernelGGL((conv5_fwd_kernel<S, OW, MT, NT, CC>), grid, dim3(256), 0, st, p);
+    if (p.aff.sc) hipLaunchKernelGGL((conv5_fwd_kernel<S, OW, MT, NT, CC, true>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((conv5_fwd_kernel<S, OW, MT, NT, CC, false>), grid, dim3(256), 0, st, p);
     JVAE_LAUNCH_CHECK();
     return 0;
 }
@@ -298,10 +308,10 @@ int jvae_conv5_fwd_max_splits(int N, int OW) { return (int)(((long)N * OW * OW +
 
 int jvae_conv5_fwd(const float* in, const float* w, int swap, int flip, const float* bias, float* out,
                    int N, int Cin, int H, int W, int Cout, int OW, int S, int P, float* ws, hipStream_t st,
-                   float* stats, int* nsplit) {
+                   float* stats, int* nsplit, const InAff* aff) {
     int rc = jvae_conv5_pack(w, ws, Cin, Cout, swap, flip, st);
     if (rc) return rc;
-    FwdP p{in, ws, bias, out, N, Cin, H, W, (Cout + 31) / 32 * 32, P, Cout, stats};
+    FwdP p{in, ws, bias, out, N, Cin, H, W, (Cout + 31) / 32 * 32, P, Cout, stats, aff ? *aff : InAff{nullptr, nullptr, 0}};
     struct Fin { int* n; ~Fin() { if (n) *n = g_last_splits; } } fin{nsplit};
     if (S == 1) {
         switch (OW) {

@@ -19,6 +19,7 @@ struct SmP {
     const float* bias;   // (CO) or null
     float* out;          // (N, CO, H, W)
     int N, Cin, P;
+    InAff aff;           // deferred BatchNorm(+ReLU) of the input
 };
 
 template <int OW, int CO, int CC>
@@ -52,6 +53,7 @@ __global__ __launch_bounds__(256) void conv5_smallco_kernel(SmP p) {
     constexpr int XUNITS = CC * ROWS * W4;
     constexpr int XU = (XUNITS + 255) / 256;
     f32x4 rx[XU];
+    float rsc[XU], rsh[XU];         // deferred-BatchNorm coefficients, applied when the units are written to LDS
     const int in_row0 = row0 - p.P;
     auto gload = [&](int c0) {
 #pragma unroll
@@ -62,9 +64,12 @@ __global__ __launch_bounds__(256) void conv5_smallco_kernel(SmP p) {
             const int lr = t % ROWS, c = t / ROWS;
             const int ir = in_row0 + lr, ch = c0 + c;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (u < XUNITS && ir >= 0 && ir < OH && ch < p.Cin)
+            float sc = 0.f, sh = 0.f;
+            if (u < XUNITS && ir >= 0 && ir < OH && ch < p.Cin) {
                 v = *reinterpret_cast<const f32x4*>(p.in + (((long)n * p.Cin + ch) * OH + ir) * OW + x4 * 4);
-            rx[k] = v;
+                if (p.aff.sc) { sc = p.aff.sc[ch]; sh = p.aff.sh[ch]; }
+            }
+            rx[k] = v; rsc[k] = sc; rsh[k] = sh;
         }
     };
     gload(0);
@@ -77,7 +82,8 @@ __global__ __launch_bounds__(256) void conv5_smallco_kernel(SmP p) {
                 const int x4 = u % W4;
                 const int t = u / W4;
                 const int lr = t % ROWS, c = t / ROWS;
-                *reinterpret_cast<f32x4*>(&Xs[c * CH + lr * WP + 4 + x4 * 4]) = rx[k];
+                *reinterpret_cast<f32x4*>(&Xs[c * CH + lr * WP + 4 + x4 * 4]) =
+                    p.aff.sc ? aff4(rx[k], rsc[k], rsh[k], p.aff.relu) : rx[k];
             }
         }
         for (int i = tid; i < CC * 25 * 4; i += 256) {           // Wl[c][tap][co]
@@ -140,8 +146,8 @@ bool jvae_conv5_smallco_ok(int Cin, int H, int W, int Cout, int KH, int KW, int 
 }
 
 int jvae_conv5_smallco(const float* in, const float* w, const float* bias, float* out, int N, int Cin, int W, int Cout,
-                       hipStream_t st) {
-    SmP p{in, w, bias, out, N, Cin, 2};
+                       hipStream_t st, const InAff* aff) {
+    SmP p{in, w, bias, out, N, Cin, 2, aff ? *aff : InAff{nullptr, nullptr, 0}};
     if (W == 32) return launch_sm<32>(p, Cout, st);
     if (W == 64) return launch_sm<64>(p, Cout, st);
     return JVAE_ENOTSUP;

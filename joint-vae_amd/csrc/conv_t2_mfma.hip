@@ -26,6 +26,7 @@ struct T2P {
     float* out;          // big (N, O, 2HS, 2WS)
     int N, C, O;
     float* stats;        // optional (O, gridDim.x, 2): per-workgroup sum / sum of squares of (out - bias)
+    InAff aff;           // deferred BatchNorm(+ReLU) of the input
 };
 
 template <int WS, int NT, int CC>
@@ -43,8 +44,10 @@ struct T2Geom {
     static constexpr int WSZ = CC * 25 * WCOLS;
 };
 
-template <int WS, int NT, int CC>
-__global__ __launch_bounds__(256, 2) void convt2_kernel(T2P p) {
+// NT = 1: 64 accumulator registers; <= 128 VGPRs keeps 4 workgroups per CU resident (measured: 134 VGPRs = 3 per CU
+// costs 15 %)
+template <int WS, int NT, int CC, bool AFF>
+__global__ __launch_bounds__(256, NT == 1 ? 4 : 2) void convt2_kernel(T2P p) {
     using G = T2Geom<WS, NT, CC>;
     __shared__ __attribute__((aligned(16))) float lds[G::XS + G::WSZ];
     float* Xs = lds;
@@ -79,6 +82,7 @@ __global__ __launch_bounds__(256, 2) void convt2_kernel(T2P p) {
 
     constexpr int XU = (XUNITS + 255) / 256, WU = (WUNITS + 255) / 256;
     f32x4 rx[XU], rw[WU];
+    float rsc[AFF ? XU : 1], rsh[AFF ? XU : 1];   // deferred-BatchNorm coefficients, applied when the units go to LDS
     auto gload = [&](int c0) {
 #pragma unroll
         for (int k = 0; k < XU; ++k) {
@@ -89,9 +93,13 @@ __global__ __launch_bounds__(256, 2) void convt2_kernel(T2P p) {
             const int c = t % CC, i2 = t / CC;
             const int ir = row0 - 1 + lr, n = img0 + i2, ch = c0 + c;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (u < XUNITS && ir >= 0 && ir < G::HS && n < p.N && ch < p.C)
+            float sc = 0.f, sh = 0.f;
+            if (u < XUNITS && ir >= 0 && ir < G::HS && n < p.N && ch < p.C) {
                 v = *reinterpret_cast<const f32x4*>(p.in + (((long)n * p.C + ch) * G::HS + ir) * WS + x4 * 4);
+                if (AFF) { sc = p.aff.sc[ch]; sh = p.aff.sh[ch]; }
+            }
             rx[k] = v;
+            if (AFF) { rsc[k] = sc; rsh[k] = sh; }
         }
 #pragma unroll
         for (int k = 0; k < WU; ++k) {
@@ -115,7 +123,8 @@ __global__ __launch_bounds__(256, 2) void convt2_kernel(T2P p) {
                 int t = u / W4;
                 const int lr = t % G::ROWS; t /= G::ROWS;
                 const int c = t % CC, i2 = t / CC;
-                *reinterpret_cast<f32x4*>(&Xs[(i2 * CC + c) * G::CH + lr * G::WP + 4 + x4 * 4]) = rx[k];
+                *reinterpret_cast<f32x4*>(&Xs[(i2 * CC + c) * G::CH + lr * G::WP + 4 + x4 * 4]) =
+                    AFF ? aff4(rx[k], rsc[AFF ? k : 0], rsh[AFF ? k : 0], p.aff.relu) : rx[k];
             }
         }
 #pragma unroll
@@ -216,7 +225,8 @@ int launch_t2(const T2P& p, hipStream_t st) {
     dim3 grid(G::HSWS >= G::PIX ? (unsigned)((long)p.N * G::HSWS / G::PIX) : (unsigned)((p.N + G::NIMG - 1) / G::NIMG),
               (unsigned)(p.O / G::WCOLS));
     g_t2_splits = (int)grid.x;
-    hipLaunchKernelGGL((convt2_kernel<WS, NT, 4>), grid, dim3(256), 0, st, p);
+    if (p.aff.sc) hipLaunchKernelGGL((convt2_kernel<WS, NT, 4, true>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((convt2_kernel<WS, NT, 4, false>), grid, dim3(256), 0, st, p);
     JVAE_LAUNCH_CHECK();
     return 0;
 }
@@ -232,8 +242,8 @@ bool jvae_convt2_ok(int C, int HS, int WS, int O, int HB, int WB, int KH, int KW
 }
 
 int jvae_convt2(const float* in, const float* wpacked, const float* bias, float* out, int N, int C, int WS, int O,
-                hipStream_t st, float* stats, int* nsplit) {
-    T2P p{in, wpacked, bias, out, N, C, O, stats};
+                hipStream_t st, float* stats, int* nsplit, const InAff* aff) {
+    T2P p{in, wpacked, bias, out, N, C, O, stats, aff ? *aff : InAff{nullptr, nullptr, 0}};
     struct Fin { int* n; ~Fin() { if (n) *n = g_t2_splits; } } fin{nsplit};
     const bool two = false;      // NT = 2 needs 128 accumulator registers (1 wave/SIMD): one 32-channel tile per wave instead
     switch (WS) {

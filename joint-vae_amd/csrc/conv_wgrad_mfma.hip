@@ -27,6 +27,7 @@ struct WgP {
     const float* q;      // (N, Cb, HB, WB)
     float* slab;         // (G, Ca, Cb*25)
     int N, Ca, Cb, P, G;
+    InAff aff_p, aff_q;  // deferred BatchNorm(+ReLU) of ps / q (whichever is the layer's input; sc == nullptr: none)
 };
 
 template <int S, int WS, int CB>
@@ -48,10 +49,11 @@ struct WgGeom {
     static constexpr int NBT = (NTILE + 3) / 4;               // per wave
 };
 
-template <int S, int WS, int CB, bool PF>
+template <int S, int WS, int CB, bool PF, bool AFF>
 __global__ __launch_bounds__(256, 2) void conv5_wgrad_kernel(WgP p) {
     using G = WgGeom<S, WS, CB>;
     __shared__ __attribute__((aligned(16))) float lds[G::QS + G::PSZ];
+    __shared__ float coef[AFF ? 2 * (CB + 32) : 1];           // deferred-BatchNorm (scale, shift) of this workgroup's channels
     float* Qs = lds;
     float* Pt = lds + G::QS;
 
@@ -63,6 +65,14 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_kernel(WgP p) {
     const int cols_here = cb_here * 25;
 
     for (int i = tid; i < G::QS / 4; i += 256) reinterpret_cast<f32x4*>(Qs)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (AFF && tid < CB + 32) {                                // identity where no transform was given
+        const bool isq = tid < CB;
+        const InAff& a = isq ? p.aff_q : p.aff_p;
+        const int ch = isq ? b0 + tid : a0 + (tid - CB);
+        const bool ok = a.sc && ch < (isq ? p.Cb : p.Ca);
+        coef[2 * tid] = ok ? a.sc[ch] : 1.f;
+        coef[2 * tid + 1] = ok ? a.sh[ch] : 0.f;
+    }
 
     // this lane's columns: LDS offset of (b_local, tap) relative to a pixel's patch origin
     int boff[G::NBT];
@@ -121,7 +131,9 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_kernel(WgP p) {
             rp[k] = v;
         }
     };
-    auto lstore = [&]() {
+    // `item`: the work item whose data sits in rq / rp (needed to tell padding rows, which must stay zero, from data)
+    auto lstore = [&](int item) {
+        const int in_row0 = (item % G::TILES) * G::TH * S - p.P;
 #pragma unroll
         for (int k = 0; k < QU; ++k) {
             const int u = tid + k * 256;
@@ -129,7 +141,12 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_kernel(WgP p) {
                 const int x4 = u % W4;
                 const int t = u / W4;
                 const int lr = t % G::ROWS, c = t / G::ROWS;
-                *reinterpret_cast<f32x4*>(&Qs[c * G::CH + lr * G::WP + 4 + x4 * 4]) = rq[k];
+                f32x4 v = rq[k];
+                if (AFF && p.aff_q.sc) {
+                    const int ir = in_row0 + lr;
+                    if (ir >= 0 && ir < HB && c < cb_here) v = aff4(v, coef[2 * c], coef[2 * c + 1], p.aff_q.relu);
+                }
+                *reinterpret_cast<f32x4*>(&Qs[c * G::CH + lr * G::WP + 4 + x4 * 4]) = v;
             }
         }
 #pragma unroll
@@ -137,8 +154,10 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_kernel(WgP p) {
             const int u = tid + k * 256;
             if (u < PUNITS) {
                 const int p4 = u % (G::TPIX / 4), a = u / (G::TPIX / 4);
+                f32x4 v = rp[k];
+                if (AFF && p.aff_p.sc && a0 + a < p.Ca) v = aff4(v, coef[2 * (CB + a)], coef[2 * (CB + a) + 1], p.aff_p.relu);
                 float* d = &Pt[a * G::PPITCH + p4 * 4];
-                d[0] = rp[k][0]; d[1] = rp[k][1]; d[2] = rp[k][2]; d[3] = rp[k][3];
+                d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
             }
         }
     };
@@ -148,7 +167,7 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_kernel(WgP p) {
     for (int item = item_beg; item < item_end; ++item) {
         __syncthreads();
         if (!PF) gload(item);                    // wide (CB = 32) variant: no registers to spare for a prefetch
-        lstore();
+        lstore(item);
         __syncthreads();
         if (PF && item + 1 < item_end) gload(item + 1);
 #pragma unroll
@@ -206,9 +225,11 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 template <int S, int WS, int CB, bool PF = true>
 int launch_wg(const WgP& p, hipStream_t st) {
     using G = WgGeom<S, WS, CB>;
-    static_assert((G::QS + G::PSZ) * 4 <= 64 * 1024, "static LDS budget");
+    static_assert((G::QS + G::PSZ) * 4 + 8 * (CB + 32) <= 64 * 1024, "static LDS budget");
     dim3 grid(p.G, (p.Ca + 31) / 32, (p.Cb + CB - 1) / CB);
-    hipLaunchKernelGGL((conv5_wgrad_kernel<S, WS, CB, PF>), grid, dim3(256), 0, st, p);
+    // two instantiations: the deferred-BatchNorm transform costs registers / LDS only where it is used
+    if (p.aff_p.sc || p.aff_q.sc) hipLaunchKernelGGL((conv5_wgrad_kernel<S, WS, CB, PF, true>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((conv5_wgrad_kernel<S, WS, CB, PF, false>), grid, dim3(256), 0, st, p);
     JVAE_LAUNCH_CHECK();
     return 0;
 }
@@ -259,8 +280,10 @@ size_t jvae_conv5_wgrad_ws_floats(int N, int Ca, int Cb, int S, int WS) {
 
 // dW (+)= ... ; swapflip: the caller passed the role-swapped problem (see wgrad_reduce_kernel).
 int jvae_conv5_wgrad(const float* ps, const float* q, float* dw, int accumulate, int swapflip,
-                     int N, int Ca, int WS, int Cb, int S, int P, float* ws, hipStream_t st) {
-    WgP p{ps, q, ws, N, Ca, Cb, P, slab_count(N, Ca, Cb, S, WS)};
+                     int N, int Ca, int WS, int Cb, int S, int P, float* ws, hipStream_t st,
+                     const InAff* aff_p, const InAff* aff_q) {
+    const InAff none{nullptr, nullptr, 0};
+    WgP p{ps, q, ws, N, Ca, Cb, P, slab_count(N, Ca, Cb, S, WS), aff_p ? *aff_p : none, aff_q ? *aff_q : none};
     int rc = JVAE_ENOTSUP;
     if (Cb <= 4) {
         if (S == 1) {

@@ -21,6 +21,11 @@ int jvae_gemm_launch_ex(int M, int N, int K, int batch,
 int jvae_splitk_fold(const float* part, const float* bias, float* y, int S, long MN, int N, int relu, int accumulate,
                      hipStream_t st);
 
+// Optional per-input-channel transform applied while a convolution stages its INPUT: a = [relu](x*sc[c] + sh[c]).
+// This is the BatchNorm(+ReLU) that produced the layer input, deferred into the consumer so that the normalised
+// activation is never written to / re-read from HBM (sc == nullptr: identity).
+struct InAff { const float* sc; const float* sh; int relu; };
+
 // Geometry of one (transposed) convolution.  "big" side = the tensor that is unfolded (conv input /
 // transposed-conv output), "small" side = the tensor on the folded grid (conv output / transposed-conv input).
 struct ConvGeom {

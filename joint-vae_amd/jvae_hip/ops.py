@@ -203,6 +203,31 @@ def conv_fwd_stats_raw(x, w, b, spec):
     return y, (stats if ns.value > 0 else None), ns.value
 
 
+def conv_affine_ok(spec, N, H, W):
+    """Can this layer apply a deferred BatchNorm(+ReLU) to its input (forward and weight gradient kernels)?"""
+    return bool(L.load().jvae_conv2d_affine_ok(*spec.geom(N, H, W)))
+
+
+def conv_fwd_aff_raw(x, w, b, spec, aff, want_stats):
+    """Forward with a = [relu](x*scale[c] + shift[c]) applied to the input while it is staged; aff = (scale, shift, relu).
+    -> (y, stats, nsplit) as conv_fwd_stats_raw."""
+    lib = L.load()
+    N, _, H, W = x.shape
+    geom = spec.geom(N, H, W)
+    oh, ow = spec.out_hw(H, W)
+    y = torch.empty((N, spec.cout, oh, ow), device=x.device, dtype=torch.float32)
+    stats, ns = None, c_int(0)
+    if want_stats:
+        cap = lib.jvae_conv2d_stats_splits(*geom)
+        if cap > 0:
+            stats = torch.empty((spec.cout * cap * 2,), device=x.device, dtype=torch.float32)
+    ws, nb = _conv_ws(geom, x.device)
+    rc = lib.jvae_conv2d_fwd_aff_f32(L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(y), L.ptr(stats), byref(ns),
+                                     L.ptr(aff[0]), L.ptr(aff[1]), int(aff[2]), *geom, L.ptr(ws), nb, L.stream_ptr())
+    L.check(rc, 'jvae_conv2d_fwd_aff_f32')
+    return y, (stats if ns.value > 0 else None), ns.value
+
+
 def conv_dgrad_raw(gy, w, spec, xshape):
     N, _, H, W = xshape
     gx = torch.empty(xshape, device=gy.device, dtype=torch.float32)
@@ -213,9 +238,10 @@ def conv_dgrad_raw(gy, w, spec, xshape):
     return gx
 
 
-def conv_wgrad_raw(x, gy, spec, wshape, want_bias, w_slot=None, b_slot=None):
+def conv_wgrad_raw(x, gy, spec, wshape, want_bias, w_slot=None, b_slot=None, aff=None):
     """-> (gw, gb).  With w_slot / b_slot (existing .grad tensors) the result is ADDED there and None is returned
-    for that gradient.  The C entry point takes one accumulate flag: both slots or neither."""
+    for that gradient.  The C entry point takes one accumulate flag: both slots or neither.
+    aff = (scale, shift, relu): x is a pre-BatchNorm tensor whose normalisation is applied while it is staged."""
     N, _, H, W = x.shape
     inplace = w_slot is not None and (b_slot is not None or not want_bias)
     gw = w_slot if inplace else torch.empty(wshape, device=x.device, dtype=torch.float32)
@@ -224,8 +250,13 @@ def conv_wgrad_raw(x, gy, spec, wshape, want_bias, w_slot=None, b_slot=None):
         gb = b_slot if inplace else torch.empty(spec.cout, device=x.device, dtype=torch.float32)
     geom = spec.geom(N, H, W)
     ws, nb = _conv_ws(geom, x.device)
-    rc = L.load().jvae_conv2d_wgrad_f32(L.ptr(x), L.ptr(gy), L.ptr(gw), L.ptr(gb), int(inplace), *geom, L.ptr(ws), nb,
-                                        L.stream_ptr())
+    if aff is not None:
+        rc = L.load().jvae_conv2d_wgrad_aff_f32(L.ptr(x), L.ptr(gy), L.ptr(gw), L.ptr(gb), int(inplace),
+                                                L.ptr(aff[0]), L.ptr(aff[1]), int(aff[2]), *geom, L.ptr(ws), nb,
+                                                L.stream_ptr())
+    else:
+        rc = L.load().jvae_conv2d_wgrad_f32(L.ptr(x), L.ptr(gy), L.ptr(gw), L.ptr(gb), int(inplace), *geom, L.ptr(ws), nb,
+                                            L.stream_ptr())
     L.check(rc, 'jvae_conv2d_wgrad_f32')
     return (None, None) if inplace else (gw, gb)
 
@@ -234,11 +265,16 @@ class _Conv(torch.autograd.Function):
     """nn.Conv2d / nn.ConvTranspose2d (conv.py:186-196)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, spec, dead_bias, stats_out):
+    def forward(ctx, x, w, b, spec, dead_bias, stats_out, aff=None):
         x = _c(_f32(x, 'conv'))
         ctx.w_ref, ctx.b_ref = w, b
         w = _c(w)
-        if stats_out is not None:          # the caller is a train-mode BatchNorm: let the conv epilogue do its sums
+        ctx.aff = aff
+        if aff is not None:                # x is a pre-BatchNorm tensor: normalise (+ReLU) while staging it
+            y, st, ns = conv_fwd_aff_raw(x, w, b, spec, aff, stats_out is not None)
+            if stats_out is not None:
+                stats_out['stats'], stats_out['nsplit'], stats_out['pivot'] = st, ns, b
+        elif stats_out is not None:        # the caller is a train-mode BatchNorm: let the conv epilogue do its sums
             y, st, ns = conv_fwd_stats_raw(x, w, b, spec)
             stats_out['stats'], stats_out['nsplit'], stats_out['pivot'] = st, ns, b
         else:
@@ -267,21 +303,25 @@ class _Conv(torch.autograd.Function):
                 side = L.side_stream(x.device)
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
-                    conv_wgrad_raw(x, gy, ctx.spec, w.shape, want_b, w_slot, b_slot)
+                    conv_wgrad_raw(x, gy, ctx.spec, w.shape, want_b, w_slot, b_slot, ctx.aff)
                 x.record_stream(side)
                 gy.record_stream(side)
+                if ctx.aff is not None:
+                    ctx.aff[0].record_stream(side)
+                    ctx.aff[1].record_stream(side)
                 _join_after_backward()
             else:
-                gw, gb = conv_wgrad_raw(x, gy, ctx.spec, w.shape, want_b, w_slot, b_slot)
+                gw, gb = conv_wgrad_raw(x, gy, ctx.spec, w.shape, want_b, w_slot, b_slot, ctx.aff)
         if ctx.dead_bias and ctx.has_bias and ctx.needs_input_grad[2] and _grad_slot(ctx.b_ref) is None:
             gb = torch.zeros_like(ctx.b_ref)          # exact value; makes the bias a regular optimiser citizen
-        return gx, gw, gb, None, None, None
+        return gx, gw, gb, None, None, None, None
 
 
-def conv2d(x, w, b, spec, dead_bias=False, stats_out=None):
+def conv2d(x, w, b, spec, dead_bias=False, stats_out=None, aff=None):
     """dead_bias: the bias feeds a train-mode BatchNorm, which removes the channel mean: its true gradient is
-    exactly zero (what autograd would produce is rounding noise), so the channel reduction is skipped."""
-    return _Conv.apply(x, w, b, spec, dead_bias, stats_out)
+    exactly zero (what autograd would produce is rounding noise), so the channel reduction is skipped.
+    aff: (scale, shift, relu) of a deferred BatchNorm on x (batchnorm_defer)."""
+    return _Conv.apply(x, w, b, spec, dead_bias, stats_out, aff)
 
 
 # ------------------------------------------------------------------------------------------- batch norm
@@ -347,6 +387,53 @@ def batchnorm_act(x, gamma, beta, running_mean, running_var, num_batches_tracked
     """ext: {'stats', 'nsplit', 'pivot'} filled by conv2d(..., stats_out=ext) for the tensor x."""
     return _BatchNormAct.apply(x, gamma, beta, running_mean, running_var, num_batches_tracked, training, relu,
                                momentum, eps, ext)
+
+
+class _BatchNormDefer(torch.autograd.Function):
+    """nn.BatchNorm2d (train or eval) + optional ReLU whose arithmetic is deferred into the next convolution: forward
+    only produces the statistics and the per-channel (scale, shift); the returned activation IS the input tensor (the
+    consumer applies fmaf(x, scale, shift) [+ReLU] while staging it).  Backward is the ordinary BatchNorm backward on the
+    gradient the consumer's dgrad returns (which is w.r.t. the normalised activation)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, rm, rv, nbt, training, relu, momentum, eps, ext):
+        x = _c(_f32(x, 'batchnorm'))
+        N, C = x.shape[0], x.shape[1]
+        P = x.numel() // max(N * C, 1)
+        lib = L.load()
+        mean = torch.empty(C, device=x.device, dtype=torch.float32)
+        invstd = torch.empty(C, device=x.device, dtype=torch.float32)
+        coef = torch.empty((2, C), device=x.device, dtype=torch.float32)
+        ws = L.workspace(lib.jvae_bn_workspace_bytes(C), x.device)
+        use_ext = ext is not None and ext.get('stats') is not None and training
+        rc = lib.jvae_bn_finalize_f32(L.ptr(x), L.ptr(gamma), L.ptr(beta), L.ptr(rm), L.ptr(rv), L.ptr(nbt),
+                                      L.ptr(mean), L.ptr(invstd), L.ptr(coef[0]), L.ptr(coef[1]), N, C, P, momentum, eps,
+                                      int(training), L.ptr(ext['stats']) if use_ext else None,
+                                      int(ext['nsplit']) if use_ext else 0, L.ptr(ext.get('pivot')) if use_ext else None,
+                                      L.ptr(ws), ws.numel(), L.stream_ptr())
+        L.check(rc, 'jvae_bn_finalize_f32')
+        if training:
+            ctx.save_for_backward(x, gamma, beta, mean, invstd)
+            ctx.relu = relu
+            ctx.dims = (N, C, P)
+            ctx.g_ref, ctx.b_ref = gamma, beta
+        else:
+            ctx.dims = None
+        ctx.mark_non_differentiable(coef)
+        return x.view_as(x), coef
+
+    @staticmethod
+    def backward(ctx, gy, _gcoef):
+        g = _BatchNormAct.backward(ctx, gy)
+        return g
+
+
+def batchnorm_defer(x, gamma, beta, running_mean, running_var, num_batches_tracked, training, relu,
+                    momentum=0.1, eps=1e-5, ext=None):
+    """-> (x_alias, (scale, shift, relu)): hand both to conv2d(..., aff=...) of a layer with conv_affine_ok()."""
+    xa, coef = _BatchNormDefer.apply(x, gamma, beta, running_mean, running_var, num_batches_tracked, training, relu,
+                                     momentum, eps, ext)
+    return xa, (coef[0], coef[1], relu)
 
 
 class _SyncBatchNormAct(torch.autograd.Function):

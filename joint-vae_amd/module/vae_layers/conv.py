@@ -93,8 +93,8 @@ class HipConv2d(nn.Conv2d):
     def _spec(self):
         return ops.ConvSpec(self.in_channels, self.out_channels, self.kernel_size[0], self.stride[0], self.padding[0])
 
-    def forward(self, x, dead_bias=False, stats_out=None):
-        return ops.conv2d(x, self.weight, self.bias, self._spec(), dead_bias, stats_out)
+    def forward(self, x, dead_bias=False, stats_out=None, aff=None):
+        return ops.conv2d(x, self.weight, self.bias, self._spec(), dead_bias, stats_out, aff)
 
 
 class HipConvTranspose2d(nn.ConvTranspose2d):
@@ -102,8 +102,8 @@ class HipConvTranspose2d(nn.ConvTranspose2d):
         return ops.ConvSpec(self.in_channels, self.out_channels, self.kernel_size[0], self.stride[0], self.padding[0],
                             self.output_padding[0], transposed=True)
 
-    def forward(self, x, output_size=None, dead_bias=False, stats_out=None):
-        return ops.conv2d(x, self.weight, self.bias, self._spec(), dead_bias, stats_out)
+    def forward(self, x, output_size=None, dead_bias=False, stats_out=None, aff=None):
+        return ops.conv2d(x, self.weight, self.bias, self._spec(), dead_bias, stats_out, aff)
 
 
 class HipBatchNorm2d(nn.BatchNorm2d):
@@ -111,6 +111,11 @@ class HipBatchNorm2d(nn.BatchNorm2d):
 
     sync_world = 1          # > 1: statistics over all data-parallel ranks (ClassificationVariationalNetwork.set_sync_batchnorm)
     sync_group = None
+
+    def defer(self, x, relu=False, ext=None):
+        """Statistics + coefficients only; the consumer convolution applies the normalisation (ops.batchnorm_defer)."""
+        return ops.batchnorm_defer(x, self.weight, self.bias, self.running_mean, self.running_var,
+                                   self.num_batches_tracked, self.training, relu, self.momentum, self.eps, ext)
 
     def forward(self, x, relu=False, ext=None):
         if self.training and self.sync_world > 1:
@@ -131,6 +136,8 @@ class HipConvStack(nn.Sequential):
     geometry has no bf16 kernel at all (the 3x3 / 4x4 / 7x7 / 8x8 heads) stay on the fp32 kernels."""
 
     compute_dtype = 'fp32'
+    # BatchNorm+ReLU applied by the consuming convolution where its kernels can (fp32 path); JVAE_DEFER_BN=0: A/B switch
+    defer_batchnorm = os.environ.get('JVAE_DEFER_BN', '1') != '0'
 
     def forward(self, x):
         if self.compute_dtype == 'bf16':
@@ -138,11 +145,21 @@ class HipConvStack(nn.Sequential):
         mods = list(self)
         i = 0
         ext = None
+        aff = None           # (scale, shift, relu) of a BatchNorm deferred into the next convolution
         while i < len(mods):
             m = mods[i]
             if isinstance(m, HipBatchNorm2d) and i + 1 < len(mods) and type(mods[i + 1]) in ACT_OF_MODULE \
                     and ACT_OF_MODULE[type(mods[i + 1])] in (ops.RELU, ops.IDENT):
-                x = m(x, relu=ACT_OF_MODULE[type(mods[i + 1])] == ops.RELU, ext=ext)
+                relu = ACT_OF_MODULE[type(mods[i + 1])] == ops.RELU
+                nxt = mods[i + 2] if i + 2 < len(mods) else None
+                if self.defer_batchnorm and isinstance(nxt, (HipConv2d, HipConvTranspose2d)) \
+                        and not (m.training and m.sync_world > 1) \
+                        and ops.conv_affine_ok(nxt._spec(), x.shape[0], x.shape[2], x.shape[3]):
+                    # the normalised activation is never materialised: the next convolution (forward and weight
+                    # gradient) applies fmaf(x, scale, shift) + ReLU while it stages its input
+                    x, aff = m.defer(x, relu=relu, ext=ext)
+                else:
+                    x = m(x, relu=relu, ext=ext)
                 ext = None
                 i += 2
                 continue
@@ -150,10 +167,14 @@ class HipConvStack(nn.Sequential):
                     and isinstance(mods[i + 1], HipBatchNorm2d) and mods[i + 1].training:
                 ext = {} if mods[i + 1].sync_world <= 1 else None      # synchronised BN reduces its own sums
                 # BatchNorm removes the channel mean: d(loss)/d(bias) == 0 exactly
-                x = m(x, dead_bias=True, stats_out=ext)
+                x = m(x, dead_bias=True, stats_out=ext, aff=aff)
+            elif isinstance(m, (HipConv2d, HipConvTranspose2d)):
+                ext = None
+                x = m(x, aff=aff)
             else:
                 ext = None
                 x = m(x)
+            aff = None
             i += 1
         return x
 

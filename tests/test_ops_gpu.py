@@ -130,6 +130,40 @@ def test_linear(act):
     assert rel(xd.grad, xr.grad) < 2e-5 and rel(wd.grad, wr.grad) < 2e-5 and rel(bd.grad, br.grad) < 2e-5
 
 
+AFF_CONVS = [(32, 32, 5, 2, 2, 0, False, 32), (32, 64, 5, 1, 2, 0, False, 16), (64, 64, 5, 1, 2, 0, True, 8),
+             (64, 64, 5, 2, 2, 1, True, 8), (32, 32, 5, 2, 2, 1, True, 16), (32, 32, 5, 1, 2, 0, True, 32),
+             (32, 3, 5, 1, 2, 0, False, 32), (64, 32, 5, 1, 2, 0, True, 16)]
+
+
+@pytest.mark.parametrize('cin,cout,k,s,p,op,tr,H', AFF_CONVS)
+@pytest.mark.parametrize('relu', [True, False])
+def test_conv_with_deferred_batchnorm_input(cin, cout, k, s, p, op, tr, H, relu):
+    """conv(x*scale + shift [relu]) with the per-channel transform applied inside the kernels (forward and weight
+    gradient) against PyTorch on the explicitly transformed input; dgrad is w.r.t. the transformed input."""
+    from jvae_hip import ops
+    N = 5
+    g = torch.Generator().manual_seed(cin * 7 + cout + H + int(relu))
+    x = torch.randn(N, cin, H, H, generator=g)
+    sc = torch.rand(cin, generator=g) + 0.5
+    sh = torch.randn(cin, generator=g) * 0.5
+    wshape = (cin, cout, k, k) if tr else (cout, cin, k, k)
+    w = (torch.randn(wshape, generator=g) / math.sqrt(cin * k * k)).requires_grad_(True)
+    b = torch.randn(cout, generator=g)
+    a = x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+    a = torch.relu(a) if relu else a
+    yr = F.conv_transpose2d(a, w, b, stride=s, padding=p, output_padding=op) if tr else F.conv2d(a, w, b, stride=s, padding=p)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    spec = ops.ConvSpec(cin, cout, k, s, p, op, tr)
+    assert ops.conv_affine_ok(spec, N, H, H)
+    aff = (sc.to(DEV), sh.to(DEV), relu)
+    y, st, ns = ops.conv_fwd_aff_raw(x.to(DEV), w.detach().to(DEV), b.to(DEV), spec, aff, True)
+    assert rel(y, yr) < 3e-5
+    gw, _ = ops.conv_wgrad_raw(x.to(DEV), gy.to(DEV), spec, wshape, False, aff=aff)
+    assert rel(gw, w.grad) < 3e-5
+    assert not ops.conv_affine_ok(ops.ConvSpec(64, 200, 7, 1, 0), N, 8, 8)       # generic path: must materialise
+
+
 @pytest.mark.parametrize('cin,cout,k,s,p,op,tr,H', [(128, 200, 3, 1, 0, 0, False, 8), (8, 128, 4, 1, 0, 0, True, 5)])
 def test_small_grid_wgrad_joint_product(cin, cout, k, s, p, op, tr, H):
     """6x6 / 5x5 folded grids (heads of conv32+ / deconv32+) at a batch where the weight gradient runs as one product

@@ -27,9 +27,15 @@ for name, N, cin, cout, k, s, p, op, tr, H in LAYERS:
     y = ops.conv_fwd_raw(x, w, b, spec)
     gy = torch.randn_like(y)
     flops = 2.0 * y.numel() / cout * cout * cin * k * k if not tr else 2.0 * x.numel() * cout * k * k
-    t_f = timeit(lambda: ops.conv_fwd_raw(x, w, b, spec))
+    aff = None
+    if os.environ.get('AFF') == '1' and ops.conv_affine_ok(spec, N, H, H):      # deferred BatchNorm on the input
+        aff = (torch.rand(cin, device='cuda') + 0.5, torch.randn(cin, device='cuda'), True)
+    if aff is not None:
+        t_f = timeit(lambda: ops.conv_fwd_aff_raw(x, w, b, spec, aff, True))
+    else:
+        t_f = timeit(lambda: ops.conv_fwd_stats_raw(x, w, b, spec))
     t_d = timeit(lambda: ops.conv_dgrad_raw(gy, w, spec, x.shape))
-    t_w = timeit(lambda: ops.conv_wgrad_raw(x, gy, spec, w.shape, False))
+    t_w = timeit(lambda: ops.conv_wgrad_raw(x, gy, spec, w.shape, False, aff=aff))
     tot += t_f + t_d + t_w
     print(f'{name} {flops/1e9:6.2f} GF  fwd {t_f:7.1f} us {flops/t_f/1e6:6.1f} TF | dgrad {t_d:7.1f} us {flops/t_d/1e6:6.1f} TF | wgrad {t_w:7.1f} us {flops/t_w/1e6:6.1f} TF')
 print('sum of all conv kernels (E0 dgrad included although unused): %.2f ms' % (tot / 1e3))
