@@ -70,7 +70,9 @@ int jvae_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, float* dbi
                           void* ws, size_t ws_bytes, void* stream);
 
 /* out[c] (+)= sum_{n,q} t[n][c][q]: bias gradient of a conv (P = OH*OW) or linear (P = 1) layer. */
-int jvae_channel_sum_f32(const float* t, float* out, int N, int C, int P, int accumulate, void* stream);
+size_t jvae_channel_sum_workspace_bytes(int C);
+int jvae_channel_sum_f32(const float* t, float* out, int N, int C, int P, int accumulate, void* ws, size_t ws_bytes,
+                         void* stream);
 
 /* ---- BatchNorm2d (+ fused ReLU) -------------------------------------------------------------------
  * x,y,dx,dy: (N,C,P) with P = H*W.  training != 0: batch statistics (biased variance in the forward,
@@ -247,7 +249,8 @@ int jvae_xent_bwd_f32(const float* logits, const long long* y, const float* g_ce
  * jvae_sqnorm_accum_f32: *acc += sum g^2 (reset != 0 zeroes acc first).
  * jvae_adam_step_f32: g' = g*min(1, max_norm/(sqrt(*sqnorm)+1e-6)) + weight_decay*p, Adam with bias
  * correction for `step` (>= 1); *nonfinite_flag |= 1 when an updated parameter is NaN/Inf. */
-int jvae_sqnorm_accum_f32(const float* g, long n, float* acc, int reset, void* stream);
+size_t jvae_sqnorm_workspace_bytes(void);
+int jvae_sqnorm_accum_f32(const float* g, long n, float* acc, int reset, void* ws, size_t ws_bytes, void* stream);
 int jvae_clip_scale_f32(float* g, long n, const float* sqnorm, float max_norm, void* stream);
 int jvae_adam_step_f32(float* p, const float* g, float* m, float* v, long n,
                        float lr, float beta1, float beta2, float eps, float weight_decay, long step,

@@ -9,7 +9,9 @@
 
 namespace {
 
-__global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g, long n, float* acc) {
+// partial[block] = sum of squares of this block's grid-stride share; sqnorm_fold_kernel adds the partials in block order
+// (no float atomics: the clip coefficient, hence every parameter update, is reproducible run to run)
+__global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g, long n, float* __restrict__ partial) {
     __shared__ float red[17];
     float s = 0.f;
     const long n4 = n >> 2;
@@ -20,7 +22,15 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g
     if (blockIdx.x == 0)
         for (long i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) s += g[i] * g[i];
     s = block_sum(s, red);
-    if (threadIdx.x == 0) atomicAdd(acc, s);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(256) void sqnorm_fold_kernel(const float* __restrict__ partial, int nblocks, float* acc, int reset) {
+    __shared__ float red[17];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nblocks; i += 256) s += partial[i];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) *acc = (reset ? 0.f : *acc) + s;
 }
 
 struct AdamP {
@@ -85,17 +95,25 @@ inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 
 extern "C" {
 
-// *acc (device float) += sum(g^2); reset != 0 zeroes it first (stream-ordered)
-int jvae_sqnorm_accum_f32(const float* g, long n, float* acc, int reset, void* stream) {
+// *acc (device float) (+)= sum(g^2) (reset != 0: = ); deterministic.  ws: jvae_sqnorm_workspace_bytes() bytes.
+size_t jvae_sqnorm_workspace_bytes(void) { return sizeof(float) * 8192; }
+
+int jvae_sqnorm_accum_f32(const float* g, long n, float* acc, int reset, void* ws, size_t ws_bytes, void* stream) {
     if (!acc || n < 0 || (n > 0 && !g)) return JVAE_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    if (reset) {
-        hipError_t e = hipMemsetAsync(acc, 0, sizeof(float), st);
-        if (e != hipSuccess) return (int)e;
+    if (n == 0) {
+        if (reset) {
+            hipError_t e = hipMemsetAsync(acc, 0, sizeof(float), st);
+            if (e != hipSuccess) return (int)e;
+        }
+        return 0;
     }
-    if (n == 0) return 0;
     if (!al16(g)) return JVAE_EINVAL;
-    hipLaunchKernelGGL(sqnorm_kernel, dim3(grid_for(n / 4)), dim3(256), 0, st, g, n, acc);
+    if (!ws || ws_bytes < jvae_sqnorm_workspace_bytes()) return JVAE_EWORKSPACE;
+    const int blocks = grid_for(n / 4);                      // <= 8192
+    hipLaunchKernelGGL(sqnorm_kernel, dim3(blocks), dim3(256), 0, st, g, n, (float*)ws);
+    JVAE_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sqnorm_fold_kernel, dim3(1), dim3(256), 0, st, (const float*)ws, blocks, acc, reset);
     JVAE_LAUNCH_CHECK();
     return 0;
 }

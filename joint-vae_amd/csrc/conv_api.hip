@@ -122,7 +122,7 @@ int jvae_conv2d_wgrad_aff_f32(const float* x, const float* dy, float* dw, float*
     const InAff aff{in_scale, in_shift, in_relu};
     int rc = jvae_conv_wgrad(g, transposed, x, dy, dw, (float*)ws, ws_bytes, st, &aff);
     if (rc) return rc;
-    if (dbias) rc = jvae_channel_sum(dy, dbias, N, Cout, oh * ow, accumulate, st);
+    if (dbias) rc = jvae_channel_sum(dy, dbias, N, Cout, oh * ow, accumulate, (float*)ws, ws_bytes, st);   // ws is free again
     return rc;
 }
 
@@ -156,14 +156,17 @@ int jvae_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, float* dbi
     }
     int rc = jvae_conv_wgrad(g, transposed, x, dy, dw, (float*)ws, ws_bytes, st);
     if (rc) return rc;
-    if (dbias) rc = jvae_channel_sum(dy, dbias, N, Cout, oh * ow, accumulate, st);
+    if (dbias) rc = jvae_channel_sum(dy, dbias, N, Cout, oh * ow, accumulate, (float*)ws, ws_bytes, st);   // ws is free again
     return rc;
 }
 
 // out[c] (+)= sum over n, q of t[n][c][q]   (bias gradients of conv / linear layers)
-int jvae_channel_sum_f32(const float* t, float* out, int N, int C, int P, int accumulate, void* stream) {
+size_t jvae_channel_sum_workspace_bytes(int C) { return jvae_channel_sum_ws_bytes(C); }
+
+int jvae_channel_sum_f32(const float* t, float* out, int N, int C, int P, int accumulate, void* ws, size_t ws_bytes,
+                         void* stream) {
     if (!t || !out || N < 0 || C <= 0 || P <= 0) return JVAE_EINVAL;
-    return jvae_channel_sum(t, out, N, C, P, accumulate, (hipStream_t)stream);
+    return jvae_channel_sum(t, out, N, C, P, accumulate, (float*)ws, ws_bytes, (hipStream_t)stream);
 }
 
 }  // extern "C"

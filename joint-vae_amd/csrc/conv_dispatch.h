@@ -12,7 +12,9 @@ int jvae_fold_bwd(const ConvGeom& g, const float* ys, const float* w, const floa
                   float* ws, size_t ws_bytes, hipStream_t st);
 int jvae_fold_wgrad(const ConvGeom& g, const float* xb, const float* ys, float* dw,
                     float* ws, size_t ws_bytes, hipStream_t st);
-int jvae_channel_sum(const float* t, float* out, int N, int C, int P, int accumulate, hipStream_t st);
+size_t jvae_channel_sum_ws_bytes(int C);
+int jvae_channel_sum(const float* t, float* out, int N, int C, int P, int accumulate, float* ws, size_t ws_bytes,
+                     hipStream_t st);
 
 // conv_mfma.hip: implicit-GEMM 5x5 kernels (forward-type)
 bool jvae_conv5_fwd_ok(int Cin, int H, int W, int Cout, int OH, int OW, int S, int P);

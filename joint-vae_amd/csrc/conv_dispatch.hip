@@ -55,7 +55,10 @@ size_t jvae_conv_ws(const ConvGeom& g, int transposed) {
     size_t b = is5(g) ? 4 * jvae_conv5_pack_floats(g.Cb, g.Cs) : 0;
     size_t c = wgrad_fast(g) ? 4 * wgrad_ws_floats(g) : 0;
     if (b > a) a = b;
-    return a > c ? a : c;
+    if (c > a) a = c;
+    if (transposed && point_input(g)) { const size_t d = 4 * (size_t)16 * g.N * g.Cs; if (d > a) a = d; }
+    const size_t e = jvae_channel_sum_ws_bytes(g.Cb > g.Cs ? g.Cb : g.Cs);
+    return a > e ? a : e;
 }
 
 // Can the forward of this layer emit per-workgroup BatchNorm partial sums, and how many per channel at most?
@@ -116,10 +119,13 @@ int jvae_conv_dgrad(const ConvGeom& g, int transposed, const float* dy, const fl
         return jvae_fold_bwd(g, dy, w, nullptr, dx, ws, ws_bytes, st);
     }
     if (point_input(g)) {
-        const int cols = g.Cb * g.KH * g.KW;        // dx[n][ci] = sum_j dy[n][j] w[ci][j]: few tiles, long K -> split-K
-        hipError_t e = hipMemsetAsync(dx, 0, sizeof(float) * (size_t)g.N * g.Cs, st);
-        if (e != hipSuccess) return (int)e;
-        return jvae_gemm_launch(g.N, g.Cs, cols, 1, dy, cols, 1, 0, w, 1, cols, 0, dx, g.Cs, 1, 0, nullptr, 0, 0, 16, st);
+        const int cols = g.Cb * g.KH * g.KW;        // dx[n][ci] = sum_j dy[n][j] w[ci][j]: few tiles, long K -> K pieces,
+        const long outf = (long)g.N * g.Cs;         // stored side by side and folded in a fixed order (deterministic)
+        if (ws_bytes < 4 * (size_t)(16 * outf)) return JVAE_EWORKSPACE;
+        int S = 0;
+        int rc = jvae_gemm_launch_part(g.N, g.Cs, cols, 1, dy, cols, 1, 0, w, 1, cols, 0, ws, g.Cs, 1, 0, outf, 16, &S, st);
+        if (rc) return rc;
+        return jvae_splitk_fold(ws, nullptr, dx, S, outf, g.Cs, 0, 0, st);
     }
     if (fold_fwd_fast(g) && ws_bytes >= 4 * jvae_conv5_pack_floats(g.Cb, g.Cs))
         return jvae_conv5_fwd(dy, w, 0, 0, nullptr, dx, g.N, g.Cb, g.Hb, g.Wb, g.Cs, g.Ws, g.S, g.P, ws, st);

@@ -85,9 +85,9 @@ __global__ __launch_bounds__(256) void fold_kernel(const float* __restrict__ col
     }
 }
 
-// out[c] += sum_{n in split, q} t[n][c][q]   (bias gradients; reference: autograd of the conv bias add).
-// grid (C, nsplit): each block reduces a slice of images with 16-byte loads, one float atomic per block.
-__global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ t, float* __restrict__ out,
+// partial[c][sp] = sum_{n in split sp, q} t[n][c][q]   (bias gradients; reference: autograd of the conv bias add).
+// grid (C, nsplit): each block reduces a slice of images with 16-byte loads; channel_fold_kernel adds the slices in order.
+__global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ t, float* __restrict__ partial,
                                                           int N, int C, int P, int nsplit) {
     __shared__ float red[17];
     const int c = blockIdx.x, sp = blockIdx.y;
@@ -110,7 +110,16 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restric
         }
     }
     s = block_sum(s, red);
-    if (threadIdx.x == 0 && ne > nb) atomicAdd(&out[c], s);
+    if (threadIdx.x == 0) partial[(long)c * nsplit + sp] = s;
+}
+
+__global__ void channel_fold_kernel(const float* __restrict__ partial, float* __restrict__ out, int C, int nsplit,
+                                    int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int k = 0; k < nsplit; ++k) s += partial[(long)c * nsplit + k];
+    out[c] = (accumulate ? out[c] : 0.f) + s;
 }
 
 inline int grid_for(long total) {
@@ -130,6 +139,16 @@ inline int wgrad_slices(const ConvGeom& g) {
     for (int S = 16; S > 1; S >>= 1)
         if (tiles * S <= 2048 && K % S == 0 && K / S >= 256) return S;
     return 1;
+}
+
+// position-batched forward: K pieces when the (image, channel, position) tiles alone cannot fill the chip
+inline int fwd_slices(const ConvGeom& g) {
+    if (!pixel_batched(g)) return 1;
+    const long Kd = (long)g.Cb * g.KH * g.KW;
+    const long tiles = (long)cdiv(g.N, 64) * cdiv(g.Cs, 64) * g.Hs * g.Ws;
+    if (tiles >= 512 || Kd < 1024) return 1;
+    int s = (int)(512 / tiles) + 1;
+    return s > 8 ? 8 : s;
 }
 
 // Yt[q][n][cs] = Ys[n][cs][q]
@@ -156,9 +175,11 @@ size_t jvae_conv_generic_ws(const ConvGeom& g) {
     if (imgs > g.N) imgs = g.N;
     if (pixel_batched(g)) imgs = g.N;            // [q][n][k] layout is not chunked (tiny grids only)
     size_t bytes = (size_t)(imgs * per);
+    size_t extra = 0;
     if (wgrad_joint(g))                          // + transposed Ys + the K-slice partial products
-        bytes += 4 * ((size_t)g.N * g.Cs * g.Hs * g.Ws + (size_t)wgrad_slices(g) * g.Cs * g.Cb * g.KH * g.KW);
-    return bytes;
+        extra = 4 * ((size_t)g.N * g.Cs * g.Hs * g.Ws + (size_t)wgrad_slices(g) * g.Cs * g.Cb * g.KH * g.KW);
+    const size_t fwd_extra = fwd_slices(g) > 1 ? 4 * (size_t)fwd_slices(g) * g.N * g.Cs * g.Hs * g.Ws : 0;
+    return bytes + (extra > fwd_extra ? extra : fwd_extra);
 }
 
 static int chunk_images(const ConvGeom& g, size_t ws_bytes) {
@@ -177,16 +198,20 @@ int jvae_fold_fwd(const ConvGeom& g, const float* xb, const float* w, const floa
         hipLaunchKernelGGL(unfold_kernel, dim3(grid_for((long)g.N * Kd * Ps)), dim3(256), 0, st, xb, ws, g, 0, g.N,
                            (long)Kd, 1L, (long)g.N * Kd, 1);
         JVAE_LAUNCH_CHECK();
-        const long tiles = (long)cdiv(g.N, 64) * cdiv(g.Cs, 64) * Ps;
-        int splitk = 1;
-        if (tiles < 512 && Kd >= 1024) {
-            splitk = (int)(512 / tiles) + 1;                     // long K, few tiles: split-K onto a zeroed output
-            if (splitk > 8) splitk = 8;
-            hipError_t e = hipMemsetAsync(ys, 0, sizeof(float) * (size_t)g.N * g.Cs * Ps, st);
-            if (e != hipSuccess) return (int)e;
+        const int want = fwd_slices(g);
+        if (want > 1) {
+            // long K, few tiles: K pieces stored side by side (copies of the output layout), folded in a fixed order
+            const long colf = (long)col_floats_per_image(g) * g.N, outf = (long)g.N * g.Cs * Ps;
+            if (ws_bytes < 4 * (size_t)(colf + want * outf)) return JVAE_EWORKSPACE;
+            float* part = ws + colf;
+            int S = 0;
+            int rc = jvae_gemm_launch_part(g.N, g.Cs, Kd, Ps, ws, Kd, 1, (long)g.N * Kd, w, 1, Kd, 0,
+                                           part, (long)g.Cs * Ps, Ps, 1, outf, want, &S, st);
+            if (rc) return rc;
+            return jvae_splitk_fold(part, bias, ys, S, outf, g.Cs, 0, 0, st, Ps);
         }
         return jvae_gemm_launch(g.N, g.Cs, Kd, Ps, ws, Kd, 1, (long)g.N * Kd, w, 1, Kd, 0,
-                                ys, (long)g.Cs * Ps, Ps, 1, bias, bias ? 1 : 0, 0, splitk, st);
+                                ys, (long)g.Cs * Ps, Ps, 1, bias, bias ? 1 : 0, 0, 1, st);
     }
     const int chunk = chunk_images(g, ws_bytes);
     if (chunk < 1) return JVAE_EWORKSPACE;
@@ -280,20 +305,30 @@ int jvae_fold_wgrad(const ConvGeom& g, const float* xb, const float* ys, float* 
     return 0;
 }
 
-int jvae_channel_sum(const float* t, float* out, int N, int C, int P, int accumulate, hipStream_t st) {
+size_t jvae_channel_sum_ws_bytes(int C) { return sizeof(float) * (size_t)(C > 0 ? C : 1) * 64; }
+
+// out[c] (+)= sum_{n,q} t[n][c][q], deterministic (no float atomics); ws: jvae_channel_sum_ws_bytes(C)
+int jvae_channel_sum(const float* t, float* out, int N, int C, int P, int accumulate, float* ws, size_t ws_bytes,
+                     hipStream_t st) {
     if (C <= 0) return 0;
-    if (!accumulate) {
-        hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)C, st);
-        if (e != hipSuccess) return (int)e;
+    if (N <= 0) {
+        if (!accumulate) {
+            hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)C, st);
+            if (e != hipSuccess) return (int)e;
+        }
+        return 0;
     }
-    if (N <= 0) return 0;
+    if (!ws || ws_bytes < jvae_channel_sum_ws_bytes(C)) return JVAE_EWORKSPACE;
     long work = (long)N * P;
     int ns = (int)(work / 4096);
     const int cap = (1024 + C - 1) / C;
     if (ns > cap) ns = cap;
+    if (ns > 64) ns = 64;
     if (ns > N) ns = N;
     if (ns < 1) ns = 1;
-    hipLaunchKernelGGL(channel_sum_kernel, dim3(C, ns), dim3(256), 0, st, t, out, N, C, P, ns);
+    hipLaunchKernelGGL(channel_sum_kernel, dim3(C, ns), dim3(256), 0, st, t, ws, N, C, P, ns);
+    JVAE_LAUNCH_CHECK();
+    hipLaunchKernelGGL(channel_fold_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, (const float*)ws, out, C, ns, accumulate);
     JVAE_LAUNCH_CHECK();
     return 0;
 }

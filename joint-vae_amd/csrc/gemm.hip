@@ -27,7 +27,8 @@ struct GemmP {
     int M, N, K;
     int splitk;          // grid.z = batch * splitk
     int kchunk;          // K elements per split (multiple of BK)
-    int flags;           // 1 = accumulate into C, 2 = ReLU, 4 = atomic add (split-K)
+    int flags;           // 1 = accumulate into C, 2 = ReLU, 4 = atomic add (split-K), 8 = split s stores to C + s*sCsplit
+    long sCsplit;        // (flag 8) element distance between the partial results of consecutive K splits
     int vecA, vecB;      // 16-byte vector loads are legal for this operand
 };
 
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
     const int kend = min(p.K, kbeg + p.kchunk);
     const float* A = p.A + (long)batch * p.sAb;
     const float* B = p.B + (long)batch * p.sBb;
-    float* C = p.C + (long)batch * p.sCb;
+    float* C = p.C + (long)batch * p.sCb + ((p.flags & 8) ? (long)split * p.sCsplit : 0L);
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
     }
 
     // epilogue: D[i][j]: j = lane&31, i = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    const bool lead = (split == 0);
+    const bool lead = (split == 0) && !(p.flags & 8);
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -174,7 +175,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
                 float v = acc[i][j][r] + bn;
                 if (p.bias_mode == 2 && lead) v += p.bias[m];
                 float* dst = C + (long)m * p.sCm + (long)n * p.sCn;
-                if (p.flags & 4) {
+                if (p.flags & 8) {
+                    *dst = v;
+                } else if (p.flags & 4) {
                     atomicAdd(dst, v);
                 } else {
                     if (p.flags & 1) v += *dst;
@@ -231,7 +234,8 @@ int jvae_gemm_launch_ex(int M, int N, int K, int batch,
     p.kchunk = cdiv(ktiles, splitk) * BK;
     splitk = K > 0 ? cdiv(K, p.kchunk) : 1;
     p.splitk = splitk;
-    p.flags = flags;
+    p.flags = flags & ~8;
+    p.sCsplit = 0;
     if (splitk > 1) {
         if (flags & 2) return JVAE_EINVAL;        // ReLU cannot follow a partial sum
         p.flags |= 4;                             // caller pre-zeroes C (or wants accumulation)
@@ -245,13 +249,44 @@ int jvae_gemm_launch_ex(int M, int N, int K, int batch,
     return launch_tile<64, 64>(p, batch, st);
 }
 
+// Deterministic split-K: K is cut into *splits pieces whose partial products are STORED side by side (part + s*sCsplit,
+// same strides as C); no atomics, no bias.  Fold them with jvae_splitk_fold.  Returns the number of pieces in *splits.
+int jvae_gemm_launch_part(int M, int N, int K, int batch,
+                          const float* A, long sAm, long sAk, long sAb,
+                          const float* B, long sBk, long sBn, long sBb,
+                          float* part, long sCm, long sCn, long sCb, long sCsplit, int want_splits, int* splits,
+                          hipStream_t st) {
+    if (splits) *splits = 0;
+    if (M <= 0 || N <= 0 || batch <= 0) return 0;
+    if (K <= 0 || !A || !B || !part || !splits) return JVAE_EINVAL;
+    GemmP p;
+    p.A = A; p.sAm = sAm; p.sAk = sAk; p.sAb = sAb;
+    p.B = B; p.sBk = sBk; p.sBn = sBn; p.sBb = sBb;
+    p.C = part; p.sCm = sCm; p.sCn = sCn; p.sCb = sCb;
+    p.bias = nullptr; p.bias_mode = 0; p.bias_div = 1;
+    p.M = M; p.N = N; p.K = K;
+    int splitk = want_splits < 1 ? 1 : want_splits;
+    const int ktiles = cdiv(K, BK);
+    if (splitk > ktiles) splitk = ktiles;
+    p.kchunk = cdiv(ktiles, splitk) * BK;
+    splitk = cdiv(K, p.kchunk);
+    p.splitk = splitk;
+    p.flags = 8;
+    p.sCsplit = sCsplit;
+    const bool ak = (sAk == 1), bnc = (sBn == 1);
+    p.vecA = aligned16(A) && (sAb % 4 == 0) && (ak ? (sAm % 4 == 0) : (sAm == 1 && sAk % 4 == 0));
+    p.vecB = aligned16(B) && (sBb % 4 == 0) && (bnc ? (sBk % 4 == 0) : (sBk == 1 && sBn % 4 == 0));
+    *splits = splitk;
+    return launch_tile<64, 64>(p, batch, st);
+}
+
 // y[i] = [relu](bias[i % N] + sum_s part[s][i]) in a fixed order: the deterministic second half of a split-K product
 // whose S partial products were written side by side by a batched launch (batch = K slices).
 __global__ __launch_bounds__(256) void splitk_fold_kernel(const float* __restrict__ part, const float* __restrict__ bias,
                                                           float* __restrict__ y, int S, long MN, int N, int relu,
-                                                          int accumulate) {
+                                                          int accumulate, int bias_div) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < MN; i += (long)gridDim.x * blockDim.x) {
-        float v = bias ? bias[i % N] : 0.f;
+        float v = bias ? bias[(i / bias_div) % N] : 0.f;
         for (int s = 0; s < S; ++s) v += part[(long)s * MN + i];
         if (accumulate) v += y[i];
         y[i] = relu ? fmaxf(v, 0.f) : v;
@@ -259,10 +294,11 @@ __global__ __launch_bounds__(256) void splitk_fold_kernel(const float* __restric
 }
 
 int jvae_splitk_fold(const float* part, const float* bias, float* y, int S, long MN, int N, int relu, int accumulate,
-                     hipStream_t st) {
+                     hipStream_t st, int bias_div) {
     if (MN == 0) return 0;
     const int blocks = (int)((MN + 255) / 256 > 4096 ? 4096 : (MN + 255) / 256);
-    hipLaunchKernelGGL(splitk_fold_kernel, dim3(blocks), dim3(256), 0, st, part, bias, y, S, MN, N, relu, accumulate);
+    hipLaunchKernelGGL(splitk_fold_kernel, dim3(blocks), dim3(256), 0, st, part, bias, y, S, MN, N, relu, accumulate,
+                       bias_div > 0 ? bias_div : 1);
     JVAE_LAUNCH_CHECK();
     return 0;
 }

@@ -18,8 +18,16 @@ int jvae_gemm_launch_ex(int M, int N, int K, int batch,
                         const float* bias, int bias_mode, int bias_div, int flags, int splitk, hipStream_t st);
 
 // y[i] = [relu]([y[i] +] bias[i % N] + sum_s part[s][i]): fixed-order fold of S partial products (gemm.hip)
+// bias index = (i / bias_div) % N
 int jvae_splitk_fold(const float* part, const float* bias, float* y, int S, long MN, int N, int relu, int accumulate,
-                     hipStream_t st);
+                     hipStream_t st, int bias_div = 1);
+
+// deterministic split-K: partial products stored side by side (gemm.hip); *splits receives the number of pieces
+int jvae_gemm_launch_part(int M, int N, int K, int batch,
+                          const float* A, long sAm, long sAk, long sAb,
+                          const float* B, long sBk, long sBn, long sBb,
+                          float* part, long sCm, long sCn, long sCb, long sCsplit, int want_splits, int* splits,
+                          hipStream_t st);
 
 // Optional per-input-channel transform applied while a convolution stages its INPUT: a = [relu](x*sc[c] + sh[c]).
 // This is the BatchNorm(+ReLU) that produced the layer input, deferred into the consumer so that the normalised

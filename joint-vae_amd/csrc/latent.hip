@@ -124,7 +124,8 @@ __global__ __launch_bounds__(256) void latent_fwd_kernel(LatentP p, float* __res
 
 // Backward.  Upstream: gz (L+1,N,K) [may be null], g_kl, g_zdist, g_vkl (N,) [each may be null],
 // gmu_direct / glv_direct (N,K) [may be null: gradients reaching mu / clipped log_var from other consumers].
-// Outputs: gmu, glv_raw (N,K); gmeans (C,K) and gT accumulate with float atomics (pre-zeroed by caller).
+// Outputs: gmu, glv_raw (N,K); gd_scratch (N,K) = per-sample contribution to the gradient of its class mean (reduced in
+// sample order by means_grad_kernel: deterministic); gT (diag / full variance only) accumulates with float atomics.
 __global__ __launch_bounds__(256) void latent_bwd_kernel(LatentP p, const float* __restrict__ lv,   // clipped
                                                          const float* __restrict__ gz, const float* __restrict__ g_kl,
                                                          const float* __restrict__ g_zdist, const float* __restrict__ g_vkl,
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(256) void latent_bwd_kernel(LatentP p, const float*
                                                          const float* __restrict__ glv_direct,
                                                          const float* __restrict__ kl_fwd_terms,   // uniform: (N,2) = (elogq+nel, vk)
                                                          float* __restrict__ gmu, float* __restrict__ glv_raw,
-                                                         float* gmeans, float* gT) {
+                                                         float* gd_scratch, float* gT) {
     const int lane = threadIdx.x & 63;
     const int n = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (n >= p.N) return;
@@ -226,12 +227,24 @@ __global__ __launch_bounds__(256) void latent_bwd_kernel(LatentP p, const float*
             g_d += g_dist * 2.f * Td;
         }
         g_mu += g_d;
-        if (gmeans && g_d != 0.f) atomicAdd(&gmeans[(long)cls * K + k], -g_d);
+        if (gd_scratch) gd_scratch[row + k] = -g_d;          // summed per class in sample order by means_grad_kernel
         gmu[row + k] = g_mu;
         const float raw = p.lv_raw ? p.lv_raw[row + k] : 0.f;
         const bool pass = p.has_forced ? false : (raw >= -20.f && raw <= 20.f);
         glv_raw[row + k] = pass ? g_lv : 0.f;
     }
+}
+
+// gmeans[cls][k] += sum over the samples n of class cls, in sample order, of gd[n][k]
+__global__ __launch_bounds__(256) void means_grad_kernel(const float* __restrict__ gd, const long long* __restrict__ y,
+                                                         float* __restrict__ gmeans, int N, int C, int K) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C * K) return;
+    const int cls = i / K, k = i % K;
+    float s = 0.f;
+    for (int n = 0; n < N; ++n)
+        if ((int)y[n] == cls) s += gd[(long)n * K + k];
+    gmeans[i] += s;
 }
 
 // dict[0..K) = mean over classes of the dictionary rows; dict[K] = mean_c |m_c|^2 - |mean|^2   (cvae.py:747-752)
@@ -350,9 +363,18 @@ int jvae_latent_bwd_f32(const float* mu, const float* lv_raw, const float* lv, c
         hipLaunchKernelGGL(uniform_terms_kernel, dim3(cdiv(N, 4)), dim3(256), 0, st, p, lv, terms);
         JVAE_LAUNCH_CHECK();
     }
+    float* gd = nullptr;
+    if (gmeans) {                                   // per-sample scratch behind the 2N floats of the uniform prior's terms
+        if (!ws || ws_bytes < sizeof(float) * ((size_t)2 * N + (size_t)N * K)) return JVAE_EWORKSPACE;
+        gd = (float*)ws + (size_t)2 * N;
+    }
     hipLaunchKernelGGL(latent_bwd_kernel, dim3(cdiv(N, 4)), dim3(256), 0, st, p, lv, gz, g_kl, g_zdist, g_vkl,
-                       gmu_direct, glv_direct, terms, gmu, glv_raw, gmeans, gT);
+                       gmu_direct, glv_direct, terms, gmu, glv_raw, gd, gT);
     JVAE_LAUNCH_CHECK();
+    if (gmeans) {
+        hipLaunchKernelGGL(means_grad_kernel, dim3(cdiv((long)C * K, 256)), dim3(256), 0, st, (const float*)gd, y, gmeans, N, C, K);
+        JVAE_LAUNCH_CHECK();
+    }
     return 0;
 }
 

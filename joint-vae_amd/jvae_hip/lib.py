@@ -43,7 +43,8 @@ _SIGS = {
     'jvae_conv2d_affine_ok': (c_int, [c_int] * 11),
     'jvae_conv2d_fwd_aff_f32': (c_int, [P, P, P, P, P, POINTER(c_int), P, P, c_int] + [c_int] * 11 + [P, c_size_t, P]),
     'jvae_conv2d_wgrad_aff_f32': (c_int, [P, P, P, P, c_int, P, P, c_int] + [c_int] * 11 + [P, c_size_t, P]),
-    'jvae_channel_sum_f32': (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    'jvae_channel_sum_workspace_bytes': (c_size_t, [c_int]),
+    'jvae_channel_sum_f32': (c_int, [P, P, c_int, c_int, c_int, c_int, P, c_size_t, P]),
     'jvae_bn_workspace_bytes': (c_size_t, [c_int]),
     'jvae_bn_fwd_f32': (c_int, [P] * 9 + [c_int, c_int, c_int, c_float, c_float, c_int, c_int, P, c_size_t, P]),
     'jvae_bn_fwd_ext_f32': (c_int, [P] * 9 + [c_int, c_int, c_int, c_float, c_float, c_int, c_int, P, c_int, P, P, c_size_t, P]),
@@ -65,7 +66,8 @@ _SIGS = {
     'jvae_xent_fwd_f32': (c_int, [P, P, P, c_int, c_int, c_int, P]),
     'jvae_xent_bwd_f32': (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
     'jvae_augment_u8_f32': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
-    'jvae_sqnorm_accum_f32': (c_int, [P, c_long, P, c_int, P]),
+    'jvae_sqnorm_workspace_bytes': (c_size_t, []),
+    'jvae_sqnorm_accum_f32': (c_int, [P, c_long, P, c_int, P, c_size_t, P]),
     'jvae_clip_scale_f32': (c_int, [P, c_long, P, c_float, P]),
     'jvae_adam_step_f32': (c_int, [P, P, P, P, c_long] + [c_float] * 5 + [c_long, c_float, P, P, P]),
 }

@@ -4,6 +4,7 @@ PyTorch is plumbing here (device memory, streams, the autograd tape); every FLOP
 executed by the hand-written gfx950 kernels.  Every function raises if its tensors are not on the GPU.
 """
 import math
+import os as _os
 from ctypes import byref, c_int
 
 import torch
@@ -59,7 +60,9 @@ def channel_sum(t, N, C, P, out=None, accumulate=False):
     lib = L.load()
     if out is None:
         out = torch.empty(C, device=t.device, dtype=torch.float32)
-    L.check(lib.jvae_channel_sum_f32(L.ptr(t), L.ptr(out), N, C, P, int(accumulate), L.stream_ptr()), 'channel_sum')
+    ws = L.workspace(lib.jvae_channel_sum_workspace_bytes(C), t.device)
+    L.check(lib.jvae_channel_sum_f32(L.ptr(t), L.ptr(out), N, C, P, int(accumulate), L.ptr(ws), ws.numel(), L.stream_ptr()),
+            'channel_sum')
     return out
 
 
@@ -296,7 +299,8 @@ class _Conv(torch.autograd.Function):
         if ctx.needs_input_grad[1] or want_b:
             w_slot = _grad_slot(ctx.w_ref)
             b_slot = _grad_slot(ctx.b_ref) if want_b else None
-            if OVERLAP_WGRAD and w_slot is not None and (b_slot is not None or not want_b):
+            if OVERLAP_WGRAD and w_slot is not None and (b_slot is not None or not want_b) \
+                    and not (ctx.aff is not None and _os.environ.get('JVAE_AFF_SIDE') == '0'):
                 # in-place into the flat gradient buffer: nothing downstream of this node consumes the result before
                 # the optimiser, so the kernel goes to the side stream and overlaps the rest of backward
                 main = torch.cuda.current_stream(x.device)
@@ -578,7 +582,7 @@ class _Latent(torch.autograd.Function):
         need_T = ctx.needs_input_grad[5] and var_dim != 0
         gmeans = torch.zeros_like(means) if need_means else None
         gT = torch.zeros_like(T) if need_T else None
-        nb = 8 * N
+        nb = 8 * N + 4 * N * mu.shape[-1]
         ws = L.workspace(nb, dev)
 
         def opt(t):
@@ -686,7 +690,7 @@ def measures(x, wmse, zdist, var_kl, sigma, sigma_is_log, means, flag, scratch, 
     `prev`: the tensor returned for the previous batch (running means are continued on the device)."""
     lib = L.load()
     x = _c(x)
-    L.check(lib.jvae_sqnorm_accum_f32(L.ptr(x), x.numel(), L.ptr(scratch), 1, L.stream_ptr()), 'sumsq(x)')
+    sqnorm_accum(x, scratch, True)
     out = torch.empty(16, device=x.device, dtype=torch.float32)
     C, K = (means.shape if means is not None else (0, 0))
     rc = lib.jvae_measures_f32(L.ptr(scratch), x.numel(), L.ptr(_c(wmse)), L.ptr(_c(zdist)), L.ptr(_c(var_kl)), wmse.numel(), zdist.numel(),
@@ -727,7 +731,9 @@ def cross_entropy_rows(logits, y):
 
 # ------------------------------------------------------------------------------------------- optimiser
 def sqnorm_accum(g, acc, reset):
-    L.check(L.load().jvae_sqnorm_accum_f32(L.ptr(g), g.numel(), L.ptr(acc), int(reset), L.stream_ptr()), 'sqnorm')
+    lib = L.load()
+    ws = L.workspace(lib.jvae_sqnorm_workspace_bytes(), g.device)
+    L.check(lib.jvae_sqnorm_accum_f32(L.ptr(g), g.numel(), L.ptr(acc), int(reset), L.ptr(ws), ws.numel(), L.stream_ptr()), 'sqnorm')
 
 
 def clip_scale(g, sqnorm, max_norm):

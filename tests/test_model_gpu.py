@@ -303,3 +303,28 @@ def test_wim_finetune_step_matches_reference_golden(golden_dir):
     for f in g.files:
         if f.startswith('buffer_after.'):                       # BatchNorm saw two batches: running stats updated twice
             assert rel(bufs[f[13:]].double(), g[f]) < 2e-5, f
+
+
+def test_training_step_is_bit_reproducible():
+    """Two identical models on the same batch / epsilon: gradients after the first backward and parameters after two
+    optimiser steps are BIT-identical (no float atomics anywhere on the path: K-sliced products and channel / class /
+    norm reductions are folded in a fixed order; weight gradients on the side stream write disjoint slots)."""
+    case = get_case('c2_n8')
+    kw = case['net']
+    a, b = build(case), build(case)
+    x, y, eps = (t.to(DEV) for t in det_inputs(8, kw['input_shape'], kw['num_labels'], 1, kw['latent_dim']))
+    for step in range(2):
+        for net in (a, b):
+            net.optimizer.zero_grad()
+            out = net.evaluate(x, y, with_beta=True, epsilon=eps)
+            out[2]['total'].mean().backward()
+        torch.cuda.synchronize()
+        for (k, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
+            if p.grad is not None:
+                assert torch.equal(p.grad, q.grad), (step, k)
+        for net in (a, b):
+            net.optimizer.clip(net.parameters())
+            net.optimizer.step()
+        torch.cuda.synchronize()
+        for (k, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
+            assert torch.equal(p, q), (step, k)

@@ -21,6 +21,11 @@ for step in range(2):
     torch.cuda.synchronize()
     worst = max(((float((p.grad - q.grad).abs().max() / (q.grad.abs().max() + 1e-30)), k) for (k, p), (_, q) in zip(a.named_parameters(), b.named_parameters()) if p.grad is not None), key=lambda t: t[0])
     print('step', step, 'worst grad rel diff', worst)
+    if step == 0:
+        for (k, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
+            if p.grad is not None:
+                d = float((p.grad - q.grad).abs().max() / (q.grad.abs().max() + 1e-30))
+                if d > 1e-5: print('   ', k, d)
     for n in (a, b):
         n.optimizer.clip(n.parameters()); n.optimizer.step()
     torch.cuda.synchronize()
