@@ -8,7 +8,8 @@ spec = ops.ConvSpec(32, 32, 5, 1, 2, 0, transposed=True)
 x = torch.randn(1024, 32, 32, 32, device='cuda')
 w = torch.randn(32, 32, 5, 5, device='cuda') * 0.03
 b = torch.zeros(32, device='cuda')
+aff = (torch.rand(32, device='cuda') + 0.5, torch.randn(32, device='cuda') * 0.1, True)      # as in the training step
 for _ in range(10):
-    y = ops.conv_fwd_raw(x, w, b, spec)
+    y, _, _ = ops.conv_fwd_aff_raw(x, w, b, spec, aff, True)
 torch.cuda.synchronize()
 print('done', float(y[0, 0, 0, 0]))
