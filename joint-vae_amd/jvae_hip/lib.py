@@ -107,7 +107,13 @@ def check(rc, what):
         raise JvaeHipError(f'{what} failed: {msg}')
 
 
-def stream_ptr():
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
+def stream_ptr(device_index=None):
+    """hipStream_t of the current stream (the raw-handle query: this is called by every op)."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device() if device_index is None else device_index)
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -147,8 +153,8 @@ def join_side_stream(device=None):
 
 def workspace(nbytes, device):
     """Stream-ordered scratch shared by all ops of one (device, stream) (grown on demand, never shrunk)."""
-    key = (device.type, device.index if device.index is not None else torch.cuda.current_device(),
-           torch.cuda.current_stream(device).cuda_stream)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    key = (idx, stream_ptr(idx))
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
         _workspaces[key] = ws = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)

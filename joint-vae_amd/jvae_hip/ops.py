@@ -152,6 +152,17 @@ def linear(x, w, b=None, act=IDENT):
 
 
 # ------------------------------------------------------------------------------------------- conv
+_GEOM_CACHE = {}          # pure functions of the layer geometry asked through the C ABI (host-side memo: every op asks)
+
+
+def _geom_query(name, geom):
+    key = (name, geom)
+    r = _GEOM_CACHE.get(key)
+    if r is None:
+        _GEOM_CACHE[key] = r = getattr(L.load(), name)(*geom)
+    return r
+
+
 class ConvSpec:
     __slots__ = ('cin', 'cout', 'k', 's', 'p', 'op', 'transposed')
 
@@ -159,18 +170,22 @@ class ConvSpec:
         self.cin, self.cout, self.k, self.s, self.p, self.op, self.transposed = cin, cout, k, s, p, op, bool(transposed)
 
     def out_hw(self, H, W):
-        oh, ow = c_int(), c_int()
-        rc = L.load().jvae_conv2d_out_shape(H, W, self.k, self.k, self.s, self.p, self.op, int(self.transposed),
-                                            byref(oh), byref(ow))
-        L.check(rc, 'jvae_conv2d_out_shape')
-        return oh.value, ow.value
+        key = ('hw', self.k, self.s, self.p, self.op, self.transposed, H, W)
+        r = _GEOM_CACHE.get(key)
+        if r is None:
+            oh, ow = c_int(), c_int()
+            rc = L.load().jvae_conv2d_out_shape(H, W, self.k, self.k, self.s, self.p, self.op, int(self.transposed),
+                                                byref(oh), byref(ow))
+            L.check(rc, 'jvae_conv2d_out_shape')
+            _GEOM_CACHE[key] = r = (oh.value, ow.value)
+        return r
 
     def geom(self, N, H, W):
         return (N, self.cin, H, W, self.cout, self.k, self.k, self.s, self.p, self.op, int(self.transposed))
 
 
 def _conv_ws(geom, device):
-    nbytes = L.load().jvae_conv2d_workspace_bytes(*geom)
+    nbytes = _geom_query('jvae_conv2d_workspace_bytes', geom)
     ws = L.workspace(nbytes, device)
     return ws, ws.numel()
 
@@ -192,7 +207,7 @@ def conv_fwd_stats_raw(x, w, b, spec):
     lib = L.load()
     N, _, H, W = x.shape
     geom = spec.geom(N, H, W)
-    cap = lib.jvae_conv2d_stats_splits(*geom)
+    cap = _geom_query('jvae_conv2d_stats_splits', geom)
     if cap <= 0:
         return conv_fwd_raw(x, w, b, spec), None, 0
     oh, ow = spec.out_hw(H, W)
@@ -208,7 +223,7 @@ def conv_fwd_stats_raw(x, w, b, spec):
 
 def conv_affine_ok(spec, N, H, W):
     """Can this layer apply a deferred BatchNorm(+ReLU) to its input (forward and weight gradient kernels)?"""
-    return bool(L.load().jvae_conv2d_affine_ok(*spec.geom(N, H, W)))
+    return bool(_geom_query('jvae_conv2d_affine_ok', spec.geom(N, H, W)))
 
 
 def conv_fwd_aff_raw(x, w, b, spec, aff, want_stats):
@@ -221,7 +236,7 @@ def conv_fwd_aff_raw(x, w, b, spec, aff, want_stats):
     y = torch.empty((N, spec.cout, oh, ow), device=x.device, dtype=torch.float32)
     stats, ns = None, c_int(0)
     if want_stats:
-        cap = lib.jvae_conv2d_stats_splits(*geom)
+        cap = _geom_query('jvae_conv2d_stats_splits', geom)
         if cap > 0:
             stats = torch.empty((spec.cout * cap * 2,), device=x.device, dtype=torch.float32)
     ws, nb = _conv_ws(geom, x.device)

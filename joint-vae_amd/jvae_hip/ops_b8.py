@@ -40,11 +40,11 @@ def unpack(y, C, out=None, accumulate=False):
 
 
 def native_mask(spec, N, H, W):
-    return L.load().jvae_conv2d_native_b8(*spec.geom(N, H, W))
+    return O._geom_query('jvae_conv2d_native_b8', spec.geom(N, H, W))
 
 
 def _ws(geom, device):
-    nbytes = L.load().jvae_conv2d_workspace_bytes_b8(*geom)
+    nbytes = O._geom_query('jvae_conv2d_workspace_bytes_b8', geom)
     ws = L.workspace(max(nbytes, 16), device)
     return ws, ws.numel()
 
@@ -62,7 +62,7 @@ def conv_fwd_raw(x, w, b, spec, out_f32=False, want_stats=False):
         y = torch.empty((N, cblocks(spec.cout), oh, ow, 8), device=x.device, dtype=torch.bfloat16)
     stats, ns = None, c_int(0)
     if want_stats:
-        cap = lib.jvae_conv2d_stats_splits_b8(*geom)
+        cap = O._geom_query('jvae_conv2d_stats_splits_b8', geom)
         if cap > 0:
             stats = torch.empty((spec.cout * cap * 2,), device=x.device, dtype=torch.float32)
     ws, nb = _ws(geom, x.device)

@@ -91,7 +91,11 @@ class HipConv2d(nn.Conv2d):
     """nn.Conv2d parameters (same init / state_dict), forward on the HIP implicit-GEMM kernels."""
 
     def _spec(self):
-        return ops.ConvSpec(self.in_channels, self.out_channels, self.kernel_size[0], self.stride[0], self.padding[0])
+        sp = self.__dict__.get('_conv_spec')
+        if sp is None:
+            sp = ops.ConvSpec(self.in_channels, self.out_channels, self.kernel_size[0], self.stride[0], self.padding[0])
+            self.__dict__['_conv_spec'] = sp
+        return sp
 
     def forward(self, x, dead_bias=False, stats_out=None, aff=None):
         return ops.conv2d(x, self.weight, self.bias, self._spec(), dead_bias, stats_out, aff)
@@ -99,8 +103,12 @@ class HipConv2d(nn.Conv2d):
 
 class HipConvTranspose2d(nn.ConvTranspose2d):
     def _spec(self):
-        return ops.ConvSpec(self.in_channels, self.out_channels, self.kernel_size[0], self.stride[0], self.padding[0],
-                            self.output_padding[0], transposed=True)
+        sp = self.__dict__.get('_conv_spec')
+        if sp is None:
+            sp = ops.ConvSpec(self.in_channels, self.out_channels, self.kernel_size[0], self.stride[0], self.padding[0],
+                              self.output_padding[0], transposed=True)
+            self.__dict__['_conv_spec'] = sp
+        return sp
 
     def forward(self, x, output_size=None, dead_bias=False, stats_out=None, aff=None):
         return ops.conv2d(x, self.weight, self.bias, self._spec(), dead_bias, stats_out, aff)
