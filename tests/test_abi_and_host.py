@@ -31,6 +31,34 @@ def test_library_exports_every_declared_symbol():
     assert b'gfx950' in lib.load().jvae_version()
 
 
+def test_ctypes_signatures_match_the_header():
+    """Argument count and pointer / integer / float class of every ctypes signature against the prototype in the header
+    (a mismatch would pass garbage registers to the kernels' launchers)."""
+    import ctypes
+    from jvae_hip import lib
+    src = open(os.path.join(REPO, 'include', 'jvae_hip.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    protos = dict(re.findall(r'\b(jvae_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;', src, flags=re.S))
+    assert set(protos) == set(lib._SIGS)
+    for name, (res, args) in lib._SIGS.items():
+        plist = [a.strip() for a in protos[name].replace('\n', ' ').split(',')]
+        if plist == ['void'] or plist == ['']:
+            plist = []
+        assert len(plist) == len(args), (name, len(plist), len(args))
+        for decl, ct in zip(plist, args):
+            is_ptr = '*' in decl
+            if is_ptr:
+                assert ct in (ctypes.c_void_p, ctypes.c_char_p) or hasattr(ct, '_type_') and hasattr(ct, 'contents'), (name, decl)
+            elif re.match(r'^(const\s+)?float\b', decl):
+                assert ct is ctypes.c_float, (name, decl)
+            elif re.match(r'^(const\s+)?size_t\b', decl):
+                assert ct is ctypes.c_size_t, (name, decl)
+            elif re.match(r'^(const\s+)?long\b', decl):
+                assert ct is ctypes.c_long, (name, decl)
+            else:
+                assert ct is ctypes.c_int, (name, decl)
+
+
 def test_out_shape_entry_point_is_host_only():
     from jvae_hip import ops
     assert ops.ConvSpec(3, 32, 5, 1, 2).out_hw(32, 32) == (32, 32)
