@@ -271,10 +271,10 @@ int launch_fwd_ow(const FwdP& p, hipStream_t st) {
     auto wgs = [&](int mt, int nt) { return ((pixels + mt * 128 - 1) / (mt * 128)) * (p.Cout / (nt * 32)); };
     constexpr long ENOUGH = 768;
     if (p.Cin <= 4) return launch_fwd<S, OW, 4, 1, 4>(p, st);      // 3-channel inputs: one chunk of 2 channel pairs
-    if (p.Cout % 64 == 0 && wgs(2, 2) >= ENOUGH) return launch_fwd<S, OW, 2, 2, 4>(p, st);
+    if (p.Cout % 64 == 0 && wgs(2, 2) >= ENOUGH) return launch_fwd<S, OW, 2, 2, (S == 1 ? 8 : 4)>(p, st);
     if (wgs(4, 1) >= ENOUGH) return launch_fwd<S, OW, 4, 1, (S == 1 ? 8 : 4)>(p, st);
-    if (wgs(2, 1) >= ENOUGH) return launch_fwd<S, OW, 2, 1, 4>(p, st);
-    return launch_fwd<S, OW, 1, 1, 4>(p, st);
+    if (wgs(2, 1) >= ENOUGH) return launch_fwd<S, OW, 2, 1, (S == 1 ? 8 : 4)>(p, st);
+    return launch_fwd<S, OW, 1, 1, (S == 1 ? 8 : 4)>(p, st);
 }
 
 }  // namespace
