@@ -180,6 +180,23 @@ int jvae_bn_bwd_b8(const void* dy, const void* x, const float* gamma, const floa
                    const float* save_mean, const float* save_invstd,
                    void* dx, float* dgamma, float* dbeta, int accumulate,
                    int N, int C, long HW, int relu, void* ws, size_t ws_bytes, void* stream);
+/* Deferred form (as jvae_bn_finalize_f32 / *_aff_f32 for fp32): statistics + coef = (2, ceil(C/8)*8) floats (scale, shift;
+ * zero on the padding channels); the consuming bf16 convolution applies them (+ReLU) to its input while staging it. */
+int jvae_bn_finalize_b8(const void* x, const float* gamma, const float* beta,
+                        float* running_mean, float* running_var, long long* num_batches_tracked,
+                        float* save_mean, float* save_invstd, float* coef,
+                        int N, int C, long HW, float momentum, float eps, int training,
+                        const float* ext_stats, int ext_nsplit, const float* ext_pivot,
+                        void* ws, size_t ws_bytes, void* stream);
+int jvae_conv2d_affine_ok_b8(int N, int Cin, int H, int W, int Cout, int KH, int KW, int S, int P, int OP, int transposed);
+int jvae_conv2d_fwd_aff_b8(const void* x, const float* w, const float* bias, void* y, int y_f32, float* stats, int* nsplit,
+                           const float* in_scale, const float* in_shift, int in_relu,
+                           int N, int Cin, int H, int W, int Cout, int KH, int KW, int S, int P, int OP, int transposed,
+                           void* ws, size_t ws_bytes, void* stream);
+int jvae_conv2d_wgrad_aff_b8(const void* x, const void* dy, float* dw, float* dbias, int accumulate,
+                             const float* in_scale, const float* in_shift, int in_relu,
+                             int N, int Cin, int H, int W, int Cout, int KH, int KW, int S, int P, int OP, int transposed,
+                             void* ws, size_t ws_bytes, void* stream);
 int jvae_relu_fwd_b8(const void* x, void* y, long units, void* stream);                /* units of 8 bf16 */
 int jvae_relu_bwd_b8(const void* dy, const void* y, void* dx, long units, void* stream);
 

@@ -340,6 +340,39 @@ int jvae_bn_fwd_b8(const void* x, const float* gamma, const float* beta,
     return 0;
 }
 
+// Statistics + coefficients only (the consuming bf16 convolution normalises its input while staging it, see InAff):
+// coef = (2, C8) floats, C8 = ceil(C/8)*8: scale then shift, zero for the padding channels.
+int jvae_bn_finalize_b8(const void* x, const float* gamma, const float* beta,
+                        float* running_mean, float* running_var, long long* num_batches_tracked,
+                        float* save_mean, float* save_invstd, float* coef,
+                        int N, int C, long HW, float momentum, float eps, int training,
+                        const float* ext_stats, int ext_nsplit, const float* ext_pivot,
+                        void* ws, size_t ws_bytes, void* stream) {
+    if (!x || !coef || N <= 0 || C <= 0 || HW <= 0) return JVAE_EINVAL;
+    if (ws_bytes < jvae_bn_workspace_bytes_b8(C) || !ws) return JVAE_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int CB = (C + 7) / 8;
+    const float* partial = (const float*)ws;
+    int ns = 1;
+    const bool ext = training && ext_stats && ext_nsplit > 0;
+    if (training && (!save_mean || !save_invstd)) return JVAE_EINVAL;
+    if (ext) {
+        partial = ext_stats;
+        ns = ext_nsplit;
+    } else if (training) {
+        ns = pick_split(N, CB, HW);
+        hipLaunchKernelGGL(bn8_stats_kernel, dim3(CB, ns), dim3(256), 0, st, (const bf16x8*)x, (float*)ws, N, C, CB, HW, ns);
+        JVAE_LAUNCH_CHECK();
+    } else if (!running_mean || !running_var) {
+        return JVAE_EINVAL;
+    }
+    hipLaunchKernelGGL(bn8_finalize_kernel, dim3(CB * 8), dim3(64), 0, st, (const bf16x8*)x, partial, gamma, beta,
+                       running_mean, running_var, num_batches_tracked, save_mean, save_invstd, coef, N, C, CB * 8, HW, ns,
+                       momentum, eps, training, ext ? 1 : 0, ext_pivot);
+    JVAE_LAUNCH_CHECK();
+    return 0;
+}
+
 int jvae_bn_bwd_b8(const void* dy, const void* x, const float* gamma, const float* beta,
                    const float* save_mean, const float* save_invstd,
                    void* dx, float* dgamma, float* dbeta, int accumulate,

@@ -57,3 +57,16 @@ __device__ __forceinline__ f32x4 aff4(f32x4 v, float s, float t, int relu) {
     for (int j = 0; j < 4; ++j) { const float x = fmaf(v[j], s, t); v[j] = relu ? fmaxf(x, 0.f) : x; }
     return v;
 }
+
+// the same transform on one B8 unit (8 bf16 channels of a pixel): a = [relu](x*sc[c] + sh[c]), rounded back to bf16
+typedef __bf16 jvae_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int jvae_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ jvae_u32x4 aff8(jvae_u32x4 u, const float* sc8, const float* sh8, int relu) {
+    jvae_bf16x8 v = __builtin_bit_cast(jvae_bf16x8, u);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float x = fmaf((float)v[j], sc8[j], sh8[j]);
+        v[j] = (__bf16)(relu ? fmaxf(x, 0.f) : x);
+    }
+    return __builtin_bit_cast(jvae_u32x4, v);
+}

@@ -133,6 +133,7 @@ struct B8FwdP {
     int N, CBin, H, W, OP, P, CoutReal, CBout;
     float* stats;        // optional (CoutReal, gridDim.x, 2): per-workgroup sum / sum of squares of (out - bias), fp32
     int out_f32;
+    InAff aff;           // deferred BatchNorm(+ReLU) of the input (sc == nullptr: none); CBin*8 coefficients
 };
 
 template <int S, int OW, int MT, int NT>
@@ -154,14 +155,17 @@ struct B8Geom {
     static constexpr int LDS_BYTES = (XS + WS) * 16;
 };
 
-template <int S, int OW, int MT, int NT>
+template <int S, int OW, int MT, int NT, bool AFF>
 __global__ __launch_bounds__(256, 2) void conv5_b8_kernel(B8FwdP p) {
     using G = B8Geom<S, OW, MT, NT>;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     u32x4* Xs = reinterpret_cast<u32x4*>(lds_raw);
     u32x4* Ws = Xs + G::XS;
+    __shared__ float ctab[AFF ? 2 * 256 : 1];                 // (scale, shift) of all input channels (<= 256)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (AFF)
+        for (int i = tid; i < p.CBin * 8; i += 256) { ctab[i] = p.aff.sc[i]; ctab[256 + i] = p.aff.sh[i]; }
     const int half = lane >> 5, l31 = lane & 31;
     constexpr int TILES_PER_IMG = G::OHW >= G::PIX ? G::OHW / G::PIX : 1;
     const int img0 = (G::OHW >= G::PIX) ? (int)(blockIdx.x / TILES_PER_IMG) : (int)blockIdx.x * G::NIMG;
@@ -217,7 +221,7 @@ __global__ __launch_bounds__(256, 2) void conv5_b8_kernel(B8FwdP p) {
             rw[k] = v;
         }
     };
-    auto lstore = [&]() {
+    auto lstore = [&](int kb) {                    // kb: the K step whose data sits in rx
 #pragma unroll
         for (int k = 0; k < XU; ++k) {
             const int u = tid + k * 256;
@@ -226,7 +230,12 @@ __global__ __launch_bounds__(256, 2) void conv5_b8_kernel(B8FwdP p) {
                 int t = u / G::WIN;
                 const int lr = t % G::ROWS; t /= G::ROWS;
                 const int h = t % 2, im = t / 2;
-                Xs[(im * 2 + h) * G::CH + lr * G::WP + 4 + x] = rx[k];
+                u32x4 v = rx[k];
+                if (AFF) {                         // deferred BatchNorm(+ReLU) of the input; padding cells stay zero
+                    const int ir = in_row0 + lr, n = img0 + im, cb = kb * 2 + h;
+                    if (ir >= 0 && ir < p.H && n < p.N && cb < p.CBin) v = aff8(v, &ctab[cb * 8], &ctab[256 + cb * 8], p.aff.relu);
+                }
+                Xs[(im * 2 + h) * G::CH + lr * G::WP + 4 + x] = v;
             }
         }
 #pragma unroll
@@ -239,7 +248,7 @@ __global__ __launch_bounds__(256, 2) void conv5_b8_kernel(B8FwdP p) {
     gload(0);
     for (int kb = 0; kb < KB; ++kb) {
         __syncthreads();
-        lstore();
+        lstore(kb);
         __syncthreads();
         if (kb + 1 < KB) gload(kb + 1);
         // one-deep software pipeline: the fragments of tap t+1 are read from LDS before the MFMAs of tap t are issued
@@ -339,11 +348,14 @@ thread_local int g_b8_splits = 0;
 template <int S, int OW, int MT, int NT>
 int launch_b8(const B8FwdP& p, hipStream_t st) {
     using G = B8Geom<S, OW, MT, NT>;
-    static_assert(G::LDS_BYTES <= 80 * 1024, "two workgroups per CU must fit the 160 KB LDS");
+    static_assert(G::LDS_BYTES + 2048 <= 80 * 1024, "two workgroups per CU must fit the 160 KB LDS");
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_b8_kernel<S, OW, MT, NT>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_b8_kernel<S, OW, MT, NT, false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_b8_kernel<S, OW, MT, NT, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
@@ -351,7 +363,12 @@ int launch_b8(const B8FwdP& p, hipStream_t st) {
     dim3 grid((unsigned)((pixels + G::PIX - 1) / G::PIX), (unsigned)(p.OP / G::WCOLS));
     if (G::OHW < G::PIX) grid.x = (unsigned)((p.N + G::NIMG - 1) / G::NIMG);
     g_b8_splits = (int)grid.x;
-    hipLaunchKernelGGL((conv5_b8_kernel<S, OW, MT, NT>), grid, dim3(256), G::LDS_BYTES, st, p);
+    if (p.aff.sc) {
+        if (p.CBin * 8 > 256) return JVAE_ENOTSUP;
+        hipLaunchKernelGGL((conv5_b8_kernel<S, OW, MT, NT, true>), grid, dim3(256), G::LDS_BYTES, st, p);
+    } else {
+        hipLaunchKernelGGL((conv5_b8_kernel<S, OW, MT, NT, false>), grid, dim3(256), G::LDS_BYTES, st, p);
+    }
     JVAE_LAUNCH_CHECK();
     return 0;
 }
@@ -420,11 +437,11 @@ int jvae_conv5_b8_wpack(const float* w, void* wp, int C, int O, int swap, int fl
 // in: B8 (N, ceil(Cin/8), H, W); out: B8 (N, ceil(Cout/8), OW, OW) or fp32 NCHW (out_f32).  ws: packed weights.
 int jvae_conv5_b8_fwd(const void* in, const float* w, int swap, int flip, const float* bias, void* out, int out_f32,
                       int N, int Cin, int H, int W, int Cout, int OW, int S, int P, void* ws, hipStream_t st,
-                      float* stats, int* nsplit) {
+                      float* stats, int* nsplit, const InAff* aff) {
     int rc = jvae_conv5_b8_wpack(w, ws, Cin, Cout, swap, flip, st);
     if (rc) return rc;
     B8FwdP p{(const u32x4*)in, (const u32x4*)ws, bias, out, N, (Cin + 7) / 8, H, W, (Cout + 31) / 32 * 32, P,
-             Cout, (Cout + 7) / 8, stats, out_f32};
+             Cout, (Cout + 7) / 8, stats, out_f32, aff ? *aff : InAff{nullptr, nullptr, 0}};
     struct Fin { int* n; ~Fin() { if (n) *n = g_b8_splits; } } fin{nsplit};
     if (S == 1) {
         switch (OW) {

@@ -140,6 +140,43 @@ int jvae_conv2d_fwd_b8(const void* x, const float* w, const float* bias, void* y
     return JVAE_ENOTSUP;
 }
 
+// ---- deferred BatchNorm(+ReLU) on the B8 layer input: in_scale / in_shift hold ceil(Cin/8)*8 floats (jvae_bn_finalize_b8)
+int jvae_conv2d_affine_ok_b8(int N, int Cin, int H, int W, int Cout, int KH, int KW, int S, int P, int OP, int transposed) {
+    ConvGeom g; int oh, ow;
+    if (!make_geom(N, Cin, H, W, Cout, KH, KW, S, P, OP, transposed, &g, &oh, &ow)) return 0;
+    if ((Cin + 7) / 8 * 8 > 256) return 0;
+    const int m = native_mask(g, transposed);
+    return (m & DIR_FWD) && (m & DIR_WGRAD) ? 1 : 0;
+}
+
+int jvae_conv2d_fwd_aff_b8(const void* x, const float* w, const float* bias, void* y, int y_f32, float* stats, int* nsplit,
+                           const float* in_scale, const float* in_shift, int in_relu,
+                           int N, int Cin, int H, int W, int Cout, int KH, int KW, int S, int P, int OP, int transposed,
+                           void* ws, size_t ws_bytes, void* stream) {
+    ConvGeom g; int oh, ow;
+    if (nsplit) *nsplit = 0;
+    if (!x || !w || !y || !in_scale || !in_shift) return JVAE_EINVAL;
+    if (stats && !nsplit) return JVAE_EINVAL;
+    if (!make_geom(N, Cin, H, W, Cout, KH, KW, S, P, OP, transposed, &g, &oh, &ow)) return JVAE_EINVAL;
+    if (N == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const InAff aff{in_scale, in_shift, in_relu};
+    if (!transposed) {
+        if (!fold_fwd_fast(g)) return JVAE_ENOTSUP;
+        if (ws_bytes < jvae_conv5_b8_pack_bytes(g.Cb, g.Cs) || !ws) return JVAE_EWORKSPACE;
+        return jvae_conv5_b8_fwd(x, w, 0, 0, bias, y, y_f32, g.N, g.Cb, g.Hb, g.Wb, g.Cs, g.Ws, g.S, g.P, ws, st, stats, nsplit, &aff);
+    }
+    if (fold_bwd_fast_s1(g)) {
+        if (ws_bytes < jvae_conv5_b8_pack_bytes(g.Cs, g.Cb) || !ws) return JVAE_EWORKSPACE;
+        return jvae_conv5_b8_fwd(x, w, 1, 1, bias, y, y_f32, g.N, g.Cs, g.Hs, g.Ws, g.Cb, g.Wb, 1, 4 - g.P, ws, st, stats, nsplit, &aff);
+    }
+    if (fold_bwd_fast_s2(g) && !y_f32) {
+        if (ws_bytes < jvae_conv5_b8_pack_bytes(g.Cs, g.Cb) || !ws) return JVAE_EWORKSPACE;
+        return jvae_convt2_b8(x, w, bias, y, g.N, g.Cs, g.Ws, g.Cb, ws, st, stats, nsplit, &aff);
+    }
+    return JVAE_ENOTSUP;
+}
+
 // dy: B8 -> dx: B8
 int jvae_conv2d_dgrad_b8(const void* dy, const float* w, void* dx,
                          int N, int Cin, int H, int W, int Cout, int KH, int KW, int S, int P, int OP, int transposed,
@@ -164,7 +201,7 @@ int jvae_conv2d_dgrad_b8(const void* dy, const float* w, void* dx,
 }
 
 // x, dy: B8 (layer input / gradient of the layer output); dw fp32 in the layer's own layout; dbias may be NULL
-int jvae_conv2d_wgrad_b8(const void* x, const void* dy, float* dw, float* dbias, int accumulate,
+static int wgrad_b8_impl(const void* x, const void* dy, float* dw, float* dbias, int accumulate, const InAff* aff,
                          int N, int Cin, int H, int W, int Cout, int KH, int KW, int S, int P, int OP, int transposed,
                          void* ws, size_t ws_bytes, void* stream) {
     ConvGeom g; int oh, ow;
@@ -181,14 +218,33 @@ int jvae_conv2d_wgrad_b8(const void* x, const void* dy, float* dw, float* dbias,
     if (N == 0) return 0;
     const void* big = transposed ? dy : x;
     const void* small = transposed ? x : dy;
+    const InAff* aff_big = transposed ? nullptr : aff;       // the deferred BatchNorm belongs to the layer input x
+    const InAff* aff_small = transposed ? aff : nullptr;
     int rc;
     if (wgrad_swap(g))
-        rc = jvae_conv5_wgrad_b8(big, small, dw, 1, 1, g.N, g.Cb, g.Wb, g.Cs, 1, 4 - g.P, (float*)ws, st);
+        rc = jvae_conv5_wgrad_b8(big, small, dw, 1, 1, g.N, g.Cb, g.Wb, g.Cs, 1, 4 - g.P, (float*)ws, st, aff_big, aff_small);
     else
-        rc = jvae_conv5_wgrad_b8(small, big, dw, 1, 0, g.N, g.Cs, g.Ws, g.Cb, g.S, g.P, (float*)ws, st);
+        rc = jvae_conv5_wgrad_b8(small, big, dw, 1, 0, g.N, g.Cs, g.Ws, g.Cb, g.S, g.P, (float*)ws, st, aff_small, aff_big);
     if (rc) return rc;
     if (dbias) rc = jvae_b8_channel_sum(dy, dbias, N, Cout, (long)oh * ow, 1, (float*)((char*)ws + wgrad_ws_bytes(g)), st);
     return rc;
+}
+
+int jvae_conv2d_wgrad_b8(const void* x, const void* dy, float* dw, float* dbias, int accumulate,
+                         int N, int Cin, int H, int W, int Cout, int KH, int KW, int S, int P, int OP, int transposed,
+                         void* ws, size_t ws_bytes, void* stream) {
+    return wgrad_b8_impl(x, dy, dw, dbias, accumulate, nullptr, N, Cin, H, W, Cout, KH, KW, S, P, OP, transposed, ws, ws_bytes,
+                         stream);
+}
+
+int jvae_conv2d_wgrad_aff_b8(const void* x, const void* dy, float* dw, float* dbias, int accumulate,
+                             const float* in_scale, const float* in_shift, int in_relu,
+                             int N, int Cin, int H, int W, int Cout, int KH, int KW, int S, int P, int OP, int transposed,
+                             void* ws, size_t ws_bytes, void* stream) {
+    if (!in_scale || !in_shift) return JVAE_EINVAL;
+    const InAff aff{in_scale, in_shift, in_relu};
+    return wgrad_b8_impl(x, dy, dw, dbias, accumulate, &aff, N, Cin, H, W, Cout, KH, KW, S, P, OP, transposed, ws, ws_bytes,
+                         stream);
 }
 
 }  // extern "C"

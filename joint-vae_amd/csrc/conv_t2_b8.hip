@@ -28,6 +28,7 @@ struct T2B8P {
     u32x2* out;          // big, B8 half units (N, CBout, 2HS, 2WS, 2)
     int N, CBin, OP, O, CBout;
     float* stats;        // optional (O, gridDim.x, 2)
+    InAff aff;           // deferred BatchNorm(+ReLU) of the input
 };
 
 template <int WS, int NW>
@@ -45,14 +46,17 @@ struct T2B8Geom {
     static constexpr int LDS_BYTES = (XS + WSZ) * 16;
 };
 
-template <int WS, int NW>
+template <int WS, int NW, bool AFF>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void convt2_b8_kernel(T2B8P p) {
     using G = T2B8Geom<WS, NW>;
     constexpr int NT_ = NW * 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     u32x4* Xs = reinterpret_cast<u32x4*>(lds_raw);
     u32x4* Ws = Xs + G::XS;
+    __shared__ float ctab[AFF ? 2 * 256 : 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (AFF)
+        for (int i = tid; i < p.CBin * 8; i += NW * 64) { ctab[i] = p.aff.sc[i]; ctab[256 + i] = p.aff.sh[i]; }
     const int half = lane >> 5, l31 = lane & 31;
     constexpr int TILES_PER_IMG = G::HSWS >= G::PIX ? G::HSWS / G::PIX : 1;
     const int img0 = (G::HSWS >= G::PIX) ? (int)(blockIdx.x / TILES_PER_IMG) : (int)blockIdx.x * G::NIMG;
@@ -112,7 +116,12 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void convt2_b8_kernel(T2B
                 int t = u / WS;
                 const int lr = t % G::ROWS; t /= G::ROWS;
                 const int h = t % 2, i2 = t / 2;
-                Xs[(i2 * 2 + h) * G::CH + lr * G::WP + 1 + x] = rx[k];
+                u32x4 v = rx[k];
+                if (AFF) {
+                    const int ir = row0 - 1 + lr, n = img0 + i2, cb = kb * 2 + h;
+                    if (ir >= 0 && ir < G::HS && n < p.N && cb < p.CBin) v = aff8(v, &ctab[cb * 8], &ctab[256 + cb * 8], p.aff.relu);
+                }
+                Xs[(i2 * 2 + h) * G::CH + lr * G::WP + 1 + x] = v;
             }
         }
 #pragma unroll
@@ -205,7 +214,12 @@ int launch_t2b8(const T2B8P& p, hipStream_t st) {
     dim3 grid(G::HSWS >= G::PIX ? (unsigned)((long)p.N * G::HSWS / G::PIX) : (unsigned)((p.N + G::NIMG - 1) / G::NIMG),
               (unsigned)(p.OP / 32));
     g_t2b8_splits = (int)grid.x;
-    hipLaunchKernelGGL((convt2_b8_kernel<WS, NW>), grid, dim3(NW * 64), G::LDS_BYTES, st, p);
+    if (p.aff.sc) {
+        if (p.CBin * 8 > 256) return JVAE_ENOTSUP;
+        hipLaunchKernelGGL((convt2_b8_kernel<WS, NW, true>), grid, dim3(NW * 64), G::LDS_BYTES, st, p);
+    } else {
+        hipLaunchKernelGGL((convt2_b8_kernel<WS, NW, false>), grid, dim3(NW * 64), G::LDS_BYTES, st, p);
+    }
     JVAE_LAUNCH_CHECK();
     return 0;
 }
@@ -221,10 +235,11 @@ bool jvae_convt2_b8_ok(int C, int HS, int WS, int O, int HB, int WB, int KH, int
 
 // small (N, ceil(C/8), WS, WS, 8) --ConvT 5x5 s2 p2 op1--> big (N, ceil(O/8), 2WS, 2WS, 8); ws: packed weights
 int jvae_convt2_b8(const void* in, const float* w, const float* bias, void* out, int N, int C, int WS, int O,
-                   void* ws, hipStream_t st, float* stats, int* nsplit) {
+                   void* ws, hipStream_t st, float* stats, int* nsplit, const InAff* aff) {
     int rc = jvae_conv5_b8_wpack(w, ws, C, O, 1, 0, st);
     if (rc) return rc;
-    T2B8P p{(const u32x4*)in, (const u32x4*)ws, bias, (u32x2*)out, N, (C + 7) / 8, (O + 31) / 32 * 32, O, (O + 7) / 8, stats};
+    T2B8P p{(const u32x4*)in, (const u32x4*)ws, bias, (u32x2*)out, N, (C + 7) / 8, (O + 31) / 32 * 32, O, (O + 7) / 8, stats,
+            aff ? *aff : InAff{nullptr, nullptr, 0}};
     struct Fin { int* n; ~Fin() { if (n) *n = g_t2b8_splits; } } fin{nsplit};
     switch (WS) {
         case 8: return launch_t2b8<8, 4>(p, st);

@@ -33,6 +33,7 @@ struct WgB8P {
     const u32x4* q;      // B8 units (N, CBb, HB, WB)
     float* slab;         // (G, Ca, Cb*25)
     int N, Ca, Cb, CBa, CBb, P, G;
+    InAff aff_p, aff_q;  // deferred BatchNorm(+ReLU) of ps / q (whichever is the layer input); CBa*8 / CBb*8 coefficients
 };
 
 template <int S, int WS, int MODE>
@@ -62,7 +63,7 @@ __device__ __forceinline__ bf16x8 tr_pair(const unsigned char* base, int off) {
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-template <int S, int WS, int MODE>
+template <int S, int WS, int MODE, bool AFF>
 __global__ __launch_bounds__(256, 2) void conv5_wgrad_b8_kernel(WgB8P p) {
     using G = WgB8Geom<S, WS, MODE>;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -77,6 +78,16 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_b8_kernel(WgB8P p) {
     const int cbq0 = blockIdx.z * 4;                           // first channel block of Q (MODE 0)
 
     for (int i = tid; i < G::QS; i += 256) Qs[i] = u32x4{0u, 0u, 0u, 0u};
+    __shared__ float ctab[AFF ? 2 * 8 * (G::NCBQ + 4) : 1];     // (scale, shift) of this workgroup's q / ps channel blocks
+    if (AFF && tid < 8 * (G::NCBQ + 4)) {
+        constexpr int NQ = 8 * G::NCBQ;
+        const bool isq = tid < NQ;
+        const InAff& a = isq ? p.aff_q : p.aff_p;
+        const int ch = isq ? cbq0 * 8 + tid : a0 + (tid - NQ);
+        const bool ok = a.sc && ch < (isq ? p.CBb : p.CBa) * 8;
+        ctab[tid] = ok ? a.sc[ch] : 0.f;
+        ctab[8 * (G::NCBQ + 4) + tid] = ok ? a.sh[ch] : 0.f;
+    }
 
     // transposed-read roles of this lane: row (pixel) q of the 4x16 block, channel quad pp; cg = 16-column group
     const int cg = (lane >> 4) & 1, q4 = (lane & 15) >> 2, pp = lane & 3;
@@ -136,7 +147,9 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_b8_kernel(WgB8P p) {
             rp[k] = v;
         }
     };
-    auto lstore = [&]() {
+    auto lstore = [&](int item) {                  // item: the work item whose data sits in rq / rp
+        constexpr int NT8 = 8 * (G::NCBQ + 4);
+        const int in_row0 = (item % G::TILES) * G::TH * S - p.P;
 #pragma unroll
         for (int k = 0; k < QU; ++k) {
             const int u = tid + k * 256;
@@ -144,13 +157,25 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_b8_kernel(WgB8P p) {
                 const int x = u % G::WB;
                 const int t = u / G::WB;
                 const int lr = t % G::ROWS, c = t / G::ROWS;
-                Qs[c * G::CH + lr * G::WP + 4 + x] = rq[k];
+                u32x4 v = rq[k];
+                if (AFF && p.aff_q.sc) {           // padding rows / missing channel blocks stay exact zeros
+                    const int ir = in_row0 + lr;
+                    if (ir >= 0 && ir < HB && cbq0 + c < p.CBb) v = aff8(v, &ctab[c * 8], &ctab[NT8 + c * 8], p.aff_q.relu);
+                }
+                Qs[c * G::CH + lr * G::WP + 4 + x] = v;
             }
         }
 #pragma unroll
         for (int k = 0; k < PU; ++k) {
             const int u = tid + k * 256;
-            if (u < PUNITS) Pt[u] = rp[k];
+            if (u < PUNITS) {
+                u32x4 v = rp[k];
+                if (AFF && p.aff_p.sc) {
+                    const int c = u / G::TPIX;
+                    if ((a0 >> 3) + c < p.CBa) v = aff8(v, &ctab[(G::NCBQ + c) * 8], &ctab[NT8 + (G::NCBQ + c) * 8], p.aff_p.relu);
+                }
+                Pt[u] = v;
+            }
         }
     };
 
@@ -158,7 +183,7 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_b8_kernel(WgB8P p) {
     if (item_beg < item_end) gload(item_beg);
     for (int item = item_beg; item < item_end; ++item) {
         __syncthreads();
-        lstore();
+        lstore(item);
         __syncthreads();
         if (item + 1 < item_end) gload(item + 1);
 #pragma unroll
@@ -199,7 +224,8 @@ int launch_wgb8(const WgB8P& p, hipStream_t st) {
     using G = WgB8Geom<S, WS, MODE>;
     static_assert(G::LDS_BYTES <= 64 * 1024, "LDS budget");
     dim3 grid(p.G, (p.Ca + 31) / 32, MODE == 0 ? (p.Cb + 31) / 32 : 1);
-    hipLaunchKernelGGL((conv5_wgrad_b8_kernel<S, WS, MODE>), grid, dim3(256), G::LDS_BYTES, st, p);
+    if (p.aff_p.sc || p.aff_q.sc) hipLaunchKernelGGL((conv5_wgrad_b8_kernel<S, WS, MODE, true>), grid, dim3(256), G::LDS_BYTES, st, p);
+    else hipLaunchKernelGGL((conv5_wgrad_b8_kernel<S, WS, MODE, false>), grid, dim3(256), G::LDS_BYTES, st, p);
     JVAE_LAUNCH_CHECK();
     return 0;
 }
@@ -228,8 +254,11 @@ size_t jvae_conv5_wgrad_b8_ws_floats(int N, int Ca, int Cb) { return (size_t)sla
 
 // dW (+)= ...; ps / q: B8 tensors; swapflip: the caller passed the role-swapped problem (dst = (b*Ca + a)*25 + 24 - tap)
 int jvae_conv5_wgrad_b8(const void* ps, const void* q, float* dw, int accumulate, int swapflip,
-                        int N, int Ca, int WS, int Cb, int S, int P, float* ws, hipStream_t st) {
-    WgB8P p{(const u32x4*)ps, (const u32x4*)q, ws, N, Ca, Cb, (Ca + 7) / 8, (Cb + 7) / 8, P, slab_count(N, Ca, Cb)};
+                        int N, int Ca, int WS, int Cb, int S, int P, float* ws, hipStream_t st,
+                        const InAff* aff_p, const InAff* aff_q) {
+    const InAff none{nullptr, nullptr, 0};
+    WgB8P p{(const u32x4*)ps, (const u32x4*)q, ws, N, Ca, Cb, (Ca + 7) / 8, (Cb + 7) / 8, P, slab_count(N, Ca, Cb),
+            aff_p ? *aff_p : none, aff_q ? *aff_q : none};
     int rc = JVAE_ENOTSUP;
 #define WG_CASE(S_, WS_)                                                              \
     case WS_: rc = Cb <= 8 ? launch_wgb8<S_, WS_, 1>(p, st) : launch_wgb8<S_, WS_, 0>(p, st); break;

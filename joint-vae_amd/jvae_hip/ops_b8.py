@@ -49,7 +49,12 @@ def _ws(geom, device):
     return ws, ws.numel()
 
 
-def conv_fwd_raw(x, w, b, spec, out_f32=False, want_stats=False):
+def conv_affine_ok(spec, N, H, W):
+    """Forward and weight gradient of this layer run on bf16 kernels that can apply a deferred BatchNorm to the input."""
+    return bool(O._geom_query('jvae_conv2d_affine_ok_b8', spec.geom(N, H, W)))
+
+
+def conv_fwd_raw(x, w, b, spec, out_f32=False, want_stats=False, aff=None):
     """x: B8.  -> (y, stats, nsplit); y is B8, or fp32 NCHW with out_f32.  Raises JvaeHipError(ENOTSUP) when the geometry
     has no native bf16 kernel (ask native_mask first)."""
     lib = L.load()
@@ -66,8 +71,12 @@ def conv_fwd_raw(x, w, b, spec, out_f32=False, want_stats=False):
         if cap > 0:
             stats = torch.empty((spec.cout * cap * 2,), device=x.device, dtype=torch.float32)
     ws, nb = _ws(geom, x.device)
-    rc = lib.jvae_conv2d_fwd_b8(L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(y), int(out_f32), L.ptr(stats), byref(ns), *geom,
-                                L.ptr(ws), nb, L.stream_ptr())
+    if aff is not None:
+        rc = lib.jvae_conv2d_fwd_aff_b8(L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(y), int(out_f32), L.ptr(stats), byref(ns),
+                                        L.ptr(aff[0]), L.ptr(aff[1]), int(aff[2]), *geom, L.ptr(ws), nb, L.stream_ptr())
+    else:
+        rc = lib.jvae_conv2d_fwd_b8(L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(y), int(out_f32), L.ptr(stats), byref(ns), *geom,
+                                    L.ptr(ws), nb, L.stream_ptr())
     L.check(rc, 'jvae_conv2d_fwd_b8')
     return y, (stats if ns.value > 0 else None), ns.value
 
@@ -82,8 +91,9 @@ def conv_dgrad_raw(gy, w, spec, N, H, W):
     return gx
 
 
-def conv_wgrad_raw(x, gy, spec, wshape, want_bias, w_slot=None, b_slot=None):
-    """x, gy: B8.  -> (gw, gb) fp32; with slots the result is ADDED into them (see ops.conv_wgrad_raw)."""
+def conv_wgrad_raw(x, gy, spec, wshape, want_bias, w_slot=None, b_slot=None, aff=None):
+    """x, gy: B8.  -> (gw, gb) fp32; with slots the result is ADDED into them (see ops.conv_wgrad_raw).
+    aff = (scale, shift, relu): x is a pre-BatchNorm tensor normalised while it is staged."""
     N, _, H, W, _ = x.shape
     inplace = w_slot is not None and (b_slot is not None or not want_bias)
     gw = w_slot if inplace else torch.empty(wshape, device=x.device, dtype=torch.float32)
@@ -92,8 +102,13 @@ def conv_wgrad_raw(x, gy, spec, wshape, want_bias, w_slot=None, b_slot=None):
         gb = b_slot if inplace else torch.empty(spec.cout, device=x.device, dtype=torch.float32)
     geom = spec.geom(N, H, W)
     ws, nb = _ws(geom, x.device)
-    rc = L.load().jvae_conv2d_wgrad_b8(L.ptr(x), L.ptr(gy), L.ptr(gw), L.ptr(gb), int(inplace), *geom, L.ptr(ws), nb,
-                                       L.stream_ptr())
+    if aff is not None:
+        rc = L.load().jvae_conv2d_wgrad_aff_b8(L.ptr(x), L.ptr(gy), L.ptr(gw), L.ptr(gb), int(inplace),
+                                               L.ptr(aff[0]), L.ptr(aff[1]), int(aff[2]), *geom, L.ptr(ws), nb,
+                                               L.stream_ptr())
+    else:
+        rc = L.load().jvae_conv2d_wgrad_b8(L.ptr(x), L.ptr(gy), L.ptr(gw), L.ptr(gb), int(inplace), *geom, L.ptr(ws), nb,
+                                           L.stream_ptr())
     L.check(rc, 'jvae_conv2d_wgrad_b8')
     return (None, None) if inplace else (gw, gb)
 
@@ -137,14 +152,15 @@ class _ConvB8(torch.autograd.Function):
     Directions without a native bf16 kernel take the fp32 kernels between two layout conversions."""
 
     @staticmethod
-    def forward(ctx, x, w, b, spec, dead_bias, stats_out, out_f32):
+    def forward(ctx, x, w, b, spec, dead_bias, stats_out, out_f32, aff=None):
         N, _, H, W, _ = x.shape
         mask = native_mask(spec, N, H, W)
         ctx.w_ref, ctx.b_ref = w, b
         w = O._c(w)
         want_stats = stats_out is not None
+        ctx.aff = aff                       # only given where conv_affine_ok(): forward and wgrad are native
         if mask & FWD and not (out_f32 and spec.transposed and spec.s == 2):
-            y, st, ns = conv_fwd_raw(x, w, b, spec, out_f32=out_f32, want_stats=want_stats)
+            y, st, ns = conv_fwd_raw(x, w, b, spec, out_f32=out_f32, want_stats=want_stats, aff=aff)
         else:
             x32 = unpack(x, spec.cin)
             if want_stats:
@@ -191,7 +207,7 @@ class _ConvB8(torch.autograd.Function):
             native = bool(mask & WGRAD)
             if native:
                 gyw = g_b8()
-                run = lambda ws_, bs_: conv_wgrad_raw(x, gyw, spec, w.shape, want_b, ws_, bs_)
+                run = lambda ws_, bs_: conv_wgrad_raw(x, gyw, spec, w.shape, want_b, ws_, bs_, ctx.aff)
             else:
                 gyw = g_f32()
                 x32 = unpack(x, spec.cin)
@@ -204,6 +220,8 @@ class _ConvB8(torch.autograd.Function):
                     run(w_slot, b_slot)
                 x.record_stream(side)
                 gyw.record_stream(side)
+                if ctx.aff is not None:
+                    ctx.aff[0].record_stream(side)
                 if not native:
                     x32.record_stream(side)
                 O._join_after_backward()
@@ -211,11 +229,11 @@ class _ConvB8(torch.autograd.Function):
                 gw, gb = run(w_slot, b_slot)
         if ctx.dead_bias and ctx.has_bias and ctx.needs_input_grad[2] and O._grad_slot(ctx.b_ref) is None:
             gb = torch.zeros_like(ctx.b_ref)
-        return gx, gw, gb, None, None, None, None
+        return gx, gw, gb, None, None, None, None, None
 
 
-def conv2d(x, w, b, spec, dead_bias=False, stats_out=None, out_f32=False):
-    return _ConvB8.apply(x, w, b, spec, dead_bias, stats_out, out_f32)
+def conv2d(x, w, b, spec, dead_bias=False, stats_out=None, out_f32=False, aff=None):
+    return _ConvB8.apply(x, w, b, spec, dead_bias, stats_out, out_f32, aff)
 
 
 class _BatchNormActB8(torch.autograd.Function):
@@ -267,6 +285,49 @@ class _BatchNormActB8(torch.autograd.Function):
         if inplace:
             gg = gb = None
         return gx, gg, gb, None, None, None, None, None, None, None, None, None
+
+
+class _BatchNormDeferB8(torch.autograd.Function):
+    """BatchNorm(+ReLU) on a B8 tensor deferred into the next bf16 convolution (see ops._BatchNormDefer): forward produces
+    the statistics and the (scale, shift) rows only and returns the input itself; backward is the ordinary one."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, rm, rv, nbt, training, relu, momentum, eps, ext, C):
+        x = O._c(x)
+        N, CB, H, W, _ = x.shape
+        HW = H * W
+        lib = L.load()
+        mean = torch.empty(C, device=x.device, dtype=torch.float32)
+        invstd = torch.empty(C, device=x.device, dtype=torch.float32)
+        coef = torch.empty((2, CB * 8), device=x.device, dtype=torch.float32)
+        ws = L.workspace(lib.jvae_bn_workspace_bytes_b8(C), x.device)
+        use_ext = ext is not None and ext.get('stats') is not None and training
+        rc = lib.jvae_bn_finalize_b8(L.ptr(x), L.ptr(gamma), L.ptr(beta), L.ptr(rm), L.ptr(rv), L.ptr(nbt),
+                                     L.ptr(mean), L.ptr(invstd), L.ptr(coef), N, C, HW, momentum, eps, int(training),
+                                     L.ptr(ext['stats']) if use_ext else None, int(ext['nsplit']) if use_ext else 0,
+                                     L.ptr(ext.get('pivot')) if use_ext else None, L.ptr(ws), ws.numel(), L.stream_ptr())
+        L.check(rc, 'jvae_bn_finalize_b8')
+        if training:
+            ctx.save_for_backward(x, gamma, beta, mean, invstd)
+            ctx.relu = relu
+            ctx.dims = (N, C, HW)
+            ctx.g_ref, ctx.b_ref = gamma, beta
+        else:
+            ctx.dims = None
+        ctx.mark_non_differentiable(coef)
+        return x.view_as(x), coef
+
+    @staticmethod
+    def backward(ctx, gy, _gcoef):
+        return _BatchNormActB8.backward(ctx, gy)
+
+
+def batchnorm_defer(x, C, gamma, beta, running_mean, running_var, num_batches_tracked, training, relu,
+                    momentum=0.1, eps=1e-5, ext=None):
+    """-> (x_alias, (scale, shift, relu)) for conv2d(..., aff=...) of a layer with conv_affine_ok()."""
+    xa, coef = _BatchNormDeferB8.apply(x, gamma, beta, running_mean, running_var, num_batches_tracked, training, relu,
+                                       momentum, eps, ext, C)
+    return xa, (coef[0], coef[1], relu)
 
 
 def batchnorm_act(x, C, gamma, beta, running_mean, running_var, num_batches_tracked, training, relu,

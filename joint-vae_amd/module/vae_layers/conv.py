@@ -191,6 +191,7 @@ class HipConvStack(nn.Sequential):
         convs = [k for k, m in enumerate(mods) if isinstance(m, (HipConv2d, HipConvTranspose2d))]
         i = 0
         ext = None
+        aff = None           # (scale, shift, relu) of a BatchNorm deferred into the next bf16 convolution
         channels = x.shape[1]
         while i < len(mods):
             m = mods[i]
@@ -209,11 +210,12 @@ class HipConvStack(nn.Sequential):
                         x = ops_b8.to_b8(x)
                     # the last convolution of the stack writes fp32 NCHW directly (it feeds the loss / the dense heads)
                     last = i == convs[-1] and not bn_next and not (spec.transposed and spec.s == 2)
-                    x = ops_b8.conv2d(x, m.weight, m.bias, spec, dead, ext, out_f32=last)
+                    x = ops_b8.conv2d(x, m.weight, m.bias, spec, dead, ext, out_f32=last, aff=aff)
                 else:
                     if b8:
                         x = ops_b8.from_b8(x, channels)
                     x = ops.conv2d(x, m.weight, m.bias, spec, dead, ext)
+                aff = None
                 channels = spec.cout
                 i += 1
                 continue
@@ -224,7 +226,14 @@ class HipConvStack(nn.Sequential):
                         and ACT_OF_MODULE[type(mods[i + 1])] in (ops.RELU, ops.IDENT):
                     relu = ACT_OF_MODULE[type(mods[i + 1])] == ops.RELU
                     step = 2
-                if b8 and not (m.training and m.sync_world > 1):
+                nxt = mods[i + step] if i + step < len(mods) else None
+                if b8 and not (m.training and m.sync_world > 1) and self.defer_batchnorm \
+                        and isinstance(nxt, (HipConv2d, HipConvTranspose2d)) \
+                        and ops_b8.conv_affine_ok(nxt._spec(), x.shape[0], x.shape[2], x.shape[3]):
+                    # normalisation + ReLU applied by the next bf16 convolution while it stages this tensor
+                    x, aff = ops_b8.batchnorm_defer(x, channels, m.weight, m.bias, m.running_mean, m.running_var,
+                                                    m.num_batches_tracked, m.training, relu, m.momentum, m.eps, ext)
+                elif b8 and not (m.training and m.sync_world > 1):
                     x = ops_b8.batchnorm_act(x, channels, m.weight, m.bias, m.running_mean, m.running_var,
                                              m.num_batches_tracked, m.training, relu, m.momentum, m.eps, ext)
                 else:

@@ -203,3 +203,36 @@ def test_b8_model_config5_against_fp32_oracle():
             num += float((got[n] * gr).sum()); den_a += float((got[n] ** 2).sum()); den_b += float((gr ** 2).sum())
     assert num / (den_a * den_b) ** 0.5 > 0.99
     assert abs(den_a ** 0.5 / den_b ** 0.5 - 1) < 2e-2
+
+
+@pytest.mark.parametrize('cin,cout,k,s,p,op,tr,H', [(32, 64, 5, 1, 2, 0, False, 16), (32, 32, 5, 2, 2, 0, False, 32),
+                                                    (64, 64, 5, 1, 2, 0, True, 8), (64, 64, 5, 2, 2, 1, True, 8),
+                                                    (32, 3, 5, 1, 2, 0, False, 32), (24, 40, 5, 1, 2, 0, False, 16)])
+def test_b8_conv_with_deferred_batchnorm_input(cin, cout, k, s, p, op, tr, H):
+    """bf16 conv(relu(x*scale + shift)) with the per-channel transform applied inside the kernels (forward and weight
+    gradient).  Reference: PyTorch on the transformed input ROUNDED to bf16 (what the kernel feeds the matrix cores)."""
+    from jvae_hip import ops, ops_b8
+    N = 5
+    g = torch.Generator().manual_seed(cin * 11 + cout + H)
+    x = rbf(torch.randn(N, cin, H, H, generator=g))
+    sc = torch.rand(cin, generator=g) + 0.5
+    sh = torch.randn(cin, generator=g) * 0.5
+    wshape = (cin, cout, k, k) if tr else (cout, cin, k, k)
+    w = torch.randn(wshape, generator=g) / math.sqrt(cin * k * k)
+    wr = rbf(w).requires_grad_(True)
+    a = rbf(torch.relu(torch.addcmul(sh.view(1, -1, 1, 1), x, sc.view(1, -1, 1, 1))))     # fmaf then bf16 rounding
+    yr = F.conv_transpose2d(a, wr, None, stride=s, padding=p, output_padding=op) if tr else F.conv2d(a, wr, None, stride=s, padding=p)
+    gy = rbf(torch.randn(yr.shape, generator=g))
+    yr.backward(gy)
+    spec = ops.ConvSpec(cin, cout, k, s, p, op, tr)
+    assert ops_b8.conv_affine_ok(spec, N, H, H)
+    C8 = (cin + 7) // 8 * 8
+    coef = torch.zeros(2, C8)
+    coef[0, :cin], coef[1, :cin] = sc, sh
+    coef = coef.to(DEV)
+    aff = (coef[0], coef[1], True)
+    xb = ops_b8.pack(x.to(DEV))
+    yb, _, _ = ops_b8.conv_fwd_raw(xb, w.to(DEV), None, spec, aff=aff)
+    assert rel(ops_b8.unpack(yb, cout), yr) < 2 * BF_TOL          # an input within rounding of a bf16 tie may round the other way
+    gw, _ = ops_b8.conv_wgrad_raw(xb, ops_b8.pack(gy.to(DEV)), spec, wshape, False, aff=aff)
+    assert rel(gw, wr.grad) < 2e-3
