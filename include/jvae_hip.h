@@ -272,6 +272,12 @@ int jvae_clip_scale_f32(float* g, long n, const float* sqnorm, float max_norm, v
 int jvae_adam_step_f32(float* p, const float* g, float* m, float* v, long n,
                        float lr, float beta1, float beta2, float eps, float weight_decay, long step,
                        float max_norm, const float* sqnorm, int* nonfinite_flag, void* stream);
+/* The same update with step count / learning rate / betas in device memory (hyper: 6 floats [lr, beta1, beta2, completed
+ * steps, 2 scratch]); advance != 0 increments the step and refreshes the bias corrections first.  No host state: the
+ * whole training step can be captured into a HIP graph and replayed (ClassificationVariationalNetwork.graph_train_step). */
+int jvae_adam_step_dev_f32(float* p, const float* g, float* m, float* v, long n, float* hyper, int advance,
+                           float eps, float weight_decay, float max_norm, const float* sqnorm, int* nonfinite_flag,
+                           void* stream);
 
 /* ---- input pipeline in front of the path: uint8 batch (NHWC if nhwc else NCHW) -> horizontal flip
  * where flip[n] != 0 -> edge padding by `pad` + crop at offsets (dy[n], dx[n]) in [0, 2*pad] -> float32 NCHW / 255.

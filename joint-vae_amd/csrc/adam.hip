@@ -37,7 +37,20 @@ struct AdamP {
     float* p; const float* g; float* m; float* v; long n;
     float lr_over_bc1, b1, b2, eps, wd, inv_sqrt_bc2, max_norm;
     const float* sqnorm; int* flag;
+    const float* hyper;  // optional device block (adam_hyper_kernel): [lr, beta1, beta2, step, lr/bc1, 1/sqrt(bc2)] - the step
+                         // count and learning rate then live on the device, so a captured HIP graph of the training step
+                         // replays with the right bias correction
 };
+
+// hyper[3] += 1 (the step count), then the two bias-correction factors of that step
+__global__ void adam_hyper_kernel(float* hyper) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double step = (double)hyper[3] + 1.0;
+    hyper[3] = (float)step;
+    const double bc1 = 1.0 - pow((double)hyper[1], step), bc2 = 1.0 - pow((double)hyper[2], step);
+    hyper[4] = (float)((double)hyper[0] / bc1);
+    hyper[5] = (float)(1.0 / sqrt(bc2));
+}
 
 __device__ __forceinline__ float adam1(float p, float g, float& m, float& v, const AdamP& a, float coef) {
     g = fmaf(g, coef, a.wd * p);
@@ -48,6 +61,7 @@ __device__ __forceinline__ float adam1(float p, float g, float& m, float& v, con
 }
 
 __global__ __launch_bounds__(256) void adam_kernel(AdamP a) {
+    if (a.hyper) { a.lr_over_bc1 = a.hyper[4]; a.inv_sqrt_bc2 = a.hyper[5]; a.b1 = a.hyper[1]; a.b2 = a.hyper[2]; }
     float coef = 1.f;
     if (a.max_norm > 0.f && a.sqnorm) coef = fminf(1.f, a.max_norm / (sqrtf(a.sqnorm[0]) + 1e-6f));
     bool bad = false;
@@ -140,8 +154,34 @@ int jvae_adam_step_f32(float* p, const float* g, float* m, float* v, long n,
     a.lr_over_bc1 = (float)((double)lr / bc1);
     a.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
     a.b1 = beta1; a.b2 = beta2; a.eps = eps; a.wd = weight_decay; a.max_norm = max_norm;
-    a.sqnorm = sqnorm; a.flag = nonfinite_flag;
+    a.sqnorm = sqnorm; a.flag = nonfinite_flag; a.hyper = nullptr;
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, a);
+    JVAE_LAUNCH_CHECK();
+    return 0;
+}
+
+// Same update with the step count, learning rate and betas in DEVICE memory: hyper = 6 floats [lr, beta1, beta2, step
+// (completed steps), scratch, scratch].  advance != 0 first increments hyper[3] and refreshes the bias corrections (once per
+// optimiser step; further parameter groups of the same step pass advance = 0 with their own block, or share one).  Nothing
+// here depends on host state, so the call can be captured into a HIP graph and replayed.
+int jvae_adam_step_dev_f32(float* p, const float* g, float* m, float* v, long n, float* hyper, int advance,
+                           float eps, float weight_decay, float max_norm, const float* sqnorm, int* nonfinite_flag,
+                           void* stream) {
+    if (n < 0 || !hyper) return JVAE_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (advance) {
+        hipLaunchKernelGGL(adam_hyper_kernel, dim3(1), dim3(64), 0, st, hyper);
+        JVAE_LAUNCH_CHECK();
+    }
+    if (n == 0) return 0;
+    if (!p || !g || !m || !v) return JVAE_EINVAL;
+    if (!al16(p) || !al16(g) || !al16(m) || !al16(v)) return JVAE_EINVAL;
+    AdamP a;
+    a.p = p; a.g = g; a.m = m; a.v = v; a.n = n;
+    a.lr_over_bc1 = 0.f; a.inv_sqrt_bc2 = 0.f; a.b1 = 0.f; a.b2 = 0.f;
+    a.eps = eps; a.wd = weight_decay; a.max_norm = max_norm;
+    a.sqnorm = sqnorm; a.flag = nonfinite_flag; a.hyper = hyper;
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4)), dim3(256), 0, st, a);
     JVAE_LAUNCH_CHECK();
     return 0;
 }

@@ -73,6 +73,7 @@ _SIGS = {
     'jvae_sqnorm_workspace_bytes': (c_size_t, []),
     'jvae_sqnorm_accum_f32': (c_int, [P, c_long, P, c_int, P, c_size_t, P]),
     'jvae_clip_scale_f32': (c_int, [P, c_long, P, c_float, P]),
+    'jvae_adam_step_dev_f32': (c_int, [P, P, P, P, c_long, P, c_int, c_float, c_float, c_float, P, P, P]),
     'jvae_adam_step_f32': (c_int, [P, P, P, P, c_long] + [c_float] * 5 + [c_long, c_float, P, P, P]),
 }
 

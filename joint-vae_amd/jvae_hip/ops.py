@@ -761,6 +761,14 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, max_norm=0.
     L.check(rc, 'jvae_adam_step_f32')
 
 
+def adam_step_dev(p, g, m, v, hyper, advance, eps, weight_decay, max_norm=0., sqnorm=None, flag=None):
+    """Adam with step count / lr / betas read from the 6-float device block `hyper` (capturable: no host state)."""
+    rc = L.load().jvae_adam_step_dev_f32(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), p.numel(), L.ptr(hyper), int(advance),
+                                         eps, weight_decay, float(max_norm or 0.), L.ptr(sqnorm), L.ptr(flag),
+                                         L.stream_ptr())
+    L.check(rc, 'jvae_adam_step_dev_f32')
+
+
 # ------------------------------------------------------------------------------------------- input pipeline
 def augment_batch(images_u8, flip=None, dy=None, dx=None, pad=0, nhwc=True):
     """uint8 batch (N,H,W,C) [or (N,C,H,W) with nhwc=False] -> float32 (N,C,H,W) in [0,1] with the reference's training

@@ -110,6 +110,7 @@ class Optimizer:
             old = self._lr
             self._epochs_decayed += 1
             self._lr = self.init_lr * (1 - self.lr_decay) ** self._epochs_decayed
+            self._sync_device_lr()
             logging.debug(f'lr updated from {old:.4e} to {self._lr:.4e}')
 
     def update_scheduler_from_epoch(self, n):
@@ -303,9 +304,36 @@ class Optimizer:
         clip = self.grad_clipping if self._clip_pending else 0.
         for g in self._groups:
             g.step += 1
-            ops.adam_step(g.p, g.g, g.m, g.v, self._lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
-                          g.step, max_norm=clip, sqnorm=self._sqnorm if clip else None, flag=self._flag)
+            if getattr(self, '_device_hyper', False):
+                # step count / lr / betas live in a device block (capturable into a HIP graph, see enable_device_hyper)
+                if getattr(g, 'hyper', None) is None or g.hyper.device != dev:
+                    g.hyper = torch.tensor([self._lr, self.betas[0], self.betas[1], float(g.step - 1), 0., 0.],
+                                           device=dev, dtype=torch.float32)
+                ops.adam_step_dev(g.p, g.g, g.m, g.v, g.hyper, True, self.eps, self.weight_decay, max_norm=clip,
+                                  sqnorm=self._sqnorm if clip else None, flag=self._flag)
+            else:
+                ops.adam_step(g.p, g.g, g.m, g.v, self._lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
+                              g.step, max_norm=clip, sqnorm=self._sqnorm if clip else None, flag=self._flag)
         self._clip_pending = False
+
+    def enable_device_hyper(self, on=True):
+        """Keep Adam's step count, learning rate and betas in device memory (updated by a one-thread kernel in front of
+        the update) so that a captured training step replays with the right bias correction.  The host-side step count
+        stays the reference for state_dict(); a graph replay must call note_replayed_step()."""
+        self._device_hyper = bool(on)
+        for g in self._groups:
+            g.hyper = None
+        return self
+
+    def note_replayed_step(self):
+        """Host bookkeeping for one optimiser step that ran inside a replayed HIP graph."""
+        for g in self._groups:
+            g.step += 1
+
+    def _sync_device_lr(self):
+        for g in self._groups:
+            if getattr(g, 'hyper', None) is not None:
+                g.hyper[0] = self._lr
 
     def nonfinite_flag(self):
         """Device int32 tensor, non-zero once any updated parameter was NaN/Inf (None before the first step)."""
