@@ -4,7 +4,6 @@ PyTorch is plumbing here (device memory, streams, the autograd tape); every FLOP
 executed by the hand-written gfx950 kernels.  Every function raises if its tensors are not on the GPU.
 """
 import math
-import os as _os
 from ctypes import byref, c_int
 
 import torch
@@ -314,8 +313,7 @@ class _Conv(torch.autograd.Function):
         if ctx.needs_input_grad[1] or want_b:
             w_slot = _grad_slot(ctx.w_ref)
             b_slot = _grad_slot(ctx.b_ref) if want_b else None
-            if OVERLAP_WGRAD and w_slot is not None and (b_slot is not None or not want_b) \
-                    and not (ctx.aff is not None and _os.environ.get('JVAE_AFF_SIDE') == '0'):
+            if OVERLAP_WGRAD and w_slot is not None and (b_slot is not None or not want_b):
                 # in-place into the flat gradient buffer: nothing downstream of this node consumes the result before
                 # the optimiser, so the kernel goes to the side stream and overlaps the rest of backward
                 main = torch.cuda.current_stream(x.device)

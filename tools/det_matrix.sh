@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box: run tools/determinism.py under a few switches (step-0 gradient difference of two identical models)
 cd "$(dirname "$0")/.."
-for cfg in "A_default:" "B_aff_wgrad_on_main:JVAE_AFF_SIDE=0" "C_no_defer:JVAE_DEFER_BN=0" "A_default_again:"; do
+for cfg in "A_default:" "B_no_defer:JVAE_DEFER_BN=0" "A_default_again:"; do
   name=${cfg%%:*}; envs=${cfg#*:}
   echo -n "$name  "
   env $envs timeout -k 10 100 python tools/determinism.py 2>&1 | grep "step 0 worst grad" | cut -c1-90
