@@ -437,6 +437,7 @@ class _BatchNormDefer(torch.autograd.Function):
         else:
             ctx.dims = None
         ctx.mark_non_differentiable(coef)
+        ctx.set_materialize_grads(False)        # no zero-fill launch for the (never used) gradient of `coef`
         return x.view_as(x), coef
 
     @staticmethod
