@@ -40,12 +40,25 @@ WORKLOADS = {   # id -> (description, FLOP per image fwd+bwd)   (BASELINE.json c
 }
 
 
+_ADAM = dict(optim_type='adam', lr=1e-3, weight_decay=3e-5, grad_clipping=100)
+
+
+def model_kwargs(workload):
+    """Constructor arguments of the BASELINE.json configurations (reference `config.ini:137-169`)."""
+    C, K, shape, feat, ups = {2: (10, 64, (3, 32, 32), 'conv32', 'deconv32'),
+                              3: (100, 64, (3, 32, 32), 'conv32', 'deconv32'),
+                              5: (20, 200, (3, 64, 64), 'conv32+', 'deconv32+')}[workload]
+    return dict(input_shape=shape, num_labels=C, type='cvae', features=feat, upsampler=ups, encoder=[], decoder=[],
+                classifier=[], batch_norm='both', latent_dim=K, latent_sampling=1, test_latent_sampling=1,
+                sigma={'value': 1.0, 'learned': True}, gamma=0, beta=1., output_activation='linear',
+                prior=dict(distribution='gaussian', init_mean=0., learned_means=True, var_dim='scalar', freeze_means=0),
+                optimizer=dict(_ADAM))
+
+
 def build_model(device, workload=2):
     from cvae import ClassificationVariationalNetwork as Net
-    from oracle.cases import full_config, get_case       # constructor kwargs only (data, not the oracle's arithmetic)
     torch.manual_seed(0)
-    kw = get_case('c5_n4')['net'] if workload == 5 else full_config(workload, BATCH_PER_GPU)['net']
-    net = Net(**kw)
+    net = Net(**model_kwargs(workload))
     net.to(device)
     net.train()
     return net

@@ -1,7 +1,7 @@
 """GPU box: config-5 geometry model, fp32 vs bf16 compute on the same weights / batch / epsilon: per-sample losses, global
 gradient, and a short training run."""
 import os, sys, copy, torch
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [REPO, os.path.join(REPO, 'joint-vae_amd')]
 from oracle.cases import get_case
 from oracle.det_init import det_inputs, load_det_state

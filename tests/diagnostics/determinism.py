@@ -1,6 +1,6 @@
 """GPU box: two identical models, same batch: how far apart are gradients / parameters after 1 and 2 steps?"""
 import os, sys, torch
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [REPO, os.path.join(REPO, 'joint-vae_amd')]
 from oracle.cases import get_case
 from oracle.det_init import det_inputs, load_det_state

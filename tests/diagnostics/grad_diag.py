@@ -1,7 +1,7 @@
 """Debug helper (GPU box): per-parameter gradient error of one golden case."""
 import os, sys
 import numpy as np, torch
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [REPO, os.path.join(REPO, 'joint-vae_amd')]
 from oracle.cases import get_case
 from oracle.det_init import det_inputs, load_det_state

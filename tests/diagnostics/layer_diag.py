@@ -1,7 +1,7 @@
 """Debug helper (GPU box): layer-by-layer forward / backward error of the HIP model vs the fp64 CPU oracle."""
 import os, sys
 import numpy as np, torch
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [REPO, os.path.join(REPO, 'joint-vae_amd')]
 from oracle import jvae_oracle as O
 from oracle.cases import get_case

@@ -71,7 +71,7 @@ def test_train_step_matches_reference_golden(name, golden_dir):
     got = {n: p.grad for n, p in net.named_parameters() if p.grad is not None}
     assert set(g['grad_names']) <= set(got)
     # Gradients: two fp32 implementations cannot agree bit-wise on the forward pass, so a handful of ReLU
-    # pre-activations within ~1e-6 of zero take the other branch (measured with tools/layer_diag.py: every
+    # pre-activations within ~1e-6 of zero take the other branch (measured with tests/diagnostics/layer_diag.py: every
     # forward tensor agrees to <3e-6, the backward differs on isolated elements only).  Per-element max-abs
     # comparison is therefore meaningless for the backward; the bar is the relative L2 error per tensor
     # (<= 5e-2 at these tiny batches of 4-8 images, typically 1e-4) and the global gradient norm (<= 1e-4).  Kernel-level exactness is pinned
