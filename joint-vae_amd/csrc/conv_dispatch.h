@@ -26,6 +26,13 @@ int jvae_conv5_fwd_max_splits(int N, int OW);
 
 int jvae_conv5_pack(const float* w, float* wp, int C, int O, int swap, int flip, hipStream_t st);
 
+// conv_x3.hip: the same operator on the bf16 matrix cores, every fp32 operand split exactly into three bf16 terms
+bool jvae_conv5_x3_ok(int Cin, int H, int W, int Cout, int OH, int OW, int S, int P);
+size_t jvae_conv5_x3_pack_bytes(int Cin, int Cout);
+int jvae_conv5_x3_fwd(const float* in, const float* w, int swap, int flip, const float* bias, float* out,
+                      int N, int Cin, int H, int W, int Cout, int OW, int S, int P, float* ws, hipStream_t st,
+                      float* stats = nullptr, int* nsplit = nullptr, const InAff* aff = nullptr);
+
 // conv_t2_mfma.hip: stride-2 transposed 5x5 (4-phase): small (C,HS,WS) -> big (O,2HS,2WS), wpacked = (C,25,O)
 bool jvae_convt2_ok(int C, int HS, int WS, int O, int HB, int WB, int KH, int KW, int S, int P);
 int jvae_convt2(const float* in, const float* wpacked, const float* bias, float* out, int N, int C, int WS, int O,

@@ -291,7 +291,11 @@ bool jvae_conv5_fwd_ok(int Cin, int H, int W, int Cout, int OH, int OW, int S, i
     return true;
 }
 
-size_t jvae_conv5_pack_floats(int Cin, int Cout) { return (size_t)Cin * 25 * ((Cout + 31) / 32 * 32); }
+// workspace of the weight re-pack in floats: the fp32 operand layout or the three bf16 planes of conv_x3.hip
+size_t jvae_conv5_pack_floats(int Cin, int Cout) {
+    const size_t a = (size_t)Cin * 25 * ((Cout + 31) / 32 * 32), b = (jvae_conv5_x3_pack_bytes(Cin, Cout) + 3) / 4;
+    return a > b ? a : b;
+}
 
 int jvae_conv5_pack(const float* w, float* wp, int C, int O, int swap, int flip, hipStream_t st) {
     const int OP = (O + 31) / 32 * 32;
@@ -309,6 +313,8 @@ int jvae_conv5_fwd_max_splits(int N, int OW) { return (int)(((long)N * OW * OW +
 int jvae_conv5_fwd(const float* in, const float* w, int swap, int flip, const float* bias, float* out,
                    int N, int Cin, int H, int W, int Cout, int OW, int S, int P, float* ws, hipStream_t st,
                    float* stats, int* nsplit, const InAff* aff) {
+    if (jvae_conv5_x3_ok(Cin, H, W, Cout, OW, OW, S, P))      // stride-1 layers with >= 16 input channels: conv_x3.hip
+        return jvae_conv5_x3_fwd(in, w, swap, flip, bias, out, N, Cin, H, W, Cout, OW, S, P, ws, st, stats, nsplit, aff);
     int rc = jvae_conv5_pack(w, ws, Cin, Cout, swap, flip, st);
     if (rc) return rc;
     FwdP p{in, ws, bias, out, N, Cin, H, W, (Cout + 31) / 32 * 32, P, Cout, stats, aff ? *aff : InAff{nullptr, nullptr, 0}};

@@ -1,0 +1,391 @@
+// fp32 5x5 convolution on the bf16 matrix cores by 3-way operand splitting ("x3").
+//
+//   out[n][o][y][x] = bias[o] + sum_{c,kh,kw} in[n][c][y*S + kh - P][x*S + kw - P] * W[c][kh*5+kw][o]
+//
+// Same operator, tensors (fp32 NCHW in, fp32 NCHW out) and weight roles (swap / flip) as conv_mfma.hip; only the
+// arithmetic unit differs.  v_mfma_f32_32x32x2_f32 retires 64 FLOP/cycle/SIMD (157 TFLOP/s per MI355X),
+// v_mfma_f32_32x32x16_bf16 1024 (2.5 PFLOP/s).  Every fp32 operand is written EXACTLY as a sum of three bf16 numbers
+//      v = hi + mid + lo,   hi = bf16(v), mid = bf16(v - hi), lo = bf16(v - hi - mid)      (8 + 8 + 8 significand bits)
+// and a product x*w is accumulated (fp32 accumulators inside the MFMA) from the six partial products whose weight is
+// >= 2^-24 of the full one: x_lo w_hi, x_hi w_lo, x_mid w_mid, x_mid w_hi, x_hi w_mid, x_hi w_hi.  Products of bf16
+// numbers are exact in fp32, the three dropped terms are <= 2^-24 |x w|: the result differs from an fp32 FMA chain
+// by less than that chain's own rounding (measured against an fp64 convolution: 2.5e-7 relative for the fp32 kernel,
+// 1e-7 for this one; tests/test_ops_gpu.py).  Six bf16 MFMAs cover K = 16 in 6*32 = 192 cycles, the fp32 MFMA needs
+// 8*64 = 512: the fp32-equivalent ceiling is 2.5 PFLOP/s / 6 = 417 TFLOP/s.
+//
+// Mapping (one workgroup = 4 waves = MT*128 output pixels x 32 output channels, K step = 16 input channels):
+//  * the input patch (with zero halo) is loaded as fp32 NCHW rows (8-byte loads, 2 pixels x 8 channels per thread),
+//    the deferred BatchNorm(+ReLU) of conv_mfma.hip is applied in registers, the value is split and stored as three
+//    planes of 16-byte units (8 channels of one pixel = one lane's MFMA operand): every fragment read is one
+//    ds_read_b128 at lane offset + immediate;
+//  * weights are split once per call by the re-pack kernel ([K step][kernel row][plane][kw][half][o] units) and
+//    staged per KERNEL ROW (5 taps, 15 KB) into a double-buffered LDS area: one barrier per 60 MFMAs, two workgroups
+//    per CU (77 KB each);
+//  * accumulators, bias, BatchNorm partial sums and the coalesced NCHW epilogue are those of the fp32 kernel.
+#include <stdlib.h>
+#include "common.h"
+#include "jvae_internal.h"
+#include "conv_dispatch.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void split3(float v, __bf16& h, __bf16& m, __bf16& l) {
+    h = (__bf16)v;
+    float r = v - (float)h;          // exact
+    m = (__bf16)r;
+    r -= (float)m;                   // exact
+    l = (__bf16)r;
+}
+
+// Wp[(kb*5 + kh)][(plane*5 + kw)*2 + half][o][ci] = plane(W[o][c = kb*16 + half*8 + ci][tap = kh*5 + kw])  (o < OP)
+// swap: source is [c][o][tap] (ConvTranspose2d layout / role swap), flip: tap -> 24 - tap
+__global__ __launch_bounds__(256) void x3_wpack_kernel(const float* __restrict__ w, __bf16* __restrict__ wp,
+                                                       int C, int O, int KB, int OP, int swap, int flip) {
+    const long total = (long)KB * 25 * 2 * OP * 8;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int ci = (int)(i % 8);
+        long t = i / 8;
+        const int o = (int)(t % OP); t /= OP;
+        const int half = (int)(t % 2); t /= 2;
+        const int tap = (int)(t % 25);
+        const int kb = (int)(t / 25);
+        const int kh = tap / 5, kw = tap % 5;
+        const int c = kb * 16 + half * 8 + ci;
+        const int st = flip ? 24 - tap : tap;
+        float v = 0.f;
+        if (c < C && o < O) v = swap ? w[((long)c * O + o) * 25 + st] : w[((long)o * C + c) * 25 + st];
+        __bf16 s[3];
+        split3(v, s[0], s[1], s[2]);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+            wp[((((long)(kb * 5 + kh) * 30 + (pl * 5 + kw) * 2 + half) * OP) + o) * 8 + ci] = s[pl];
+    }
+}
+
+struct X3P {
+    const float* in;     // (N, Cin, H, W) fp32
+    const u32x4* wp;     // packed split weights (KB*5, 30, OP) units
+    const float* bias;   // (CoutReal) or null
+    float* out;          // (N, CoutReal, OH, OW) fp32
+    int N, Cin, H, W, OP, P, CoutReal;
+    float* stats;        // optional (CoutReal, gridDim.x, 2)
+    InAff aff;           // deferred BatchNorm(+ReLU) of the input (sc == nullptr: none)
+};
+
+template <int S, int OW, int MT>
+struct X3Geom {
+    static constexpr int OH = OW;
+    static constexpr int PIX = MT * 128;
+    static constexpr int OHW = OH * OW;
+    static constexpr int NIMG = PIX >= OHW ? PIX / OHW : 1;
+    static constexpr int TH = PIX >= OHW ? OH : PIX / OW;
+    static constexpr int ROWS = (TH - 1) * S + 5;
+    static constexpr int WIN = OW * S;
+    static constexpr int WP0 = (OW - 1) * S + 9;
+    static constexpr int WP1 = WIN + 4;
+    static constexpr int WP = WP0 > WP1 ? WP0 : WP1;          // units per patch row
+    static constexpr int CH = ROWS * WP;                       // units per 8-channel block per image
+    static constexpr int XS = NIMG * 2 * CH;                   // patch units of one plane (16 channels)
+    static constexpr int WGS = 3 * 5 * 2 * 32;                 // weight units of one kernel row (3 planes x 5 taps x 2 halves)
+    static constexpr int LDS_BYTES = (3 * XS + 2 * WGS) * 16;
+};
+
+template <int S, int OW, int MT, bool AFF>
+__global__ __launch_bounds__(256, 2) void conv5_x3_kernel(X3P p) {
+    using G = X3Geom<S, OW, MT>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    u32x4* Xs = reinterpret_cast<u32x4*>(lds_raw);            // [3 planes][XS]
+    u32x4* Ws = Xs + 3 * G::XS;                                // [2 buffers][WGS]
+    __shared__ float ctab[AFF ? 2 * 256 : 1];                 // (scale, shift) of all input channels (<= 256)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    constexpr int TILES_PER_IMG = G::OHW >= G::PIX ? G::OHW / G::PIX : 1;
+    const int img0 = (G::OHW >= G::PIX) ? (int)(blockIdx.x / TILES_PER_IMG) : (int)blockIdx.x * G::NIMG;
+    const int row0 = (G::OHW >= G::PIX) ? (int)(blockIdx.x % TILES_PER_IMG) * G::TH : 0;
+    const int o0 = blockIdx.y * 32;
+    const int KB = (p.Cin + 15) / 16;
+    const int NG = KB * 5;                                     // weight groups: (K step, kernel row)
+
+    if (AFF)
+        for (int i = tid; i < KB * 16; i += 256) {
+            const bool ok = i < p.Cin;
+            ctab[i] = ok ? p.aff.sc[i] : 0.f;
+            ctab[256 + i] = ok ? p.aff.sh[i] : 0.f;
+        }
+    // halo columns / out-of-image rows / missing images / missing channels are zeroed once and never written again
+    for (int i = tid; i < 3 * G::XS; i += 256) Xs[i] = u32x4{0u, 0u, 0u, 0u};
+
+    int pixoff[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int pix = (wave * MT + mt) * 32 + l31;
+        const int im = pix / (G::TH * OW), rem = pix % (G::TH * OW);
+        const int r = rem / OW, c = rem % OW;
+        pixoff[mt] = im * (2 * G::CH) + half * G::CH + (r * S) * G::WP + c * S + 4 - p.P;
+    }
+
+    f32x16 acc[MT];
+#pragma unroll
+    for (int b = 0; b < MT; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+
+    const int in_row0 = row0 * S - p.P;
+    constexpr int W2 = G::WIN / 2;
+    constexpr int XPAIRS = G::NIMG * 2 * G::ROWS * W2;         // (2 pixels x 8 channels) items per K step
+    constexpr int XU = (XPAIRS + 255) / 256, WU = (G::WGS + 255) / 256;
+    f32x2 rx[XU][8];
+    u32x4 rw[WU];
+
+    auto gloadX = [&](int kb) {
+#pragma unroll
+        for (int k = 0; k < XU; ++k) {
+            const int u = tid + k * 256;
+            const int xp = u % W2;
+            int t = u / W2;
+            const int lr = t % G::ROWS; t /= G::ROWS;
+            const int h = t % 2, im = t / 2;
+            const int ir = in_row0 + lr, n = img0 + im, c0 = kb * 16 + h * 8;
+            const bool ok = u < XPAIRS && ir >= 0 && ir < p.H && n < p.N;
+            const float* src = p.in + (((long)n * p.Cin + c0) * p.H + ir) * p.W + 2 * xp;
+#pragma unroll
+            for (int ci = 0; ci < 8; ++ci) {
+                f32x2 v = {0.f, 0.f};
+                if (ok && c0 + ci < p.Cin) v = *reinterpret_cast<const f32x2*>(src + (long)ci * p.H * p.W);
+                rx[k][ci] = v;
+            }
+        }
+    };
+    auto gloadW = [&](int g) {
+#pragma unroll
+        for (int k = 0; k < WU; ++k) {
+            const int u = tid + k * 256;
+            const int col = u % 32, r = u / 32;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (u < G::WGS) v = p.wp[((long)g * 30 + r) * p.OP + o0 + col];
+            rw[k] = v;
+        }
+    };
+    auto lstoreX = [&](int kb) {                    // kb: the K step whose data sits in rx
+#pragma unroll
+        for (int k = 0; k < XU; ++k) {
+            const int u = tid + k * 256;
+            if (u < XPAIRS) {
+                const int xp = u % W2;
+                int t = u / W2;
+                const int lr = t % G::ROWS; t /= G::ROWS;
+                const int h = t % 2, im = t / 2;
+                bool live = true;                  // padding cells must stay exact zeros under the deferred BatchNorm
+                if (AFF) {
+                    const int ir = in_row0 + lr, n = img0 + im;
+                    live = ir >= 0 && ir < p.H && n < p.N;
+                }
+                bf16x8 s[2][3];
+#pragma unroll
+                for (int ci = 0; ci < 8; ++ci) {
+                    f32x2 v = rx[k][ci];
+                    if (AFF && live) {
+                        const int ch = kb * 16 + h * 8 + ci;               // ctab is zero beyond Cin: 0*0 + 0
+                        const float sc = ctab[ch], sh = ctab[256 + ch];
+                        v[0] = fmaf(v[0], sc, sh);
+                        v[1] = fmaf(v[1], sc, sh);
+                        if (p.aff.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        __bf16 a, b, c;
+                        split3(v[j], a, b, c);
+                        s[j][0][ci] = a; s[j][1][ci] = b; s[j][2][ci] = c;
+                    }
+                }
+                const int base = (im * 2 + h) * G::CH + lr * G::WP + 4 + 2 * xp;
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) Xs[pl * G::XS + base + j] = __builtin_bit_cast(u32x4, s[j][pl]);
+            }
+        }
+    };
+    auto lstoreW = [&](int buf) {
+#pragma unroll
+        for (int k = 0; k < WU; ++k) {
+            const int u = tid + k * 256;
+            if (u < G::WGS) Ws[buf * G::WGS + u] = rw[k];
+        }
+    };
+
+    // one kernel row (5 taps) of one K step: 6 MFMAs per tap and pixel group, fragments of tap kw+1 read ahead
+    auto compute = [&](int buf, int rowoff) {
+        const u32x4* Wb = Ws + buf * G::WGS + half * 32 + l31;
+        u32x4 fa[2][3], fb[2][3][MT];
+        auto frag = [&](int kw, u32x4 (&a)[3], u32x4 (&b)[3][MT]) {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                a[pl] = Wb[(pl * 5 + kw) * 64];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) b[pl][mt] = Xs[pl * G::XS + pixoff[mt] + rowoff + kw];
+            }
+        };
+        frag(0, fa[0], fb[0]);
+#pragma unroll
+        for (int kw = 0; kw < 5; ++kw) {
+            if (kw + 1 < 5) frag(kw + 1, fa[(kw + 1) & 1], fb[(kw + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            // (weight plane, input plane), smallest partial products first
+            constexpr int WPL[6] = {0, 2, 1, 0, 1, 0}, XPL[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[kw & 1][WPL[t]]),
+                                                                      __builtin_bit_cast(bf16x8, fb[kw & 1][XPL[t]][mt]),
+                                                                      acc[mt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    gloadX(0);
+    gloadW(0);
+    __syncthreads();                               // zero fill + coefficient table complete
+    lstoreX(0);
+    lstoreW(0);
+    if (NG > 1) gloadW(1);
+    __syncthreads();
+    int kb = 0, kh = 0;
+    for (int g = 0; g < NG; ++g) {
+        // invariant: patch of K step kb in Xs, weight group g in buffer g&1, rw = weight group g+1
+        const bool more = g + 1 < NG, last_row = kh == 4;
+        if (more && !last_row) {                   // buffer (g+1)&1 was last read in group g-1: every wave is past it
+            lstoreW((g + 1) & 1);
+            if (g + 2 < NG) gloadW(g + 2);
+        }
+        if (kh == 3 && kb + 1 < KB) gloadX(kb + 1);
+        compute(g & 1, kh * G::WP);
+        __syncthreads();
+        if (more && last_row) {                    // K step change: the patch is fully consumed
+            lstoreX(kb + 1);
+            lstoreW((g + 1) & 1);
+            if (g + 2 < NG) gloadW(g + 2);
+            __syncthreads();
+        }
+        if (++kh == 5) { kh = 0; ++kb; }
+    }
+
+    // ---- optional BatchNorm statistics of this workgroup's tile (the loop ended with a barrier: LDS is free)
+    if (p.stats) {
+        float* red = reinterpret_cast<float*>(lds_raw);       // [4 waves][32][2]
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) { const float v = acc[mt][r]; s1 += v; s2 += v * v; }
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+            if (l31 == 0) {
+                const int ch = (r & 3) + 8 * (r >> 2) + 4 * half;
+                red[(wave * 32 + ch) * 2 + 0] = s1;
+                red[(wave * 32 + ch) * 2 + 1] = s2;
+            }
+        }
+        __syncthreads();
+        if (tid < 32 && o0 + tid < p.CoutReal) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { s1 += red[(w * 32 + tid) * 2]; s2 += red[(w * 32 + tid) * 2 + 1]; }
+            float* dst = p.stats + ((long)(o0 + tid) * gridDim.x + blockIdx.x) * 2;
+            dst[0] = s1; dst[1] = s2;
+        }
+    }
+
+    // ---- epilogue: lane holds pixel l31 of each 32-pixel group, rows (channels) (r&3) + 8*(r>>2) + 4*half
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int pix = (wave * MT + mt) * 32 + l31;
+        const int im = pix / (G::TH * OW), rem = pix % (G::TH * OW);
+        const int n = img0 + im;
+        if (n >= p.N) continue;
+        const int oy = row0 + rem / OW, ox = rem % OW;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int o = o0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (o >= p.CoutReal) continue;
+            float v = acc[mt][r];
+            if (p.bias) v += p.bias[o];
+            p.out[(((long)n * p.CoutReal + o) * G::OH + oy) * OW + ox] = v;
+        }
+    }
+}
+
+thread_local int g_x3_splits = 0;
+
+template <int S, int OW, int MT>
+int launch_x3(const X3P& p, hipStream_t st) {
+    using G = X3Geom<S, OW, MT>;
+    static_assert(G::LDS_BYTES + 2048 <= 80 * 1024, "two workgroups per CU must fit the 160 KB LDS");
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_x3_kernel<S, OW, MT, false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_x3_kernel<S, OW, MT, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const long pixels = (long)p.N * G::OHW;
+    dim3 grid((unsigned)((pixels + G::PIX - 1) / G::PIX), (unsigned)(p.OP / 32));
+    if (G::OHW < G::PIX) grid.x = (unsigned)((p.N + G::NIMG - 1) / G::NIMG);
+    g_x3_splits = (int)grid.x;
+    if (p.aff.sc) {
+        if (p.Cin > 256) return JVAE_ENOTSUP;
+        hipLaunchKernelGGL((conv5_x3_kernel<S, OW, MT, true>), grid, dim3(256), G::LDS_BYTES, st, p);
+    } else {
+        hipLaunchKernelGGL((conv5_x3_kernel<S, OW, MT, false>), grid, dim3(256), G::LDS_BYTES, st, p);
+    }
+    JVAE_LAUNCH_CHECK();
+    return 0;
+}
+
+static int g_x3 = -1;        // JVAE_X3=0: keep every layer on the fp32 matrix-core kernels (A/B switch)
+
+}  // namespace
+
+// Layers the split kernel takes over from conv_mfma.hip: stride 1, at least one full K step of input channels.
+bool jvae_conv5_x3_ok(int Cin, int H, int W, int Cout, int OH, int OW, int S, int P) {
+    if (g_x3 < 0) { const char* e = getenv("JVAE_X3"); g_x3 = (e && e[0] == '0') ? 0 : 1; }
+    if (!g_x3) return false;
+    if (S != 1 || Cin < 16 || Cin > 256) return false;
+    if (OW != 8 && OW != 16 && OW != 32 && OW != 64) return false;
+    return jvae_conv5_fwd_ok(Cin, H, W, Cout, OH, OW, S, P);
+}
+
+size_t jvae_conv5_x3_pack_bytes(int Cin, int Cout) {
+    return (size_t)((Cin + 15) / 16) * 25 * 2 * ((Cout + 31) / 32 * 32) * 16 * 3;
+}
+
+int jvae_conv5_x3_fwd(const float* in, const float* w, int swap, int flip, const float* bias, float* out,
+                      int N, int Cin, int H, int W, int Cout, int OW, int S, int P, float* ws, hipStream_t st,
+                      float* stats, int* nsplit, const InAff* aff) {
+    const int KB = (Cin + 15) / 16, OP = (Cout + 31) / 32 * 32;
+    {
+        const long total = (long)KB * 25 * 2 * OP * 8;
+        const int blocks = (int)((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256);
+        hipLaunchKernelGGL(x3_wpack_kernel, dim3(blocks), dim3(256), 0, st, w, (__bf16*)ws, Cin, Cout, KB, OP, swap, flip);
+        JVAE_LAUNCH_CHECK();
+    }
+    X3P p{in, (const u32x4*)ws, bias, out, N, Cin, H, W, OP, P, Cout, stats, aff ? *aff : InAff{nullptr, nullptr, 0}};
+    struct Fin { int* n; ~Fin() { if (n) *n = g_x3_splits; } } fin{nsplit};
+    if (S != 1) return JVAE_ENOTSUP;
+    switch (OW) {
+        case 8: return launch_x3<1, 8, 1>(p, st);
+        case 16: return launch_x3<1, 16, 2>(p, st);
+        case 32: return launch_x3<1, 32, 2>(p, st);
+        case 64: return launch_x3<1, 64, 1>(p, st);
+    }
+    return JVAE_ENOTSUP;
+}
