@@ -27,6 +27,23 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// Sum over the 32 lanes of each half-wave (lanes 0-31 / 32-63) on the vector ALU's data-parallel-primitive path - no
+// LDS traffic, unlike __shfl_xor (ds_bpermute): four steps inside each row of 16 lanes, then row_bcast15 adds lane 15
+// of row 0 (2) into row 1 (3).  The total is valid in lanes 16-31 and 48-63 ONLY (JVAE_HALF_SUM_LANE = 31 reads it).
+#define JVAE_HALF_SUM_LANE 31
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float jvae_dpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float half_wave_sum_hi(float v) {
+    v += jvae_dpp<0xB1, 0xf>(v);      // quad_perm [1,0,3,2]
+    v += jvae_dpp<0x4E, 0xf>(v);      // quad_perm [2,3,0,1]
+    v += jvae_dpp<0x141, 0xf>(v);     // row_half_mirror
+    v += jvae_dpp<0x140, 0xf>(v);     // row_mirror
+    v += jvae_dpp<0x142, 0xa>(v);     // row_bcast15 into rows 1 and 3 (rows 0 and 2 add the 0 of `old`)
+    return v;
+}
+
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

@@ -288,9 +288,9 @@ __global__ __launch_bounds__(256, 2) void conv5_b8_kernel(B8FwdP p) {
                 float s1 = 0.f, s2 = 0.f;
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) { const float v = acc[nt][mt][r]; s1 += v; s2 += v * v; }
-#pragma unroll
-                for (int o = 16; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
-                if (l31 == 0) {
+                s1 = half_wave_sum_hi(s1);
+                s2 = half_wave_sum_hi(s2);
+                if (l31 == JVAE_HALF_SUM_LANE) {
                     const int ch = nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                     red[(wave * G::WCOLS + ch) * 2 + 0] = s1;
                     red[(wave * G::WCOLS + ch) * 2 + 1] = s2;

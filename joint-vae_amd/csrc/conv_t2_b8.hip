@@ -164,9 +164,9 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void convt2_b8_kernel(T2B
             for (int r = 0; r < 2; ++r)
 #pragma unroll
                 for (int q = 0; q < 2; ++q) { const float v = acc[r][q][e]; s1 += v; s2 += v * v; }
-#pragma unroll
-            for (int o = 16; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
-            if (l31 == 0) {
+            s1 = half_wave_sum_hi(s1);
+            s2 = half_wave_sum_hi(s2);
+            if (l31 == JVAE_HALF_SUM_LANE) {
                 const int ch = (e & 3) + 8 * (e >> 2) + 4 * half;
                 red[(wave * 32 + ch) * 2 + 0] = s1;
                 red[(wave * 32 + ch) * 2 + 1] = s2;

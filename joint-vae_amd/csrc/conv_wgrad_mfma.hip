@@ -222,6 +222,36 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     dw[dst] = accumulate ? dw[dst] + s : s;
 }
 
+// The same fold with 16-byte accesses (Ca*Cb*25 a multiple of 4): 16 outputs-of-4 x 16 slab lanes per workgroup, every
+// thread adds its G/16 slabs in order, the 16 partial sums are folded in a fixed order.
+__global__ __launch_bounds__(256) void wgrad_reduce4_kernel(const f32x4* __restrict__ slab, float* __restrict__ dw,
+                                                            int G, int Ca, int Cb, int accumulate, int swapflip) {
+    __shared__ f32x4 part[16][16];
+    const int total4 = Ca * Cb * 25 / 4;
+    const int ix = threadIdx.x & 15, gy = threadIdx.x >> 4;
+    const int i4 = blockIdx.x * 16 + ix;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (i4 < total4)
+        for (int g = gy; g < G; g += 16) s += slab[(long)g * total4 + i4];
+    part[gy][ix] = s;
+    __syncthreads();
+    if (gy != 0 || i4 >= total4) return;
+    f32x4 t[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) t[k] = (part[4 * k][ix] + part[4 * k + 1][ix]) + (part[4 * k + 2][ix] + part[4 * k + 3][ix]);
+    s = (t[0] + t[1]) + (t[2] + t[3]);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int i = i4 * 4 + e;
+        int dst = i;
+        if (swapflip) {
+            const int tap = i % 25, b = (i / 25) % Cb, a = i / (25 * Cb);
+            dst = (b * Ca + a) * 25 + 24 - tap;
+        }
+        dw[dst] = accumulate ? dw[dst] + s[e] : s[e];
+    }
+}
+
 template <int S, int WS, int CB, bool PF = true>
 int launch_wg(const WgP& p, hipStream_t st) {
     using G = WgGeom<S, WS, CB>;
@@ -249,7 +279,11 @@ inline int pick_cb(int S, int WS, int Cb) {
 // dw (+)= sum over the G slabs (a, b, tap) in a fixed order; shared with the bf16 path (conv_wgrad_b8.hip)
 int jvae_wgrad_slab_reduce(const float* slab, float* dw, int G, int Ca, int Cb, int accumulate, int swapflip, hipStream_t st) {
     const int total = Ca * Cb * 25;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 64)), dim3(256), 0, st, slab, dw, G, Ca, Cb, accumulate, swapflip);
+    if (total % 4 == 0 && (reinterpret_cast<uintptr_t>(slab) & 15) == 0)
+        hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3(cdiv(total / 4, 16)), dim3(256), 0, st, (const f32x4*)slab, dw, G, Ca, Cb,
+                           accumulate, swapflip);
+    else
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 64)), dim3(256), 0, st, slab, dw, G, Ca, Cb, accumulate, swapflip);
     JVAE_LAUNCH_CHECK();
     return 0;
 }

@@ -129,11 +129,13 @@ __global__ __launch_bounds__(256, 2) void conv5_x3_kernel(X3P p) {
         pixoff[mt] = im * (2 * G::CH) + half * G::CH + (r * S) * G::WP + c * S + 4 - p.P;
     }
 
-    f32x16 acc[MT];
+    // two accumulator sets: the three small partial products are summed apart from the three large ones (added in
+    // the epilogue), which also doubles the distance between dependent MFMAs
+    f32x16 acc[MT], acs[MT];
 #pragma unroll
     for (int b = 0; b < MT; ++b)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+        for (int r = 0; r < 16; ++r) { acc[b][r] = 0.f; acs[b][r] = 0.f; }
 
     const int in_row0 = row0 * S - p.P;
     constexpr int W2 = G::WIN / 2;
@@ -142,34 +144,43 @@ __global__ __launch_bounds__(256, 2) void conv5_x3_kernel(X3P p) {
     f32x2 rx[XU][8];
     u32x4 rw[WU];
 
+    // Loads are unconditional (out-of-range items read a valid stand-in address and are zeroed when they are stored to
+    // LDS): with branches around them the compiler cannot count outstanding loads and falls back to vmcnt(0).  Their
+    // addresses are computed once: per K step / weight group only a uniform stride is added.
+    const float* xsrc[XU];
+    const u32x4* wsrc[WU];
+    const long cstride = (long)p.H * p.W;
+#pragma unroll
+    for (int k = 0; k < XU; ++k) {
+        const int u = tid + k * 256;
+        const int xp = u % W2;
+        int t = u / W2;
+        const int lr = t % G::ROWS; t /= G::ROWS;
+        const int h = t % 2, im = t / 2;
+        const int ir = in_row0 + lr, n = img0 + im;
+        const bool ok = u < XPAIRS && ir >= 0 && ir < p.H && n < p.N;
+        xsrc[k] = p.in + (((long)(ok ? n : 0) * p.Cin + h * 8) * p.H + (ok ? ir : 0)) * p.W + 2 * xp;
+    }
+#pragma unroll
+    for (int k = 0; k < WU; ++k) {
+        const int u = min(tid + k * 256, G::WGS - 1);          // the tail threads re-read the last unit (not stored)
+        wsrc[k] = p.wp + (long)(u / 32) * p.OP + o0 + u % 32;
+    }
     auto gloadX = [&](int kb) {
 #pragma unroll
         for (int k = 0; k < XU; ++k) {
-            const int u = tid + k * 256;
-            const int xp = u % W2;
-            int t = u / W2;
-            const int lr = t % G::ROWS; t /= G::ROWS;
-            const int h = t % 2, im = t / 2;
-            const int ir = in_row0 + lr, n = img0 + im, c0 = kb * 16 + h * 8;
-            const bool ok = u < XPAIRS && ir >= 0 && ir < p.H && n < p.N;
-            const float* src = p.in + (((long)n * p.Cin + c0) * p.H + ir) * p.W + 2 * xp;
+            const int h = ((tid + k * 256) / (W2 * G::ROWS)) % 2;
+            const float* src = xsrc[k] + (long)kb * 16 * cstride;
 #pragma unroll
             for (int ci = 0; ci < 8; ++ci) {
-                f32x2 v = {0.f, 0.f};
-                if (ok && c0 + ci < p.Cin) v = *reinterpret_cast<const f32x2*>(src + (long)ci * p.H * p.W);
-                rx[k][ci] = v;
+                const bool okc = kb * 16 + h * 8 + ci < p.Cin;  // channels beyond Cin: stand-in address, zeroed in lstoreX
+                rx[k][ci] = *reinterpret_cast<const f32x2*>(okc ? src + ci * cstride : xsrc[k]);
             }
         }
     };
     auto gloadW = [&](int g) {
 #pragma unroll
-        for (int k = 0; k < WU; ++k) {
-            const int u = tid + k * 256;
-            const int col = u % 32, r = u / 32;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (u < G::WGS) v = p.wp[((long)g * 30 + r) * p.OP + o0 + col];
-            rw[k] = v;
-        }
+        for (int k = 0; k < WU; ++k) rw[k] = wsrc[k][(long)g * 30 * p.OP];
     };
     auto lstoreX = [&](int kb) {                    // kb: the K step whose data sits in rx
 #pragma unroll
@@ -180,15 +191,13 @@ __global__ __launch_bounds__(256, 2) void conv5_x3_kernel(X3P p) {
                 int t = u / W2;
                 const int lr = t % G::ROWS; t /= G::ROWS;
                 const int h = t % 2, im = t / 2;
-                bool live = true;                  // padding cells must stay exact zeros under the deferred BatchNorm
-                if (AFF) {
-                    const int ir = in_row0 + lr, n = img0 + im;
-                    live = ir >= 0 && ir < p.H && n < p.N;
-                }
+                // out-of-image rows / missing images / channels were loaded from a stand-in address: exact zeros
+                const int ir = in_row0 + lr, n = img0 + im;
+                const bool live = ir >= 0 && ir < p.H && n < p.N;
                 bf16x8 s[2][3];
 #pragma unroll
                 for (int ci = 0; ci < 8; ++ci) {
-                    f32x2 v = rx[k][ci];
+                    f32x2 v = (live && kb * 16 + h * 8 + ci < p.Cin) ? rx[k][ci] : f32x2{0.f, 0.f};
                     if (AFF && live) {
                         const int ch = kb * 16 + h * 8 + ci;               // ctab is zero beyond Cin: 0*0 + 0
                         const float sc = ctab[ch], sh = ctab[256 + ch];
@@ -236,45 +245,55 @@ __global__ __launch_bounds__(256, 2) void conv5_x3_kernel(X3P p) {
         for (int kw = 0; kw < 5; ++kw) {
             if (kw + 1 < 5) frag(kw + 1, fa[(kw + 1) & 1], fb[(kw + 1) & 1]);
             __builtin_amdgcn_sched_barrier(0);
-            // (weight plane, input plane), smallest partial products first
-            constexpr int WPL[6] = {0, 2, 1, 0, 1, 0}, XPL[6] = {2, 0, 1, 1, 0, 0};
+            // (weight plane, input plane): small terms (even t) -> acs, large terms (odd t) -> acc
+            constexpr int WPL[6] = {0, 0, 2, 1, 1, 0}, XPL[6] = {2, 1, 0, 0, 1, 0};
 #pragma unroll
             for (int t = 0; t < 6; ++t)
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[kw & 1][WPL[t]]),
-                                                                      __builtin_bit_cast(bf16x8, fb[kw & 1][XPL[t]][mt]),
-                                                                      acc[mt], 0, 0, 0);
+                for (int mt = 0; mt < MT; ++mt) {
+                    f32x16& d = (t & 1) ? acc[mt] : acs[mt];
+                    d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[kw & 1][WPL[t]]),
+                                                                __builtin_bit_cast(bf16x8, fb[kw & 1][XPL[t]][mt]), d, 0, 0, 0);
+                }
             __builtin_amdgcn_sched_barrier(0);
         }
     };
+
+    // LDS-only barrier: __syncthreads() also waits for vmcnt(0), i.e. for the global prefetches in flight
+    auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
 
     gloadX(0);
     gloadW(0);
     __syncthreads();                               // zero fill + coefficient table complete
     lstoreX(0);
     lstoreW(0);
+    __builtin_amdgcn_sched_barrier(0);
     if (NG > 1) gloadW(1);
-    __syncthreads();
+    lds_barrier();
     int kb = 0, kh = 0;
     for (int g = 0; g < NG; ++g) {
-        // invariant: patch of K step kb in Xs, weight group g in buffer g&1, rw = weight group g+1
+        // invariant: patch of K step kb in Xs, weight group g in buffer g&1, rw = weight group g+1 (in flight)
         const bool more = g + 1 < NG, last_row = kh == 4;
-        if (more && !last_row) {                   // buffer (g+1)&1 was last read in group g-1: every wave is past it
-            lstoreW((g + 1) & 1);
-            if (g + 2 < NG) gloadW(g + 2);
-        }
+        // buffer (g+1)&1 was last read in group g-1: every wave is past it.  The store (which waits for the loads of
+        // rw) must stay ahead of the next loads: the scheduler would otherwise issue them first and wait for all.
+        if (more) lstoreW((g + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (g + 2 < NG) gloadW(g + 2);
         if (kh == 3 && kb + 1 < KB) gloadX(kb + 1);
+        __builtin_amdgcn_sched_barrier(0);
         compute(g & 1, kh * G::WP);
-        __syncthreads();
+        lds_barrier();
         if (more && last_row) {                    // K step change: the patch is fully consumed
             lstoreX(kb + 1);
-            lstoreW((g + 1) & 1);
-            if (g + 2 < NG) gloadW(g + 2);
-            __syncthreads();
+            lds_barrier();
         }
         if (++kh == 5) { kh = 0; ++kb; }
     }
+
+#pragma unroll
+    for (int b = 0; b < MT; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[b][r] += acs[b][r];
 
     // ---- optional BatchNorm statistics of this workgroup's tile (the loop ended with a barrier: LDS is free)
     if (p.stats) {
@@ -284,9 +303,9 @@ __global__ __launch_bounds__(256, 2) void conv5_x3_kernel(X3P p) {
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) { const float v = acc[mt][r]; s1 += v; s2 += v * v; }
-#pragma unroll
-            for (int o = 16; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
-            if (l31 == 0) {
+            s1 = half_wave_sum_hi(s1);
+            s2 = half_wave_sum_hi(s2);
+            if (l31 == JVAE_HALF_SUM_LANE) {
                 const int ch = (r & 3) + 8 * (r >> 2) + 4 * half;
                 red[(wave * 32 + ch) * 2 + 0] = s1;
                 red[(wave * 32 + ch) * 2 + 1] = s2;
