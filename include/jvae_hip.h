@@ -51,6 +51,12 @@ int jvae_splitk_fold_f32(const float* part, const float* bias, float* y, int S, 
  * wgrad: accumulate != 0 adds into dw/dbias (autograd .grad accumulation), else overwrites. */
 size_t jvae_conv2d_workspace_bytes(int N, int Cin, int H, int W, int Cout, int KH, int KW, int S, int P, int OP,
                                    int transposed);
+/* Arithmetic unit of the stride-1 5x5 layers with >= 16 input channels (forward, ConvTranspose2d forward, dgrad):
+ * mode 1 (default, JVAE_X3=0 in the environment sets 0 at start-up) = bf16 matrix cores with every fp32 operand split
+ * EXACTLY into three bf16 terms and six bf16 MFMA products per fp32 product (csrc/conv_x3.hip: fp32-accurate, error
+ * below the fp32 FMA chain's own rounding); mode 0 = v_mfma_f32_32x32x2_f32 (csrc/conv_mfma.hip).  Same tensors, same
+ * results to fp32 rounding; returns the previous mode.  Same reference ops as jvae_conv2d_fwd_f32. */
+int jvae_conv2d_set_split_bf16(int mode);
 int jvae_conv2d_out_shape(int H, int W, int KH, int KW, int S, int P, int OP, int transposed, int* OH, int* OW);
 int jvae_conv2d_fwd_f32(const float* x, const float* w, const float* bias, float* y,
                         int N, int Cin, int H, int W, int Cout, int KH, int KW, int S, int P, int OP, int transposed,

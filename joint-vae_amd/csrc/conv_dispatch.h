@@ -29,6 +29,7 @@ int jvae_conv5_pack(const float* w, float* wp, int C, int O, int swap, int flip,
 // conv_x3.hip: the same operator on the bf16 matrix cores, every fp32 operand split exactly into three bf16 terms
 bool jvae_conv5_x3_ok(int Cin, int H, int W, int Cout, int OH, int OW, int S, int P);
 size_t jvae_conv5_x3_pack_bytes(int Cin, int Cout);
+int jvae_conv5_x3_set(int mode);
 int jvae_conv5_x3_fwd(const float* in, const float* w, int swap, int flip, const float* bias, float* out,
                       int N, int Cin, int H, int W, int Cout, int OW, int S, int P, float* ws, hipStream_t st,
                       float* stats = nullptr, int* nsplit = nullptr, const InAff* aff = nullptr);

@@ -370,13 +370,24 @@ int launch_x3(const X3P& p, hipStream_t st) {
     return 0;
 }
 
-static int g_x3 = -1;        // JVAE_X3=0: keep every layer on the fp32 matrix-core kernels (A/B switch)
-
 }  // namespace
 
+static int g_x3 = -1;        // JVAE_X3=0: keep every layer on the fp32 matrix-core kernels (A/B switch)
+
 // Layers the split kernel takes over from conv_mfma.hip: stride 1, at least one full K step of input channels.
-bool jvae_conv5_x3_ok(int Cin, int H, int W, int Cout, int OH, int OW, int S, int P) {
+static void x3_init() {
     if (g_x3 < 0) { const char* e = getenv("JVAE_X3"); g_x3 = (e && e[0] == '0') ? 0 : 1; }
+}
+
+int jvae_conv5_x3_set(int mode) {
+    x3_init();
+    const int old = g_x3;
+    g_x3 = mode ? 1 : 0;
+    return old;
+}
+
+bool jvae_conv5_x3_ok(int Cin, int H, int W, int Cout, int OH, int OW, int S, int P) {
+    x3_init();
     if (!g_x3) return false;
     if (S != 1 || Cin < 16 || Cin > 256) return false;
     if (OW != 8 && OW != 16 && OW != 32 && OW != 64) return false;

@@ -81,6 +81,53 @@ def test_conv_all_directions(cin, cout, k, s, p, op, tr, H, N):
     assert rel(bd.grad, br.grad) < 2e-5
 
 
+@pytest.mark.parametrize('cin,cout,tr,H,N', [(32, 32, True, 32, 6), (32, 64, False, 16, 9), (64, 32, True, 16, 5),
+                                             (64, 64, True, 8, 7), (48, 40, False, 16, 3), (128, 64, False, 64, 1)])
+def test_split_bf16_conv_is_fp32_accurate(cin, cout, tr, H, N):
+    """conv_x3.hip computes fp32 convolutions on the bf16 matrix cores (3-way exact operand split, 6 products): measured
+    against an fp64 reference its error must be at the level of the fp32-MFMA kernel's own rounding (not bf16's 4e-3),
+    on data with a wide dynamic range, in forward (with BatchNorm partial sums) and dgrad; the two modes agree to 2e-6."""
+    from jvae_hip import lib, ops
+    L = lib.load()
+    g = torch.Generator().manual_seed(cin * 7 + cout + H)
+    x = torch.randn(N, cin, H, H, generator=g) * torch.exp(2 * torch.randn(N, cin, 1, 1, generator=g))
+    w = torch.randn((cin, cout, 5, 5) if tr else (cout, cin, 5, 5), generator=g) / math.sqrt(cin * 25)
+    b = torch.randn(cout, generator=g)
+    if tr:
+        ref = F.conv_transpose2d(x.double(), w.double(), b.double(), padding=2)
+    else:
+        ref = F.conv2d(x.double(), w.double(), b.double(), padding=2)
+    gy = torch.randn(ref.shape, generator=g)
+    if tr:
+        gref = F.conv2d(gy.double(), w.double(), padding=2)
+    else:
+        gref = F.conv_transpose2d(gy.double(), w.double(), padding=2)
+    spec = ops.ConvSpec(cin, cout, 5, 1, 2, 0, tr)
+    xd, wd, bd, gyd = x.to(DEV), w.to(DEV), b.to(DEV), gy.to(DEV)
+    out = {}
+    old = L.jvae_conv2d_set_split_bf16(1)
+    try:
+        for mode in (1, 0):
+            L.jvae_conv2d_set_split_bf16(mode)
+            y = ops.conv_fwd_raw(xd, wd, bd, spec)
+            ys = ops.conv_fwd_stats_raw(xd, wd, bd, spec)
+            dx = ops.conv_dgrad_raw(gyd, wd, spec, xd.shape)
+            y2, st, ns = ys
+            assert torch.equal(y, y2)
+            if st is not None:        # BatchNorm partial sums of (y - bias) from the kernel epilogue (DPP reductions)
+                part = st[:cout * ns * 2].view(cout, ns, 2).double().sum(1).cpu()
+                yc = (y.double().cpu() - b.double().view(1, -1, 1, 1))
+                assert float((part[:, 0] - yc.sum((0, 2, 3))).abs().max() / yc.abs().sum((0, 2, 3)).max()) < 1e-5
+                assert float((part[:, 1] - (yc * yc).sum((0, 2, 3))).abs().max() / (yc * yc).sum((0, 2, 3)).max()) < 1e-5
+            out[mode] = (rel(y, ref), rel(dx, gref), y, dx)
+    finally:
+        L.jvae_conv2d_set_split_bf16(old)
+    assert out[1][0] < 1e-6 and out[1][1] < 1e-6, out[1][:2]          # split bf16: measured 2e-7 .. 6e-7
+    assert out[0][0] < 5e-6 and out[0][1] < 5e-6, out[0][:2]          # fp32 MFMA (k-ordered fmaf chain): up to 1.5e-6
+    assert out[1][0] < 2 * out[0][0] + 1e-7 and out[1][1] < 2 * out[0][1] + 1e-7, (out[1][:2], out[0][:2])
+    assert rel(out[1][2], out[0][2]) < 2e-6 and rel(out[1][3], out[0][3]) < 2e-6
+
+
 @pytest.mark.parametrize('N,C,P,relu', [(8, 32, 1024, True), (5, 3, 1024, False), (16, 200, 4, True), (2, 64, 63, True)])
 def test_batchnorm_train(N, C, P, relu):
     from jvae_hip import ops
