@@ -10,7 +10,7 @@ from ctypes import c_char_p, c_float, c_int, c_long, c_size_t, c_void_p, POINTER
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libjvae_hip.so')
+LIB_PATH = os.environ.get('JVAE_HIP_LIB') or os.path.join(_HERE, 'libjvae_hip.so')      # JVAE_HIP_LIB: A/B builds
 
 _lib = None
 
