@@ -285,6 +285,25 @@ int jvae_adam_step_dev_f32(float* p, const float* g, float* m, float* v, long n,
                            float eps, float weight_decay, float max_norm, const float* sqnorm, int* nonfinite_flag,
                            void* stream);
 
+/* torch.optim.SGD (module/optimizers.py:39-40; momentum / nesterov / weight_decay, dampening 0) with the same fused
+ * clip coefficient and NaN/Inf flag as the Adam entry points; buf = momentum buffer (may be NULL when momentum == 0),
+ * first_step != 0 initialises it with the gradient as torch does. */
+int jvae_sgd_step_f32(float* p, const float* g, float* buf, long n, float lr, float momentum, int nesterov,
+                      float weight_decay, int first_step, float max_norm, const float* sqnorm, int* nonfinite_flag,
+                      void* stream);
+
+/* ---- MaxPool2d / AvgPool2d / UpsamplingNearest2d: tokens M, A, U of the layer DSL (module/vae_layers/conv.py:201-212;
+ * conv-models.ini:13-18,28-30).  Tensors are (planes = N*C, H, W) fp32.  mode 0 = max (idx: int32 (planes, OH, OW), flat
+ * h*W + w of the first maximum, as nn.MaxPool2d's return_indices), 1 = average with count_include_pad (divisor K*K).
+ * OH = (H + 2P - K)/S + 1.  Up-sampling by an integer factor: y (planes, H*scale, W*scale). */
+int jvae_pool2d_out_shape(int H, int W, int K, int S, int P, int* OH, int* OW);
+int jvae_pool2d_fwd_f32(const float* x, float* y, int* idx, long planes, int H, int W, int K, int S, int P, int mode,
+                        void* stream);
+int jvae_pool2d_bwd_f32(const float* dy, const int* idx, float* dx, long planes, int H, int W, int K, int S, int P,
+                        int mode, void* stream);
+int jvae_upsample_nearest_fwd_f32(const float* x, float* y, long planes, int H, int W, int scale, void* stream);
+int jvae_upsample_nearest_bwd_f32(const float* dy, float* dx, long planes, int H, int W, int scale, void* stream);
+
 /* ---- input pipeline in front of the path: uint8 batch (NHWC if nhwc else NCHW) -> horizontal flip
  * where flip[n] != 0 -> edge padding by `pad` + crop at offsets (dy[n], dx[n]) in [0, 2*pad] -> float32 NCHW / 255.
  * Replaces RandomHorizontalFlip + RandomCrop(padding_mode='edge') + ToTensor of utils/torch_load.py:405-426.

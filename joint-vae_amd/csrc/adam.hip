@@ -91,6 +91,29 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamP a) {
     if (a.flag && __any(bad) && (threadIdx.x & 63) == 0) atomicOr(a.flag, 1);
 }
 
+// torch.optim.SGD (module/optimizers.py:39-40): g' = coef*g + wd*p; buf = first ? g' : mu*buf + g' (dampening 0);
+// d = nesterov ? g' + mu*buf : buf (d = g' when mu == 0); p -= lr*d
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
+                                                  long n, float lr, float mu, int nesterov, float wd, int first,
+                                                  float max_norm, const float* __restrict__ sqnorm, int* __restrict__ flag) {
+    float coef = 1.f;
+    if (max_norm > 0.f && sqnorm) coef = fminf(1.f, max_norm / (sqrtf(sqnorm[0]) + 1e-6f));
+    bool bad = false;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float pi = p[i];
+        float d = fmaf(wd, pi, coef * g[i]);
+        if (mu != 0.f) {
+            const float b = first ? d : fmaf(mu, buf[i], d);
+            buf[i] = b;
+            d = nesterov ? fmaf(mu, b, d) : b;
+        }
+        const float pn = pi - lr * d;
+        p[i] = pn;
+        bad |= !isfinite(pn);
+    }
+    if (flag && __any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
 // g *= min(1, max_norm / (sqrt(sqnorm) + 1e-6))   (what clip_grad_norm_ leaves in .grad)
 __global__ __launch_bounds__(256) void clip_scale_kernel(float* g, long n, const float* sqnorm, float max_norm) {
     const float coef = fminf(1.f, max_norm / (sqrtf(sqnorm[0]) + 1e-6f));
@@ -182,6 +205,18 @@ int jvae_adam_step_dev_f32(float* p, const float* g, float* m, float* v, long n,
     a.eps = eps; a.wd = weight_decay; a.max_norm = max_norm;
     a.sqnorm = sqnorm; a.flag = nonfinite_flag; a.hyper = hyper;
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4)), dim3(256), 0, st, a);
+    JVAE_LAUNCH_CHECK();
+    return 0;
+}
+
+int jvae_sgd_step_f32(float* p, const float* g, float* buf, long n, float lr, float momentum, int nesterov,
+                      float weight_decay, int first_step, float max_norm, const float* sqnorm, int* nonfinite_flag,
+                      void* stream) {
+    if (n < 0 || momentum < 0.f || (nesterov && momentum <= 0.f)) return JVAE_EINVAL;
+    if (n == 0) return 0;
+    if (!p || !g || (momentum != 0.f && !buf)) return JVAE_EINVAL;
+    hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, buf, n, lr, momentum, nesterov,
+                       weight_decay, first_step, max_norm, sqnorm, nonfinite_flag);
     JVAE_LAUNCH_CHECK();
     return 0;
 }

@@ -76,6 +76,12 @@ _SIGS = {
     'jvae_clip_scale_f32': (c_int, [P, c_long, P, c_float, P]),
     'jvae_adam_step_dev_f32': (c_int, [P, P, P, P, c_long, P, c_int, c_float, c_float, c_float, P, P, P]),
     'jvae_adam_step_f32': (c_int, [P, P, P, P, c_long] + [c_float] * 5 + [c_long, c_float, P, P, P]),
+    'jvae_sgd_step_f32': (c_int, [P, P, P, c_long, c_float, c_float, c_int, c_float, c_int, c_float, P, P, P]),
+    'jvae_pool2d_out_shape': (c_int, [c_int] * 5 + [POINTER(c_int), POINTER(c_int)]),
+    'jvae_pool2d_fwd_f32': (c_int, [P, P, P, c_long] + [c_int] * 6 + [P]),
+    'jvae_pool2d_bwd_f32': (c_int, [P, P, P, c_long] + [c_int] * 6 + [P]),
+    'jvae_upsample_nearest_fwd_f32': (c_int, [P, P, c_long, c_int, c_int, c_int, P]),
+    'jvae_upsample_nearest_bwd_f32': (c_int, [P, P, c_long, c_int, c_int, c_int, P]),
 }
 
 

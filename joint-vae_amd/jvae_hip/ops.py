@@ -543,6 +543,69 @@ def act(x, kind):
     return _Act.apply(x, kind)
 
 
+# ------------------------------------------------------------------------------- pooling / up-sampling
+POOL_MAX, POOL_AVG = 0, 1
+
+
+class _Pool2d(torch.autograd.Function):
+    """nn.MaxPool2d / nn.AvgPool2d of the layer DSL (tokens M / A; reference module/vae_layers/conv.py:201-206)."""
+
+    @staticmethod
+    def forward(ctx, x, K, S, P, mode):
+        lib = L.load()
+        x = _c(_f32(x, 'pool2d'))
+        N, C, H, W = x.shape
+        oh, ow = c_int(0), c_int(0)
+        L.check(lib.jvae_pool2d_out_shape(H, W, K, S, P, byref(oh), byref(ow)), 'pool2d_out_shape')
+        y = torch.empty((N, C, oh.value, ow.value), device=x.device, dtype=torch.float32)
+        idx = torch.empty((N, C, oh.value, ow.value), device=x.device, dtype=torch.int32) if mode == POOL_MAX else None
+        L.check(lib.jvae_pool2d_fwd_f32(L.ptr(x), L.ptr(y), L.ptr(idx), N * C, H, W, K, S, P, mode, L.stream_ptr()), 'pool2d_fwd')
+        ctx.save_for_backward(idx)
+        ctx.cfg = (N, C, H, W, K, S, P, mode)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        idx, = ctx.saved_tensors
+        N, C, H, W, K, S, P, mode = ctx.cfg
+        gy = _c(gy)
+        gx = torch.empty((N, C, H, W), device=gy.device, dtype=torch.float32)
+        L.check(L.load().jvae_pool2d_bwd_f32(L.ptr(gy), L.ptr(idx), L.ptr(gx), N * C, H, W, K, S, P, mode, L.stream_ptr()),
+                'pool2d_bwd')
+        return gx, None, None, None, None
+
+
+def pool2d(x, kernel_size, stride=None, padding=0, mode=POOL_MAX):
+    return _Pool2d.apply(x, int(kernel_size), int(stride or kernel_size), int(padding), mode)
+
+
+class _UpsampleNearest(torch.autograd.Function):
+    """nn.UpsamplingNearest2d(scale_factor=int) (token U; reference module/vae_layers/conv.py:208-212)."""
+
+    @staticmethod
+    def forward(ctx, x, scale):
+        x = _c(_f32(x, 'upsample_nearest'))
+        N, C, H, W = x.shape
+        y = torch.empty((N, C, H * scale, W * scale), device=x.device, dtype=torch.float32)
+        L.check(L.load().jvae_upsample_nearest_fwd_f32(L.ptr(x), L.ptr(y), N * C, H, W, scale, L.stream_ptr()), 'upsample_fwd')
+        ctx.cfg = (N, C, H, W, scale)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        N, C, H, W, scale = ctx.cfg
+        gy = _c(gy)
+        gx = torch.empty((N, C, H, W), device=gy.device, dtype=torch.float32)
+        L.check(L.load().jvae_upsample_nearest_bwd_f32(L.ptr(gy), L.ptr(gx), N * C, H, W, scale, L.stream_ptr()), 'upsample_bwd')
+        return gx, None
+
+
+def upsample_nearest(x, scale):
+    if int(scale) != scale or scale < 1:
+        raise L.JvaeHipError('nearest up-sampling is built for integer scale factors')
+    return _UpsampleNearest.apply(x, int(scale))
+
+
 # ------------------------------------------------------------------------------------------- latent
 PRIOR_KIND = {'gaussian': 0, 'tilted': 1, 'uniform': 2}
 VAR_KIND = {'scalar': 0, 'diag': 1, 'full': 2}
@@ -758,6 +821,13 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, max_norm=0.
     rc = L.load().jvae_adam_step_f32(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), p.numel(), lr, beta1, beta2, eps,
                                      weight_decay, step, float(max_norm or 0.), L.ptr(sqnorm), L.ptr(flag), L.stream_ptr())
     L.check(rc, 'jvae_adam_step_f32')
+
+
+def sgd_step(p, g, buf, lr, momentum, nesterov, weight_decay, first, max_norm=0., sqnorm=None, flag=None):
+    """torch.optim.SGD update of one flat buffer (clip coefficient and NaN/Inf flag fused as for Adam)."""
+    L.check(L.load().jvae_sgd_step_f32(L.ptr(p), L.ptr(g), L.ptr(buf), p.numel(), float(lr), float(momentum), int(bool(nesterov)),
+                                      float(weight_decay), int(bool(first)), float(max_norm or 0.), L.ptr(sqnorm), L.ptr(flag),
+                                      L.stream_ptr()), 'jvae_sgd_step_f32')
 
 
 def adam_step_dev(p, g, m, v, hyper, advance, eps, weight_decay, max_norm=0., sqnorm=None, flag=None):

@@ -2,7 +2,7 @@
 
     mse_loss(x_output, x_target, ndim, batch_mean)        reconstruction mean-square over the image dims
     x_loss(y_target, logits, batch_mean)                  cross entropy of the L(+1) sampled logits
-    categorical_loss(...)                                  256-way pixel cross entropy (not in the native contract)
+    categorical_loss(x_output, x_target, ndim, batch_mean) 256-way pixel cross entropy, summed over the image
 """
 import torch
 
@@ -46,4 +46,18 @@ def x_loss(y_target, logits, batch_mean=True):
 
 
 def categorical_loss(x_output, x_target, ndim=3, batch_mean=True):
-    raise NotImplementedError('categorical (256-way) output distribution is outside the native-kernel contract')
+    """256-way pixel cross entropy (reference module/losses.py:30-49): x_target (N1..Ng, D1..Dt) in [0, 1],
+    x_output (N1..Ng, 256, D1..Dt) logits with the class axis in front of the image axes (the `Reshape((256, C, h, w))`
+    at the end of a categorical decoder, conv.py:228-230); target class = floor(255 x).  Sum over the image, per sample.
+    The cross-entropy rows run on the HIP kernel (class axis moved last by a permuted copy)."""
+    expanded_shape = (*x_output.shape[:-ndim - 1], *x_target.shape[-ndim:])
+    x_target = x_target.expand(*expanded_shape)
+    batch_shape = x_target.shape[:-ndim]
+    image_shape = x_target.shape[-ndim:]
+    pixels = 1
+    for s_ in image_shape:
+        pixels *= s_
+    target = (x_target * 255).long().reshape(-1)
+    logits = x_output.reshape(-1, 256, pixels).permute(0, 2, 1).reshape(1, -1, 256)
+    ce = ops.cross_entropy_rows(logits, target).reshape(*batch_shape, pixels).sum(-1)
+    return ce.mean() if batch_mean else ce

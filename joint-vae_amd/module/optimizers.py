@@ -73,8 +73,10 @@ class Optimizer:
 
     def __init__(self, parameters, optim_type='adam', lr=0, lr_decay=0, weight_decay=0, grad_clipping=None,
                  epoch=0, **kw):
-        if optim_type != 'adam':
-            raise NotImplementedError("only optim_type='adam' is built on the native kernels (got {!r})".format(optim_type))
+        if optim_type not in ('adam', 'sgd'):
+            raise ValueError("optim_type must be 'adam' or 'sgd' (got {!r})".format(optim_type))
+        if optim_type == 'sgd' and kw.get('dampening'):
+            raise NotImplementedError('SGD dampening is outside the native-kernel contract')
         if kw.get('amsgrad'):
             raise NotImplementedError('amsgrad is outside the native-kernel contract')
         self.kind = optim_type
@@ -88,6 +90,8 @@ class Optimizer:
         self.weight_decay = weight_decay
         self.betas = tuple(kw.get('betas', (0.9, 0.999)))
         self.eps = kw.get('eps', 1e-8)
+        self.momentum = float(kw.get('momentum', 0.))          # optim_type='sgd' (module/optimizers.py:39-40 of the reference)
+        self.nesterov = bool(kw.get('nesterov', False))
         self._lr = lr
         self._epochs_decayed = 0
         self._all = [p for p in parameters]
@@ -304,6 +308,12 @@ class Optimizer:
         clip = self.grad_clipping if self._clip_pending else 0.
         for g in self._groups:
             g.step += 1
+            if self.kind == 'sgd':
+                # the momentum buffer lives in g.m; the first step initialises it with the gradient, as torch does
+                ops.sgd_step(g.p, g.g, g.m if self.momentum else None, self._lr, self.momentum, self.nesterov,
+                             self.weight_decay, g.step == 1, max_norm=clip, sqnorm=self._sqnorm if clip else None,
+                             flag=self._flag)
+                continue
             if getattr(self, '_device_hyper', False):
                 # step count / lr / betas live in a device block (capturable into a HIP graph, see enable_device_hyper)
                 if getattr(g, 'hyper', None) is None or g.hyper.device != dev:
@@ -343,6 +353,15 @@ class Optimizer:
     def state_dict(self, *a, **k):
         index = {id(p): i for i, p in enumerate(self._all)}
         state = {}
+        if self.kind == 'sgd':                     # torch.optim.SGD layout
+            for g in self._groups:
+                for j, p in enumerate(g.params):
+                    buf = g.view(g.m, j).detach().clone() if self.momentum and g.step > 0 else None
+                    state[index[id(p)]] = {'momentum_buffer': buf}
+            group = {'lr': self._lr, 'momentum': self.momentum, 'dampening': 0, 'weight_decay': self.weight_decay,
+                     'nesterov': self.nesterov, 'maximize': False, 'foreach': None, 'differentiable': False, 'fused': None,
+                     'initial_lr': self.init_lr, 'params': list(range(len(self._all)))}
+            return {'state': state, 'param_groups': [group]}
         for g in self._groups:
             for j, p in enumerate(g.params):
                 state[index[id(p)]] = {'step': torch.tensor(float(g.step)),
@@ -360,6 +379,21 @@ class Optimizer:
         self.betas = tuple(pg.get('betas', self.betas))
         self.eps = pg.get('eps', self.eps)
         self.weight_decay = pg.get('weight_decay', self.weight_decay)
+        if self.kind == 'sgd':
+            self.momentum = float(pg.get('momentum', self.momentum))
+            self.nesterov = bool(pg.get('nesterov', self.nesterov))
+            idxs = sorted(int(i) for i, st in sd['state'].items() if st.get('momentum_buffer') is not None)
+            self._groups = []
+            if idxs:
+                ps = [self._all[i] for i in idxs]
+                if ps[0].device.type != 'cuda':
+                    raise NotImplementedError('load the SGD state after the model has been moved to the GPU')
+                g = _FlatGroup(ps, ps[0].device, 1)            # step >= 1: the buffers are initialised
+                with torch.no_grad():
+                    for j, i in enumerate(idxs):
+                        g.view(g.m, j).copy_(sd['state'][i]['momentum_buffer'].to(ps[0].device))
+                self._groups.append(g)
+            return
         by_step = {}
         for idx, st in sd['state'].items():
             by_step.setdefault(int(float(st['step'])), []).append(int(idx))
@@ -397,7 +431,8 @@ class Optimizer:
             parts.append(f'decay={self.lr_decay}')
         else:
             level -= 1
-        shown = {'betas': self.betas, 'weight_decay': self.weight_decay, 'amsgrad': False}
+        shown = {'betas': self.betas, 'weight_decay': self.weight_decay, 'amsgrad': False, 'momentum': self.momentum,
+                 'nesterov': self.nesterov}
         extra = [f'{k}={shown[k]}' for k in params_by_type[self.kind] if shown[k] and not isinstance(shown[k], bool)]
         if extra:
             parts.append('--'.join(extra))

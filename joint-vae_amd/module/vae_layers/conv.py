@@ -84,7 +84,43 @@ def conv_layer_name(conv_layer):
         if s != 1:
             tok += f':{s}'
         return tok
+    if isinstance(conv_layer, HipPool2d):
+        tok = '{}x{}'.format(conv_layer.letter, conv_layer.kernel_size)
+        if conv_layer.stride != conv_layer.kernel_size:
+            tok += ':{}'.format(conv_layer.stride)
+        return tok
+    if isinstance(conv_layer, HipUpsamplingNearest2d):
+        return 'u:{}'.format(conv_layer.scale_factor)
     raise NotImplementedError(type(conv_layer).__name__)
+
+
+class HipPool2d(nn.Module):
+    """nn.MaxPool2d / nn.AvgPool2d of the layer DSL (tokens `M` / `A`, reference conv.py:201-206) on the HIP kernels."""
+
+    def __init__(self, letter, kernel_size, stride=None, padding=0):
+        super().__init__()
+        self.letter = letter.upper()
+        self.kernel_size, self.stride, self.padding = int(kernel_size), int(stride or kernel_size), int(padding)
+
+    def forward(self, x):
+        return ops.pool2d(x, self.kernel_size, self.stride, self.padding, ops.POOL_MAX if self.letter == 'M' else ops.POOL_AVG)
+
+    def extra_repr(self):
+        return f'{self.letter}: kernel_size={self.kernel_size}, stride={self.stride}, padding={self.padding}'
+
+
+class HipUpsamplingNearest2d(nn.Module):
+    """nn.UpsamplingNearest2d(scale_factor) of the layer DSL (token `U`, reference conv.py:208-212)."""
+
+    def __init__(self, scale_factor):
+        super().__init__()
+        self.scale_factor = scale_factor
+
+    def forward(self, x):
+        return ops.upsample_nearest(x, self.scale_factor)
+
+    def extra_repr(self):
+        return f'scale_factor={self.scale_factor}'
 
 
 class HipConv2d(nn.Conv2d):
@@ -289,9 +325,22 @@ def build_de_conv_layers(input_shape, layers_name, batch_norm=False, where='inpu
         kind = parse_conv_layer_name(tok, where=where)['ltype']
         p = parse_conv_layer_name(tok, **defaults.get(kind, {}), where=where)
         kind = p.pop('ltype')
+        if kind.endswith('pooling') or kind == 'upsampler':
+            # no parameters, no BatchNorm / activation behind them (reference conv.py:201-222)
+            if kind == 'upsampler':
+                layer = HipUpsamplingNearest2d(p['stride'])
+                h, w = int(h * p['stride']), int(w * p['stride'])
+            else:
+                k, pad = p['kernel_size'], p['padding']
+                s = p['stride'] or k
+                layer = HipPool2d(kind[0], k, s, pad)
+                h, w = (h + 2 * pad - k) // s + 1, (w + 2 * pad - k) // s + 1
+            modules.append(layer)
+            tokens.append(conv_layer_name(layer))
+            shapes.append((channels, h, w))
+            continue
         if kind not in ('conv', 'deconv'):
-            raise NotImplementedError(f'layer token {tok!r} ({kind}) is outside the native-kernel contract '
-                                      '(only convolutions and transposed convolutions are built)')
+            raise NotImplementedError(f'layer token {tok!r} ({kind}) is outside the native-kernel contract')
         if where == 'output' and n == len(toks) - 1 and output_distribution == 'categorical':
             p['out_channels'] *= 256
         k, pad, s = p['kernel_size'], p['padding'], p['stride']

@@ -84,8 +84,18 @@ def test_layer_dsl_shapes():
     assert p == dict(ltype='conv', kernel_size=5, padding=2, stride=1, out_channels=3)
     anon = build_de_conv_layers((3, 32, 32), '[x5+2]16-16:2')
     assert anon.name == '16x5-16x5:2'
+    # pooling / up-sampling tokens (vgg*, ivgg*: conv-models.ini:13-18,28-30): shapes and names as in the reference
+    v = build_de_conv_layers((3, 32, 32), 'vgg11')
+    assert v.name == 'vgg11' and tuple(v.output_shape) == (512, 1, 1)
+    assert [type(m).__name__ for m in list(v)[:3]] == ['HipConv2d', 'HipReLU', 'HipPool2d'] or \
+        [type(m).__name__ for m in list(v)[:3]][0::2] == ['HipConv2d', 'HipPool2d']
+    assert v.shapes[:3] == [(3, 32, 32), (64, 32, 32), (64, 16, 16)] and v.shapes[-1] == (512, 1, 1)
+    u = build_de_conv_layers((8, 2, 2), '[!x3+1-U:2]U-!4-U-!3', where='output')
+    assert tuple(u.output_shape) == (3, 8, 8) and u.name == 'u:2-4x3-u:2-3x3'
+    anon = build_de_conv_layers((3, 8, 8), '[x3-Mx2]4-M-Ax2')
+    assert anon.name == '4x3-Mx2-Ax2' and tuple(anon.output_shape) == (4, 2, 2)
     with pytest.raises(NotImplementedError):
-        build_de_conv_layers((3, 32, 32), 'vgg11')
+        build_de_conv_layers((3, 32, 32), 'resnet18')
 
 
 @pytest.mark.parametrize('name', list(CASES))
@@ -129,5 +139,7 @@ def test_sigma_and_optimizer_host_api():
     assert f'{o:10}' == 'adam--lr=0.001--decay=0.01--betas=(0.9, 0.999)--weight_decay=3e-05'
     o.update_lr()
     assert abs(o.lr - 1e-3 * 0.99) < 1e-12
-    with pytest.raises(NotImplementedError):
-        Optimizer([p], optim_type='sgd')
+    sgd = Optimizer([p], optim_type='sgd', momentum=0.9, weight_decay=1e-4)
+    assert sgd.lr == 0.01 and f'{sgd:10}' == 'sgd--lr=0.01--momentum=0.9--weight_decay=0.0001'
+    with pytest.raises(ValueError):
+        Optimizer([p], optim_type='rmsprop')

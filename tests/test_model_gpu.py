@@ -378,3 +378,52 @@ def test_graph_captured_training_step():
     with torch.no_grad():
         _, _, l_eval, _ = net.evaluate(x, y, with_beta=True)
     assert float(l_eval['total'].mean()) < first
+
+
+@pytest.mark.parametrize('where,spec,shape', [('input', '[x3-Mx2]8-M-16-A-Ax1', (3, 16, 16)),
+                                              ('output', '[!x3+1-U:2]U-!8-U-!3', (4, 4, 4))])
+@pytest.mark.parametrize('bn', [False, True])
+def test_pooling_and_upsampling_stacks_match_torch(where, spec, shape, bn):
+    """vgg-style (`M`, `A`) and ivgg-style (`U`, `!C`) layer strings (conv-models.ini:13-18,28-30) build and run on the
+    HIP kernels: forward / backward against the same stack made of stock torch modules with the same state_dict."""
+    import torch.nn as nn
+    from module.vae_layers.conv import build_de_conv_layers
+    torch.manual_seed(3)
+    net = build_de_conv_layers(shape, spec, batch_norm=bn, where=where, output_activation='sigmoid').to('cuda')
+    mods = []
+    for m in net:
+        n = type(m).__name__
+        if isinstance(m, nn.Conv2d):
+            mods.append(nn.Conv2d(m.in_channels, m.out_channels, m.kernel_size, m.stride, m.padding))
+        elif isinstance(m, nn.BatchNorm2d):
+            mods.append(nn.BatchNorm2d(m.num_features))
+        elif n == 'HipPool2d':
+            mods.append((nn.MaxPool2d if m.letter == 'M' else nn.AvgPool2d)(m.kernel_size, m.stride, m.padding))
+        elif n == 'HipUpsamplingNearest2d':
+            mods.append(nn.UpsamplingNearest2d(scale_factor=m.scale_factor))
+        elif 'sigmoid' in n.lower():
+            mods.append(nn.Sigmoid())
+        elif 'relu' in n.lower():
+            mods.append(nn.ReLU())
+        else:
+            mods.append(nn.Identity())
+    ref = nn.Sequential(*mods)
+    ref.load_state_dict({k: v.cpu() for k, v in net.state_dict().items()})
+    assert net.output_shape[1:] == tuple(ref(torch.zeros(2, *shape)).shape[2:])
+    x = torch.randn(6, *shape)
+    xr = x.clone().requires_grad_(True)
+    yr = ref(xr)
+    gy = torch.randn(yr.shape)
+    yr.backward(gy)
+    xd = x.cuda().requires_grad_(True)
+    yd = net(xd)
+    assert yd.shape == yr.shape
+    yd.backward(gy.cuda())
+    rel = lambda a, b: float((a.detach().cpu() - b.detach()).abs().max() / b.detach().abs().max())
+    assert rel(yd, yr) < 2e-5 and rel(xd.grad, xr.grad) < 1e-4
+    for (k, p), q in zip(net.named_parameters(), ref.parameters()):
+        if bn and k.endswith('bias') and q.grad.abs().max() < 1e-4:
+            # a conv bias in front of a train-mode BatchNorm: exact zero here, rounding noise in torch (DESIGN.md section 2)
+            assert float(p.grad.abs().max()) < 1e-4, k
+            continue
+        assert rel(p.grad, q.grad) < 2e-4, k

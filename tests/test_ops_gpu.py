@@ -402,3 +402,99 @@ def test_input_pipeline_bit_exact(N, H, C, pad):
     assert np.array_equal(ident.cpu().numpy(), imgs.transpose(0, 3, 1, 2).astype(np.float32) / np.float32(255))
     f, a, b = ops.draw_augmentation(N, pad, torch.device(DEV))
     assert f.shape == (N,) and int(a.max()) <= 2 * pad and int(b.min()) >= 0
+
+
+@pytest.mark.parametrize('mode,K,S,P,H,W', [('max', 2, 2, 0, 32, 32), ('max', 3, 2, 1, 17, 13), ('avg', 2, 2, 0, 16, 16),
+                                            ('avg', 3, 1, 1, 9, 11), ('avg', 1, 1, 0, 1, 1), ('max', 2, 2, 0, 5, 7)])
+def test_pool2d(mode, K, S, P, H, W):
+    """Tokens M / A of the layer DSL (reference conv.py:201-206): nn.MaxPool2d / nn.AvgPool2d forward and backward,
+    bit-exact (max: values and routing; avg: same divisor and summation order up to 1 ulp)."""
+    from jvae_hip import ops
+    g = torch.Generator().manual_seed(K * 100 + S * 10 + P + H)
+    x = torch.randn(3, 5, H, W, generator=g)
+    x[0, 0, 0, :2] = 1.5                                  # a tie: the first maximum wins
+    xr = x.clone().requires_grad_(True)
+    f = F.max_pool2d if mode == 'max' else F.avg_pool2d
+    yr = f(xr, K, S, P)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    xd = x.to(DEV).requires_grad_(True)
+    yd = ops.pool2d(xd, K, S, P, ops.POOL_MAX if mode == 'max' else ops.POOL_AVG)
+    assert yd.shape == yr.shape
+    yd.backward(gy.to(DEV))
+    if mode == 'max':
+        assert torch.equal(yd.detach().cpu(), yr.detach()) and torch.equal(xd.grad.cpu(), xr.grad)
+    else:
+        assert rel(yd, yr) < 1e-6 and rel(xd.grad, xr.grad) < 1e-6
+
+
+@pytest.mark.parametrize('scale,H,W', [(2, 4, 4), (2, 16, 16), (3, 5, 7)])
+def test_upsample_nearest(scale, H, W):
+    """Token U (reference conv.py:208-212): nn.UpsamplingNearest2d forward (a copy) and backward (block sums)."""
+    from jvae_hip import ops
+    g = torch.Generator().manual_seed(scale + H)
+    x = torch.randn(2, 6, H, W, generator=g)
+    xr = x.clone().requires_grad_(True)
+    yr = F.interpolate(xr, scale_factor=scale, mode='nearest')
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    xd = x.to(DEV).requires_grad_(True)
+    yd = ops.upsample_nearest(xd, scale)
+    yd.backward(gy.to(DEV))
+    assert torch.equal(yd.detach().cpu(), yr.detach())
+    assert rel(xd.grad, xr.grad) < 1e-6
+
+
+@pytest.mark.parametrize('momentum,nesterov,wd', [(0., False, 0.), (0.9, False, 3e-5), (0.9, True, 1e-4)])
+def test_sgd_matches_torch(momentum, nesterov, wd):
+    """Optimizer(optim_type='sgd') (reference optimizers.py:39-40 -> torch.optim.SGD) with clip_grad_norm_, 4 steps."""
+    from module.optimizers import Optimizer
+    g = torch.Generator().manual_seed(5)
+    shapes = [(7, 5), (3,), (2, 3, 5, 5)]
+    init = [torch.randn(s, generator=g) for s in shapes]
+    ref = [torch.nn.Parameter(t.clone()) for t in init]
+    dev = [torch.nn.Parameter(t.clone().to(DEV)) for t in init]
+    kw = dict(momentum=momentum, nesterov=nesterov) if momentum else {}
+    topt = torch.optim.SGD(ref, lr=0.05, weight_decay=wd, **kw)
+    opt = Optimizer(dev, optim_type='sgd', lr=0.05, weight_decay=wd, grad_clipping=1.5, **kw)
+    for step in range(4):
+        grads = [torch.randn(s, generator=g) * (3. if step == 1 else 0.2) for s in shapes]
+        topt.zero_grad()
+        opt.zero_grad()
+        for p, q, gr in zip(ref, dev, grads):
+            p.grad = gr.clone()
+            if q.grad is None:
+                q.grad = gr.clone().to(DEV)
+            else:
+                q.grad.copy_(gr.to(DEV))
+        torch.nn.utils.clip_grad_norm_(ref, 1.5)
+        topt.step()
+        opt.clip()
+        opt.step()
+        for p, q in zip(ref, dev):
+            assert rel(q, p) < 2e-6, step
+    sd = opt.state_dict()
+    assert set(sd['param_groups'][0]) >= {'lr', 'momentum', 'dampening', 'weight_decay', 'nesterov', 'params'}
+    if momentum:
+        for i, p in enumerate(ref):
+            assert rel(sd['state'][i]['momentum_buffer'], topt.state[p]['momentum_buffer']) < 2e-6
+
+
+def test_categorical_loss():
+    """module/losses.py:30-49 of the reference: 256-way pixel cross entropy summed over the image, with gradient."""
+    from module.losses import categorical_loss
+    g = torch.Generator().manual_seed(11)
+    L_, N, C, H, W = 2, 3, 3, 4, 5
+    x = torch.rand(N, C, H, W, generator=g)
+    out = torch.randn(L_, N, 256, C, H, W, generator=g)
+    ref_in = out.clone().requires_grad_(True)
+    tgt = (x.expand(L_, N, C, H, W) * 255).long().view(-1, C, H, W)
+    ref = F.cross_entropy(ref_in.view(-1, 256, C, H, W), tgt, reduction='none').view(L_, N, -1).sum(-1)
+    gy = torch.randn(L_, N, generator=g)
+    ref.backward(gy)
+    od = out.to(DEV).requires_grad_(True)
+    got = categorical_loss(od, x.to(DEV), ndim=3, batch_mean=False)
+    assert got.shape == ref.shape and rel(got, ref) < 2e-6
+    got.backward(gy.to(DEV))
+    assert rel(od.grad, ref_in.grad) < 2e-5
+    assert abs(float(categorical_loss(od.detach(), x.to(DEV))) - float(ref.mean())) < 1e-3
