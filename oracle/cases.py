@@ -86,7 +86,21 @@ WIM_CASES = {
 }
 
 
+# Layer-DSL tokens outside conv32 / deconv32 (SURVEY.md §8b "accept" list): max / average pooling (`M`, `A`: vgg*-style
+# features), nearest up-sampling with plain convolutions (`U`, `!C`: ivgg*-style upsampler) and optim_type='sgd'.
+# Pinned by the reference directly (tests/test_model_gpu.py); the CPU oracle restates only the conv / deconv tokens.
+DSL_CASES = {
+    'v2_n6_vgg_sgd': dict(net=_conv(10, K=16, input_shape=(3, 16, 16), features='[x3-Mx2]8-M-16-Ax2-32-M-Ax1',
+                                    upsampler='[!x3+1-U:2]U-!16-U-!8-U-!3',
+                                    optimizer=dict(optim_type='sgd', lr=0.05, weight_decay=1e-4, grad_clipping=100,
+                                                   momentum=0.9)),
+                          N=6, kl_var_weighting=1.0, gamma_weighting=1.0),
+}
+
+
 def get_case(name):
+    if name in DSL_CASES:
+        return copy.deepcopy(DSL_CASES[name])
     if name in WIM_CASES:
         return copy.deepcopy(WIM_CASES[name])
     return copy.deepcopy(CASES[name] if name in CASES else EVAL_CASES[name])

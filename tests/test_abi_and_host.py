@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from oracle.cases import CASES, get_case
+from oracle.cases import CASES, DSL_CASES, get_case
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -98,7 +98,7 @@ def test_layer_dsl_shapes():
         build_de_conv_layers((3, 32, 32), 'resnet18')
 
 
-@pytest.mark.parametrize('name', list(CASES))
+@pytest.mark.parametrize('name', list(CASES) + list(DSL_CASES))
 def test_state_dict_contract(name, golden_dir):
     """Same keys, order and shapes as the reference model (checkpoint round-trip)."""
     from cvae import ClassificationVariationalNetwork as Net

@@ -10,7 +10,7 @@ import pytest
 import torch
 
 from oracle import jvae_oracle as O
-from oracle.cases import CASES, get_case, full_config
+from oracle.cases import CASES, DSL_CASES, get_case, full_config
 from oracle.det_init import det_inputs, load_det_state
 
 pytestmark = pytest.mark.gpu
@@ -40,7 +40,7 @@ def build(case):
     return net
 
 
-@pytest.mark.parametrize('name', list(CASES))
+@pytest.mark.parametrize('name', list(CASES) + list(DSL_CASES))
 def test_train_step_matches_reference_golden(name, golden_dir):
     g = np.load(os.path.join(golden_dir, name + '.npz'))
     case = get_case(name)
