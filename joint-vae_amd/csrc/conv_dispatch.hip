@@ -24,6 +24,7 @@ inline bool fold_bwd_fast_s2(const ConvGeom& g) {
 }
 inline int run_t2(const ConvGeom& g, const float* small, const float* w, const float* bias, float* big, float* ws,
                   hipStream_t st) {
+    if (jvae_convt2_x3_ok(g.Cs, g.Ws, g.Cb)) return jvae_convt2_x3(small, w, bias, big, g.N, g.Cs, g.Ws, g.Cb, ws, st);
     int rc = jvae_conv5_pack(w, ws, g.Cs, g.Cb, 1, 0, st);
     if (rc) return rc;
     return jvae_convt2(small, ws, bias, big, g.N, g.Cs, g.Ws, g.Cb, st);
@@ -101,6 +102,8 @@ int jvae_conv_fwd(const ConvGeom& g, int transposed, const float* x, const float
     if (fold_bwd_fast_s1(g) && ws_bytes >= 4 * jvae_conv5_pack_floats(g.Cs, g.Cb))
         return jvae_conv5_fwd(x, w, 1, 1, bias, y, g.N, g.Cs, g.Hs, g.Ws, g.Cb, g.Wb, 1, 4 - g.P, ws, st, stats, nsplit, aff);
     if (fold_bwd_fast_s2(g) && ws_bytes >= 4 * jvae_conv5_pack_floats(g.Cs, g.Cb)) {
+        if (jvae_convt2_x3_ok(g.Cs, g.Ws, g.Cb))
+            return jvae_convt2_x3(x, w, bias, y, g.N, g.Cs, g.Ws, g.Cb, ws, st, stats, nsplit, aff);
         int rc = jvae_conv5_pack(w, ws, g.Cs, g.Cb, 1, 0, st);
         if (rc) return rc;
         return jvae_convt2(x, ws, bias, y, g.N, g.Cs, g.Ws, g.Cb, st, stats, nsplit, aff);

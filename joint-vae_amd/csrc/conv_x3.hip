@@ -386,6 +386,21 @@ int jvae_conv5_x3_set(int mode) {
     return old;
 }
 
+bool jvae_conv5_x3_enabled() {
+    x3_init();
+    return g_x3 != 0;
+}
+
+// split weights for conv5_x3_kernel / convt2_x3_kernel: ws must hold jvae_conv5_x3_pack_bytes(C, O)
+int jvae_conv5_x3_wpack(const float* w, float* ws, int C, int O, int swap, int flip, hipStream_t st) {
+    const int KB = (C + 15) / 16, OP = (O + 31) / 32 * 32;
+    const long total = (long)KB * 25 * 2 * OP * 8;
+    const int blocks = (int)((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256);
+    hipLaunchKernelGGL(x3_wpack_kernel, dim3(blocks), dim3(256), 0, st, w, (__bf16*)ws, C, O, KB, OP, swap, flip);
+    JVAE_LAUNCH_CHECK();
+    return 0;
+}
+
 bool jvae_conv5_x3_ok(int Cin, int H, int W, int Cout, int OH, int OW, int S, int P) {
     x3_init();
     if (!g_x3) return false;
@@ -401,12 +416,10 @@ size_t jvae_conv5_x3_pack_bytes(int Cin, int Cout) {
 int jvae_conv5_x3_fwd(const float* in, const float* w, int swap, int flip, const float* bias, float* out,
                       int N, int Cin, int H, int W, int Cout, int OW, int S, int P, float* ws, hipStream_t st,
                       float* stats, int* nsplit, const InAff* aff) {
-    const int KB = (Cin + 15) / 16, OP = (Cout + 31) / 32 * 32;
+    const int OP = (Cout + 31) / 32 * 32;
     {
-        const long total = (long)KB * 25 * 2 * OP * 8;
-        const int blocks = (int)((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256);
-        hipLaunchKernelGGL(x3_wpack_kernel, dim3(blocks), dim3(256), 0, st, w, (__bf16*)ws, Cin, Cout, KB, OP, swap, flip);
-        JVAE_LAUNCH_CHECK();
+        const int rc = jvae_conv5_x3_wpack(w, ws, Cin, Cout, swap, flip, st);
+        if (rc) return rc;
     }
     X3P p{in, (const u32x4*)ws, bias, out, N, Cin, H, W, OP, P, Cout, stats, aff ? *aff : InAff{nullptr, nullptr, 0}};
     struct Fin { int* n; ~Fin() { if (n) *n = g_x3_splits; } } fin{nsplit};

@@ -185,6 +185,18 @@ def test_checkpoint_roundtrip(tmp_path):
     assert abs(float(l1['total'].mean()) - float(l2['total'].mean())) < 2e-3 * float(l2['total'].mean())
 
 
+@pytest.mark.parametrize('name', ['c2_n8', 'c5_n4'])
+def test_train_step_on_fp32_mfma_kernels_matches_golden(name, golden_dir):
+    """The same parity bar with the split-bf16 convolution switched off (`jvae_conv2d_set_split_bf16(0)`): the stride-1
+    layers then run on v_mfma_f32_32x32x2_f32 (conv_mfma.hip), the A/B partner of conv_x3.hip."""
+    from jvae_hip import lib
+    old = lib.load().jvae_conv2d_set_split_bf16(0)
+    try:
+        test_train_step_matches_reference_golden(name, golden_dir)
+    finally:
+        lib.load().jvae_conv2d_set_split_bf16(old)
+
+
 from oracle.cases import EVAL_CASES, EVAL_OOD_METHODS   # noqa: E402
 
 
