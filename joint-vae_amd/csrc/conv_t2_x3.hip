@@ -15,20 +15,13 @@
 #include "common.h"
 #include "jvae_internal.h"
 #include "conv_dispatch.h"
+#include "conv_x3.h"
 
 namespace {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ void split3(float v, __bf16& h, __bf16& m, __bf16& l) {
-    h = (__bf16)v;
-    float r = v - (float)h;          // exact
-    m = (__bf16)r;
-    r -= (float)m;                   // exact
-    l = (__bf16)r;
-}
+typedef x3_bf16x8 bf16x8;
+typedef x3_u32x4 u32x4;
+typedef x3_f32x2 f32x2;
 
 struct T2X3P {
     const float* in;     // small (N, C, HS, WS) fp32
@@ -158,7 +151,7 @@ __global__ __launch_bounds__(256, 2) void convt2_x3_kernel(T2X3P p) {
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
                         __bf16 a, b, c;
-                        split3(v[j], a, b, c);
+                        x3_split(v[j], a, b, c);
                         s[j][0][ci] = a; s[j][1][ci] = b; s[j][2][ci] = c;
                     }
                 }

@@ -26,20 +26,13 @@
 #include "common.h"
 #include "jvae_internal.h"
 #include "conv_dispatch.h"
+#include "conv_x3.h"
 
 namespace {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ void split3(float v, __bf16& h, __bf16& m, __bf16& l) {
-    h = (__bf16)v;
-    float r = v - (float)h;          // exact
-    m = (__bf16)r;
-    r -= (float)m;                   // exact
-    l = (__bf16)r;
-}
+typedef x3_bf16x8 bf16x8;
+typedef x3_u32x4 u32x4;
+typedef x3_f32x2 f32x2;
 
 // Wp[(kb*5 + kh)][(plane*5 + kw)*2 + half][o][ci] = plane(W[o][c = kb*16 + half*8 + ci][tap = kh*5 + kw])  (o < OP)
 // swap: source is [c][o][tap] (ConvTranspose2d layout / role swap), flip: tap -> 24 - tap
@@ -59,7 +52,7 @@ __global__ __launch_bounds__(256) void x3_wpack_kernel(const float* __restrict__
         float v = 0.f;
         if (c < C && o < O) v = swap ? w[((long)c * O + o) * 25 + st] : w[((long)o * C + c) * 25 + st];
         __bf16 s[3];
-        split3(v, s[0], s[1], s[2]);
+        x3_split(v, s[0], s[1], s[2]);
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl)
             wp[((((long)(kb * 5 + kh) * 30 + (pl * 5 + kw) * 2 + half) * OP) + o) * 8 + ci] = s[pl];
@@ -208,7 +201,7 @@ __global__ __launch_bounds__(256, 2) void conv5_x3_kernel(X3P p) {
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
                         __bf16 a, b, c;
-                        split3(v[j], a, b, c);
+                        x3_split(v[j], a, b, c);
                         s[j][0][ci] = a; s[j][1][ci] = b; s[j][2][ci] = c;
                     }
                 }

@@ -1,4 +1,5 @@
-"""GPU box: time the x3 kernel on imager.15 (forward with stats, and dgrad)."""
+"""GPU box: time the stride-1 split-bf16 convolutions of config 2 (forward with BatchNorm sums, and dgrad); JVAE_X3=0 for the
+fp32-MFMA kernel, JVAE_HIP_LIB=<other build> for an A/B on one box."""
 import os, sys, torch
 REPO = os.environ.get('GRAFT_REPO_ROOT', os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [REPO, os.path.join(REPO, 'joint-vae_amd')]
@@ -17,4 +18,4 @@ for (name, N, cin, cout, H) in (('D5', 1024, 32, 32, 32), ('D3', 1024, 64, 32, 1
     b = torch.zeros(cout, device='cuda'); y = ops.conv_fwd_raw(x, w, b, spec); gy = torch.randn_like(y)
     fl = 2.0 * x.numel() * cout * 25
     tf = timeit(lambda: ops.conv_fwd_stats_raw(x, w, b, spec)); td = timeit(lambda: ops.conv_dgrad_raw(gy, w, spec, x.shape))
-    print(f'X3_DBG={os.environ.get("X3_DBG", "0")} {name} fwd+stats {tf:6.1f} us {fl/tf/1e6:6.1f} TF | dgrad {td:6.1f} us {fl/td/1e6:6.1f} TF')
+    print(f'JVAE_X3={os.environ.get("JVAE_X3", "1")} {name} fwd+stats {tf:6.1f} us {fl/tf/1e6:6.1f} TF | dgrad {td:6.1f} us {fl/td/1e6:6.1f} TF')
