@@ -12,6 +12,7 @@ from . import lib as L
 
 RELU, SIGMOID, IDENT = 1, 2, 0
 OVERLAP_WGRAD = True          # weight-gradient kernels on a second HIP stream (see _Conv.backward)
+LAST_WGRAD_ON_MAIN = __import__('os').environ.get('JVAE_LAST_WGRAD_MAIN', '1') != '0'     # A/B switch, see _Conv.backward
 ACT_KIND = {'relu': RELU, 'sigmoid': SIGMOID, 'linear': IDENT, None: IDENT}
 
 
@@ -313,7 +314,9 @@ class _Conv(torch.autograd.Function):
         if ctx.needs_input_grad[1] or want_b:
             w_slot = _grad_slot(ctx.w_ref)
             b_slot = _grad_slot(ctx.b_ref) if want_b else None
-            if OVERLAP_WGRAD and w_slot is not None and (b_slot is not None or not want_b):
+            # the first layer of the model (its input needs no gradient) is the END of the backward chain: its weight
+            # gradient stays on the main stream, where it runs beside the side stream's last kernels instead of behind them
+            if OVERLAP_WGRAD and (ctx.needs_input_grad[0] or not LAST_WGRAD_ON_MAIN) and w_slot is not None and (b_slot is not None or not want_b):
                 # in-place into the flat gradient buffer: nothing downstream of this node consumes the result before
                 # the optimiser, so the kernel goes to the side stream and overlaps the rest of backward
                 main = torch.cuda.current_stream(x.device)
