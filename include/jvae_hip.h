@@ -254,6 +254,14 @@ int jvae_elbo_bwd_f32(const float* g_wmse, const float* g_cx, const float* g_tot
                       float* g_wmse_s, float* g_kl, float* g_ce, float* gsigma, int accumulate_sigma,
                       int L, int N, int D, float beta, float cw, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- importance-weighted bound of the evaluation path (cvae.py:672-676,793-873): li[l][c][n] = log p(x|z_l) +
+ * log p(z_l|c) - log q(z_l|x) with log p(x|z_l) = -D/2 (wmse_s + 2 log sigma + log 2pi), -log q = (|eps_l|^2 + sum_k
+ * log_var)/2 + K/2 log 2pi; iws[c][n] = mean_l exp(li - max_l li) + max_l li (as the reference writes it).
+ * wmse_s (L,N); eps (L,N,K): rows 1..L of the sampling noise; log_var (N,K); log_pz (L,C,N) from the prior's
+ * log-density (C = 1 for a non-conditional prior); rows: scratch of L*N floats. */
+int jvae_iws_f32(const float* wmse_s, const float* eps, const float* log_var, const float* log_pz, const float* sigma,
+                 int sigma_is_log, int L, int N, int K, int C, int D, float* rows, float* iws, void* stream);
+
 /* ---- running measures of evaluate() in ONE device buffer (cvae.py:619-624,689-724,747-762; Encoder.capacity /
  * dict_min_distance layers.py:323-348): out[16]: [0..9] = sigma, mean x^2, mean mse, rmse, mean zdist, mean var_kl, ld-norm,
  * imut-zy, d-mind, optimiser non-finite flag; [10..15] = running means over `batch`+1 calls of xpow, mse, rmse, dB,

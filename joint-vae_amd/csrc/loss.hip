@@ -257,6 +257,42 @@ inline int ew_grid(long n) {
     return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
 }
 
+// ---- importance-weighted bound of the evaluation path (cvae.py:672-676,793-873) -------------------------------------
+// rows[l][n] = log p(x | z_l) - log q(z_l | x) = -D/2 (wmse_s + 2 log sigma + log 2pi) + (|eps_l|^2 + sum_k log_var)/2
+//              + K/2 log 2pi : one wave per (l, n), lanes over the latent dimension
+__global__ __launch_bounds__(256) void iws_rows_kernel(const float* __restrict__ wmse_s, const float* __restrict__ eps,
+                                                       const float* __restrict__ log_var, const float* __restrict__ sigma,
+                                                       int sigma_is_log, int L, int N, int K, float D, float* __restrict__ rows) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= L * N) return;
+    const int n = row % N;
+    float s = 0.f;
+    for (int k = lane; k < K; k += 64) {
+        const float e = eps[(long)row * K + k];
+        s += fmaf(e, e, log_var[(long)n * K + k]);
+    }
+    s = wave_sum(s);
+    if (lane == 0) {
+        const float log_sigma = sigma_is_log ? sigma[0] : logf(sigma[0]);
+        const float LOG2PI = 1.8378770664093453f;
+        rows[row] = -0.5f * D * (wmse_s[row] + 2.f * log_sigma + LOG2PI) + 0.5f * s + 0.5f * (float)K * LOG2PI;
+    }
+}
+
+// iws[c][n] = mean_l exp(li - m) + m,  li = rows[l][n] + log_pz[l][c][n],  m = max_l li   (sic: cvae.py:868 adds m to the
+// mean, not its logarithm); thread per (c, n), consecutive threads along n
+__global__ __launch_bounds__(256) void iws_fold_kernel(const float* __restrict__ rows, const float* __restrict__ log_pz,
+                                                       int L, int C, int N, float* __restrict__ iws) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)C * N) return;
+    const int n = (int)(i % N);
+    float m = -INFINITY;
+    for (int l = 0; l < L; ++l) m = fmaxf(m, rows[(long)l * N + n] + log_pz[(long)l * C * N + i]);
+    float s = 0.f;
+    for (int l = 0; l < L; ++l) s += expf(rows[(long)l * N + n] + log_pz[(long)l * C * N + i] - m);
+    iws[i] = s / (float)L + m;
+}
+
 }  // namespace
 
 extern "C" {
@@ -347,6 +383,20 @@ int jvae_elbo_bwd_f32(const float* g_wmse, const float* g_cx, const float* g_tot
         hipLaunchKernelGGL(vec_sum_kernel, dim3(1), dim3(256), 0, st, (const float*)ws, gsigma, N, accumulate_sigma);
         JVAE_LAUNCH_CHECK();
     }
+    return 0;
+}
+
+int jvae_iws_f32(const float* wmse_s, const float* eps, const float* log_var, const float* log_pz, const float* sigma,
+                 int sigma_is_log, int L, int N, int K, int C, int D, float* rows, float* iws, void* stream) {
+    if (!wmse_s || !eps || !log_var || !log_pz || !sigma || !rows || !iws || L < 1 || N < 0 || K < 1 || C < 1 || D <= 0)
+        return JVAE_EINVAL;
+    if (N == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(iws_rows_kernel, dim3(cdiv((long)L * N, 4)), dim3(256), 0, st, wmse_s, eps, log_var, sigma, sigma_is_log,
+                       L, N, K, (float)D, rows);
+    JVAE_LAUNCH_CHECK();
+    hipLaunchKernelGGL(iws_fold_kernel, dim3(cdiv((long)C * N, 256)), dim3(256), 0, st, (const float*)rows, log_pz, L, C, N, iws);
+    JVAE_LAUNCH_CHECK();
     return 0;
 }
 

@@ -494,8 +494,7 @@ class ClassificationVariationalNetwork(nn.Module):
         """evaluate(x) without labels (cvae.py:548-600, 793-873): every class is tried as the prior component.
         Losses kl / zdist / var_kl / total / iws [/ cross_y] are (C, N); wmse / cross_x / dzdist stay (N,).
         The heavy parts (conv stacks on (L+1)N latents, BatchNorm, latent / KL kernel on C*N rows, reconstruction,
-        Mahalanobis distances of the L*C*N sampled latents) run on the HIP kernels; the final importance-weight
-        assembly is a handful of elementwise expressions on (L, C, N) tensors."""
+        Mahalanobis distances of the L*C*N sampled latents, the importance-weight assembly) run on the HIP kernels."""
         if self.y_is_coded:
             raise NotImplementedError('y_is_coded models need labels')
         if x.dim() != self.input_dim + 1:
@@ -529,22 +528,15 @@ class ClassificationVariationalNetwork(nn.Module):
             beta = self.beta if with_beta else 1.
             losses['total'] = cross_x.unsqueeze(0) + beta * kd['kl']
             # importance-weighted bound: log p(x|z_l) + log p(z_l|y) - log q(z_l|x), cvae.py:672-676,793-873
-            log_sigma = s.squeeze() if s.is_log else s.log().squeeze()
-            log_px = -D / 2 * (wmse_s + 2 * log_sigma + LOG2PI)                           # (L, N)
             z_s = z[1:]
             if pr.conditional:
                 z_y = z_s.unsqueeze(1).expand(L, C, N, K)
                 y_s = y_all.unsqueeze(0).expand(L, C, N)
                 log_pz = pr.log_density(z_y, y_s)                                         # (L, C, N)
-                log_px = log_px.unsqueeze(1)
             else:
-                log_pz = pr.log_density(z_s, None)
-            log_inv_q = ((eps ** 2).sum(-1) + log_var.sum(-1)) / 2 + K / 2 * LOG2PI       # (L, N)
-            if pr.conditional:
-                log_inv_q = log_inv_q.unsqueeze(1)
-            li = log_px + log_pz + log_inv_q
-            rem = li.max(0)[0]
-            losses['iws'] = (li - rem).exp().mean(0) + rem                                # sic: cvae.py:868
+                log_pz = pr.log_density(z_s, None)                                        # (L, N)
+            # rows + max / mean-exp fold over the L samples in one kernel pair (jvae_iws_f32)
+            losses['iws'] = ops.iws(wmse_s, eps, log_var, log_pz, s, s.is_log, D)
             prev = current_measures._dev if isinstance(current_measures, Measures) else None
             packed = self._pack_measures(x, wmse, terms, dictionary, prev, batch)
         measures = Measures(packed, dictionary is not None, _grad_nan_exit)

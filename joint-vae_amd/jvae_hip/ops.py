@@ -765,6 +765,20 @@ def elbo(wmse_s, kl, ce, sigma, sigma_is_log, D, beta, cw):
     return _Elbo.apply(wmse_s, kl, ce, sigma, sigma_is_log, D, beta, cw)
 
 
+def iws(wmse_s, eps, log_var, log_pz, sigma, sigma_is_log, D):
+    """Importance-weighted bound of the evaluation path (no gradient): wmse_s (L,N), eps (L,N,K), log_var (N,K),
+    log_pz (L,C,N) or (L,N) -> (C,N) or (N,)  (reference cvae.py:793-873)."""
+    Ls, N, K = eps.shape
+    conditional = log_pz.dim() == 3
+    C = log_pz.shape[1] if conditional else 1
+    rows = torch.empty((Ls, N), device=eps.device, dtype=torch.float32)
+    out = torch.empty((C, N), device=eps.device, dtype=torch.float32)
+    rc = L.load().jvae_iws_f32(L.ptr(_c(_f32(wmse_s, 'iws'))), L.ptr(_c(eps)), L.ptr(_c(log_var)), L.ptr(_c(log_pz)), L.ptr(_c(sigma)),
+                              int(sigma_is_log), Ls, N, K, C, int(D), L.ptr(rows), L.ptr(out), L.stream_ptr())
+    L.check(rc, 'jvae_iws_f32')
+    return out if conditional else out[0]
+
+
 def measures(x, wmse, zdist, var_kl, sigma, sigma_is_log, means, flag, scratch, prev=None, batch=0):
     """-> device tensor of 16 floats (layout in csrc/loss.hip measures_kernel); `scratch`: 1-float device tensor;
     `prev`: the tensor returned for the previous batch (running means are continued on the device)."""
