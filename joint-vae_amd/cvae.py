@@ -10,7 +10,7 @@ clip -> Adam — executed by hand-written gfx950 HIP kernels (libjvae_hip.so) be
     .train_model(...)   (hot loop :2424-2479; test / OOD phases are out of scope)                            :2081-2547
     .train() / .to() / .save() / .load() / .latent_sampling / .device / .nparams
 
-What is NOT rebuilt here (raises NotImplementedError when asked for): types other than 'cvae'; pooling /
+What is NOT rebuilt here (raises NotImplementedError when asked for): types other than 'cvae' / 'vae'; pooling /
 up-sampling / resnet feature stacks; dropout; coded, per-dimension or rmse sigma; categorical output;
 accuracy / OOD / misclassification evaluation (`y=None` all-class evaluate lives in SURVEY §8f-1).
 There is no CPU path: calling forward/evaluate with CPU tensors raises.
@@ -168,14 +168,19 @@ class ClassificationVariationalNetwork(nn.Module):
     r"""X -- features -- encoder -- Z -- decoder -- imager -- X^   with a class-conditional prior p(z|y)
     (and a classifier head on z when gamma > 0)."""
 
+    # the tables of cvae.py:82-112 for the two types built here
     loss_components_per_type = {'cvae': ('cross_x', 'kl', 'total', 'zdist', 'var_kl', 'dzdist', 'iws',
-                                         'sigma', 'wmse', 'z_logdet', 'z_tr_inv_cov')}
-    predict_methods_per_type = {'cvae': ['iws', 'closest']}
-    metrics_per_type = {'cvae': ['rmse', 'dB', 'd-mind', 'ld-norm', 'sigma']}
+                                         'sigma', 'wmse', 'z_logdet', 'z_tr_inv_cov'),
+                                'vae': ('cross_x', 'kl', 'zdist', 'var_kl', 'total', 'iws')}
+    predict_methods_per_type = {'cvae': ['iws', 'closest'], 'vae': []}
+    metrics_per_type = {'cvae': ['rmse', 'dB', 'd-mind', 'ld-norm', 'sigma'], 'vae': ['rmse', 'dB', 'sigma']}
     ood_methods_per_type = {'cvae': ['iws-2s', 'iws-a-1-1', 'iws-a-4-1', 'iws', 'mse', 'elbo', 'soft',
-                                     'elbo-2s', 'elbo-a-1-1', 'elbo-a-4-1', 'zdist']}
+                                     'elbo-2s', 'elbo-a-1-1', 'elbo-a-4-1', 'zdist'],
+                            'vae': ['iws', 'iws-2s', 'iws-a-1-1', 'iws-a-4-1', 'elbo', 'elbo-2s', 'elbo-a-1-1',
+                                    'elbo-a-4-1', 'zdist']}
     misclass_methods_per_type = {'cvae': ['softkl*', 'iws', 'softiws*', 'kl', 'max', 'zdist', 'softzdist*',
-                                          'baseline*', 'hyz']}
+                                          'baseline*', 'hyz'],
+                                 'vae': []}
 
     def __init__(self, input_shape, num_labels, type='cvae', y_is_coded=False, output_distribution='gaussian',
                  job_number=0, features=None, pretrained_features=None, batch_norm=False, dropout=False,
@@ -185,8 +190,10 @@ class ClassificationVariationalNetwork(nn.Module):
                  encoder_forced_variance=False, output_activation=DEFAULT_OUTPUT_ACTIVATION, sigma={'value': 1},
                  optimizer={}, shadow=False, representation='rgb', version=VERSION, *args, **kw):
         super().__init__(*args, **kw)
-        if type != 'cvae':
-            raise NotImplementedError("only type='cvae' is built on the native kernels (got {!r})".format(type))
+        if type not in ('cvae', 'vae'):
+            raise NotImplementedError("types 'cvae' (class-conditional prior) and 'vae' (single prior) are built on the "
+                                      "native kernels (got {!r})".format(type))
+        assert not (y_is_coded and type == 'vae')
         if output_distribution != 'gaussian':
             raise NotImplementedError('categorical output is outside the native-kernel contract')
         if dropout:
@@ -196,7 +203,7 @@ class ClassificationVariationalNetwork(nn.Module):
         self.name = name
         self.job_number = job_number
         self.type = type
-        self.is_cvae, self.is_jvae, self.is_vib, self.is_vae, self.is_xvae = True, False, False, False, False
+        self.is_cvae, self.is_jvae, self.is_vib, self.is_vae, self.is_xvae = type == 'cvae', False, False, type == 'vae', False
         self.loss_components = self.loss_components_per_type[type]
         self.metrics = self.metrics_per_type[type]
         self.predict_methods = list(self.predict_methods_per_type[type])
@@ -206,7 +213,7 @@ class ClassificationVariationalNetwork(nn.Module):
         self.y_is_decoded = gamma                 # cvae: the classifier enters the loss iff gamma
         self.x_is_generated = True
         self.output_distribution = output_distribution
-        self.losses_might_be_computed_for_each_class = True
+        self.losses_might_be_computed_for_each_class = not self.is_vae      # cvae.py:205
 
         if self.y_is_decoded:
             self.classifier_type = 'linear'
@@ -249,7 +256,8 @@ class ClassificationVariationalNetwork(nn.Module):
         self.beta = beta
         self.gamma = gamma if self.y_is_decoded else None
         prior = dict(prior)
-        prior['num_priors'] = num_labels
+        if self.is_cvae:                          # cvae.py:274-275: one prior component per class; 'vae': a single one
+            prior['num_priors'] = num_labels
         self.encoder = Encoder(enc_in, num_labels, intermediate_dims=encoder, latent_dim=latent_dim,
                                y_is_coded=self.y_is_coded, dropout=dropout, sigma_output_dim=0,
                                forced_variance=encoder_forced_variance, sampling_size=latent_sampling, prior=prior,
@@ -526,7 +534,8 @@ class ClassificationVariationalNetwork(nn.Module):
             if self.y_is_decoded:
                 losses['cross_y'] = x_loss(None, logits, batch_mean=False)                # (C, N)
             beta = self.beta if with_beta else 1.
-            losses['total'] = cross_x.unsqueeze(0) + beta * kd['kl']
+            # one prior component per class: (C, N); a single prior (type 'vae'): (N,)
+            losses['total'] = (cross_x.unsqueeze(0) if pr.conditional else cross_x) + beta * kd['kl']
             # importance-weighted bound: log p(x|z_l) + log p(z_l|y) - log q(z_l|x), cvae.py:672-676,793-873
             z_s = z[1:]
             if pr.conditional:
@@ -570,8 +579,11 @@ class ClassificationVariationalNetwork(nn.Module):
         for name in methods:
             m = name[:-3] if name.endswith('-2s') else name
             m = m.split('-')[0] if '-a-' in m else m
+            per_class = self.losses_might_be_computed_for_each_class          # cvae.py:996-1016,1036-1039
             if m in ('elbo', 'max'):
-                v = (-losses['total']).max(0)[0]
+                v = (-losses['total']).max(0)[0] if (per_class or m == 'max') else -losses['total']
+            elif m == 'iws' and not per_class:
+                v = losses['iws']
             elif m == 'iws':
                 top = losses['iws'].max(0)[0]
                 v = (losses['iws'] - top).exp().sum(0).log() + top + math.log(C)
@@ -580,7 +592,7 @@ class ClassificationVariationalNetwork(nn.Module):
             elif m.startswith('softkl-'):
                 v = (-losses['kl'] / float(m[7:])).softmax(0).max(0)[0]
             elif m in ('zdist', 'kl'):
-                v = (-losses[m]).max(0)[0]
+                v = (-losses[m]).max(0)[0] if not self.is_vae else -losses[m]
             elif m == 'mse':
                 v = -losses['cross_x']
             elif m == 'wmse':

@@ -98,7 +98,20 @@ DSL_CASES = {
 }
 
 
+# type='vae' (single, non-conditional prior; cvae.py:188-205,274-275): one training step and one evaluation pass
+DSL_CASES['a2_n8_vae'] = dict(net=_conv(10, type='vae', prior=dict(distribution='gaussian', init_mean=0., var_dim='scalar')),
+                              N=8, kl_var_weighting=1.0, gamma_weighting=1.0)
+
+
+DSL_EVAL_CASES = {
+    'ea2_n8_vae_L3': dict(net=_conv(10, type='vae', test_latent_sampling=3,
+                                    prior=dict(distribution='gaussian', init_mean=0., var_dim='scalar')), N=8),
+}
+
+
 def get_case(name):
+    if name in DSL_EVAL_CASES:
+        return copy.deepcopy(DSL_EVAL_CASES[name])
     if name in DSL_CASES:
         return copy.deepcopy(DSL_CASES[name])
     if name in WIM_CASES:

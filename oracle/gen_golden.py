@@ -27,7 +27,7 @@ REPO = os.path.dirname(HERE)
 REF = '/root/reference'
 sys.path.insert(0, REPO)
 
-from oracle.cases import CASES, EVAL_CASES, EVAL_OOD_METHODS, WIM_CASES, get_case            # noqa: E402
+from oracle.cases import CASES, DSL_EVAL_CASES, EVAL_CASES, EVAL_OOD_METHODS, WIM_CASES, get_case            # noqa: E402
 from oracle.det_init import load_det_state, det_inputs  # noqa: E402
 
 FULL_GRAD_MAX = 8192      # parameters up to this many elements get their full gradient stored
@@ -177,13 +177,15 @@ def run_eval_case(Net, name):
         out['measure.' + k] = np.float64(v)
     for m in net.predict_methods:
         out['predict.' + m] = net.predict_after_evaluate(y_est, losses, method=m).numpy()
-    dm = net.batch_dist_measures(y_est, losses, EVAL_OOD_METHODS)
+    methods = EVAL_OOD_METHODS if name in EVAL_CASES else [m for m in EVAL_OOD_METHODS if m in net.ood_methods]
+    out['ood_methods'] = np.array(methods)
+    dm = net.batch_dist_measures(y_est, losses, methods)
     for k, v in dm.items():
         out['ood.' + k] = v.numpy()
     out['predict_methods'] = np.array(net.predict_methods)
     path = os.path.join(REPO, 'tests', 'golden', name + '.npz')
     np.savez_compressed(path, **out)
-    print(f'{name}: L={L} iws[0,:3]={out["loss.iws"][0, :3]} -> {path} ({os.path.getsize(path) / 1024:.0f} KiB)')
+    print(f'{name}: L={L} iws[:3]={out["loss.iws"].reshape(-1)[:3]} -> {path} ({os.path.getsize(path) / 1024:.0f} KiB)')
 
 
 def run_wim_case(Net, name):
@@ -251,7 +253,7 @@ def main():
     for n in names:
         if n in WIM_CASES:
             run_wim_case(Net, n)
-        elif n in EVAL_CASES:
+        elif n in EVAL_CASES or n in DSL_EVAL_CASES:
             run_eval_case(Net, n)
         else:
             run_case(Net, n)

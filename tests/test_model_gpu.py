@@ -197,10 +197,10 @@ def test_train_step_on_fp32_mfma_kernels_matches_golden(name, golden_dir):
         lib.load().jvae_conv2d_set_split_bf16(old)
 
 
-from oracle.cases import EVAL_CASES, EVAL_OOD_METHODS   # noqa: E402
+from oracle.cases import DSL_EVAL_CASES, EVAL_CASES, EVAL_OOD_METHODS   # noqa: E402
 
 
-@pytest.mark.parametrize('name', list(EVAL_CASES))
+@pytest.mark.parametrize('name', list(EVAL_CASES) + list(DSL_EVAL_CASES))
 def test_eval_path_matches_reference_golden(name, golden_dir):
     """evaluate(x) without labels in eval mode (BatchNorm on running statistics, L = test sampling):
     all-class losses (C,N), the importance-weighted bound, predictions (bit-exact) and OOD scores."""
@@ -225,8 +225,9 @@ def test_eval_path_matches_reference_golden(name, golden_dir):
         assert abs(meas[k] - ref) <= 2e-4 * max(1.0, abs(ref)), (k, meas[k], ref)
     for m in g['predict_methods']:
         assert np.array_equal(net.predict_after_evaluate(y_est, losses, method=str(m)).cpu().numpy(), g['predict.' + str(m)])
-    scores = net.batch_dist_measures(y_est, losses, EVAL_OOD_METHODS)
-    for m in EVAL_OOD_METHODS:
+    methods = [str(m) for m in g['ood_methods']] if 'ood_methods' in g.files else EVAL_OOD_METHODS
+    scores = net.batch_dist_measures(y_est, losses, methods)
+    for m in methods:
         assert rel(scores[m], g['ood.' + m]) < RTOL, m
 
 
