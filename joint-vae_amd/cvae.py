@@ -10,9 +10,10 @@ clip -> Adam — executed by hand-written gfx950 HIP kernels (libjvae_hip.so) be
     .train_model(...)   (hot loop :2424-2479; test / OOD phases are out of scope)                            :2081-2547
     .train() / .to() / .save() / .load() / .latent_sampling / .device / .nparams
 
-What is NOT rebuilt here (raises NotImplementedError when asked for): types other than 'cvae' / 'vae'; pooling /
-up-sampling / resnet feature stacks; dropout; coded, per-dimension or rmse sigma; categorical output;
-accuracy / OOD / misclassification evaluation (`y=None` all-class evaluate lives in SURVEY §8f-1).
+What is NOT rebuilt here (raises NotImplementedError when asked for): types other than 'cvae' / 'vae'; resnet
+feature stacks (torchvision); dropout; coded, per-dimension or rmse sigma; the categorical output MODE (the loss
+function exists); the accuracy / misclassification phases of train_model.  Pooling / up-sampling layer tokens, SGD,
+the `y=None` all-class evaluation with its OOD scores and the WIM fine-tuning step are built.
 There is no CPU path: calling forward/evaluate with CPU tensors raises.
 """
 import json
