@@ -10,7 +10,7 @@ clip -> Adam — executed by hand-written gfx950 HIP kernels (libjvae_hip.so) be
     .train_model(...)   (hot loop :2424-2479; test / OOD phases are out of scope)                            :2081-2547
     .train() / .to() / .save() / .load() / .latent_sampling / .device / .nparams
 
-What is NOT rebuilt here (raises NotImplementedError when asked for): types other than 'cvae' / 'vae'; resnet
+What is NOT rebuilt here (raises NotImplementedError when asked for): types other than 'cvae' / 'vae' / 'jvae' (jvae: training and labelled evaluation only); resnet
 feature stacks (torchvision); dropout; coded, per-dimension or rmse sigma; the categorical output MODE (the loss
 function exists); the accuracy / misclassification phases of train_model.  Pooling / up-sampling layer tokens, SGD,
 the `y=None` all-class evaluation with its OOD scores and the WIM fine-tuning step are built.
@@ -172,16 +172,19 @@ class ClassificationVariationalNetwork(nn.Module):
     # the tables of cvae.py:82-112 for the two types built here
     loss_components_per_type = {'cvae': ('cross_x', 'kl', 'total', 'zdist', 'var_kl', 'dzdist', 'iws',
                                          'sigma', 'wmse', 'z_logdet', 'z_tr_inv_cov'),
-                                'vae': ('cross_x', 'kl', 'zdist', 'var_kl', 'total', 'iws')}
-    predict_methods_per_type = {'cvae': ['iws', 'closest'], 'vae': []}
-    metrics_per_type = {'cvae': ['rmse', 'dB', 'd-mind', 'ld-norm', 'sigma'], 'vae': ['rmse', 'dB', 'sigma']}
+                                'vae': ('cross_x', 'kl', 'zdist', 'var_kl', 'total', 'iws'),
+                                'jvae': ('cross_x', 'kl', 'cross_y', 'total')}
+    predict_methods_per_type = {'cvae': ['iws', 'closest'], 'vae': [], 'jvae': ['loss', 'esty']}
+    metrics_per_type = {'cvae': ['rmse', 'dB', 'd-mind', 'ld-norm', 'sigma'], 'vae': ['rmse', 'dB', 'sigma'],
+                        'jvae': ['rmse', 'dB', 'sigma']}
     ood_methods_per_type = {'cvae': ['iws-2s', 'iws-a-1-1', 'iws-a-4-1', 'iws', 'mse', 'elbo', 'soft',
                                      'elbo-2s', 'elbo-a-1-1', 'elbo-a-4-1', 'zdist'],
                             'vae': ['iws', 'iws-2s', 'iws-a-1-1', 'iws-a-4-1', 'elbo', 'elbo-2s', 'elbo-a-1-1',
-                                    'elbo-a-4-1', 'zdist']}
+                                    'elbo-a-4-1', 'zdist'],
+                            'jvae': ['max', 'sum', 'std']}
     misclass_methods_per_type = {'cvae': ['softkl*', 'iws', 'softiws*', 'kl', 'max', 'zdist', 'softzdist*',
                                           'baseline*', 'hyz'],
-                                 'vae': []}
+                                 'vae': [], 'jvae': []}
 
     def __init__(self, input_shape, num_labels, type='cvae', y_is_coded=False, output_distribution='gaussian',
                  job_number=0, features=None, pretrained_features=None, batch_norm=False, dropout=False,
@@ -191,9 +194,9 @@ class ClassificationVariationalNetwork(nn.Module):
                  encoder_forced_variance=False, output_activation=DEFAULT_OUTPUT_ACTIVATION, sigma={'value': 1},
                  optimizer={}, shadow=False, representation='rgb', version=VERSION, *args, **kw):
         super().__init__(*args, **kw)
-        if type not in ('cvae', 'vae'):
-            raise NotImplementedError("types 'cvae' (class-conditional prior) and 'vae' (single prior) are built on the "
-                                      "native kernels (got {!r})".format(type))
+        if type not in ('cvae', 'vae', 'jvae'):
+            raise NotImplementedError("types 'cvae' (class-conditional prior), 'vae' (single prior) and 'jvae' (labels coded "
+                                      "into the encoder, classifier on z) are built on the native kernels (got {!r})".format(type))
         assert not (y_is_coded and type == 'vae')
         if output_distribution != 'gaussian':
             raise NotImplementedError('categorical output is outside the native-kernel contract')
@@ -204,14 +207,14 @@ class ClassificationVariationalNetwork(nn.Module):
         self.name = name
         self.job_number = job_number
         self.type = type
-        self.is_cvae, self.is_jvae, self.is_vib, self.is_vae, self.is_xvae = type == 'cvae', False, False, type == 'vae', False
+        self.is_cvae, self.is_jvae, self.is_vib, self.is_vae, self.is_xvae = type == 'cvae', type == 'jvae', False, type == 'vae', False
         self.loss_components = self.loss_components_per_type[type]
         self.metrics = self.metrics_per_type[type]
         self.predict_methods = list(self.predict_methods_per_type[type])
         self.ood_methods = list(self.ood_methods_per_type[type])
         self.misclass_methods = list(self.misclass_methods_per_type[type])
         self.y_is_coded = y_is_coded
-        self.y_is_decoded = gamma                 # cvae: the classifier enters the loss iff gamma
+        self.y_is_decoded = gamma if (self.is_cvae or self.is_vae) else True      # cvae.py:196-199
         self.x_is_generated = True
         self.output_distribution = output_distribution
         self.losses_might_be_computed_for_each_class = not self.is_vae      # cvae.py:205
@@ -450,7 +453,12 @@ class ClassificationVariationalNetwork(nn.Module):
         N = x.shape[0]
         L = self.latent_sampling
         D = int(np.prod(self.input_shape))
-        cross_y_weight = (gamma_weighting * self.gamma if self.training else False) if self.y_is_decoded else False
+        cross_y_weight = False                                               # cvae.py:557-563
+        if self.y_is_decoded:
+            if self.is_cvae or self.is_vae:
+                cross_y_weight = gamma_weighting * self.gamma if self.training else False
+            else:
+                cross_y_weight = gamma_weighting * self.gamma
 
         feats = self._features_of(x).reshape(N, -1)
         y1h = onehot_encoding(y, self.num_labels).float() if self.y_is_coded else None
@@ -504,8 +512,9 @@ class ClassificationVariationalNetwork(nn.Module):
         Losses kl / zdist / var_kl / total / iws [/ cross_y] are (C, N); wmse / cross_x / dzdist stay (N,).
         The heavy parts (conv stacks on (L+1)N latents, BatchNorm, latent / KL kernel on C*N rows, reconstruction,
         Mahalanobis distances of the L*C*N sampled latents, the importance-weight assembly) run on the HIP kernels."""
-        if self.y_is_coded:
-            raise NotImplementedError('y_is_coded models need labels')
+        if self.y_is_coded or self.is_jvae:
+            raise NotImplementedError('the all-class evaluation of models with coded labels (x repeated along the classes '
+                                      'through the encoder) is not built: pass y')
         if x.dim() != self.input_dim + 1:
             x = x.reshape(-1, *self.input_shape)
         N, C, K = x.shape[0], self.num_labels, self.latent_dim

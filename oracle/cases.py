@@ -103,6 +103,11 @@ DSL_CASES['a2_n8_vae'] = dict(net=_conv(10, type='vae', prior=dict(distribution=
                               N=8, kl_var_weighting=1.0, gamma_weighting=1.0)
 
 
+# type='jvae': labels one-hot coded into the encoder input, single prior, classifier on z always in the loss
+DSL_CASES['j2_n8_jvae'] = dict(net=_conv(10, type='jvae', y_is_coded=True, gamma=2.0, classifier=[20],
+                                         prior=dict(distribution='gaussian', init_mean=0., var_dim='scalar')),
+                               N=8, kl_var_weighting=1.0, gamma_weighting=0.5)
+
 DSL_EVAL_CASES = {
     'ea2_n8_vae_L3': dict(net=_conv(10, type='vae', test_latent_sampling=3,
                                     prior=dict(distribution='gaussian', init_mean=0., var_dim='scalar')), N=8),
