@@ -254,6 +254,11 @@ int jvae_elbo_bwd_f32(const float* g_wmse, const float* g_cx, const float* g_tot
                       float* g_wmse_s, float* g_kl, float* g_ce, float* gsigma, int accumulate_sigma,
                       int L, int N, int D, float beta, float cw, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- nn.Dropout(p) of the dense trunks (module/vae_layers/layers.py:287-288, cvae.py:297-298), train mode:
+ * y[i] = keep(seed, i) ? x[i] / (1 - p) : 0 with a counter-based mask (the backward pass calls it on dy with the same
+ * seed).  The random stream is the kernel's own; the reference draws from torch's global generator. */
+int jvae_dropout_f32(const float* x, float* y, long n, float p, long seed, void* stream);
+
 /* ---- importance-weighted bound of the evaluation path (cvae.py:672-676,793-873): li[l][c][n] = log p(x|z_l) +
  * log p(z_l|c) - log q(z_l|x) with log p(x|z_l) = -D/2 (wmse_s + 2 log sigma + log 2pi), -log q = (|eps_l|^2 + sum_k
  * log_var)/2 + K/2 log 2pi; iws[c][n] = mean_l exp(li - max_l li) + max_l li (as the reference writes it).

@@ -293,6 +293,26 @@ __global__ __launch_bounds__(256) void iws_fold_kernel(const float* __restrict__
     iws[i] = s / (float)L + m;
 }
 
+// ---- nn.Dropout of the dense trunks (layers.py:287-288, cvae.py:297-298) -----------------------------------------------
+// keep(i) = hash(seed, i) >= p * 2^32 (counter-based: forward and backward regenerate the same mask, nothing is stored);
+// y = keep ? x / (1 - p) : 0.  The stream of random bits is this kernel's own (no parity with torch's Philox draws:
+// the reference draws them from the global generator, so only the distribution is comparable).
+__device__ __forceinline__ unsigned dropout_hash(unsigned long long seed, unsigned long long i) {
+    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (i + 1);           // splitmix64
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (unsigned)(z >> 32);
+}
+
+__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, long n, float p,
+                                                      unsigned long long seed) {
+    const unsigned thr = (unsigned)fminf(p * 4294967296.f, 4294967295.f);
+    const float scale = 1.f / (1.f - p);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        y[i] = dropout_hash(seed, (unsigned long long)i) >= thr ? x[i] * scale : 0.f;
+}
+
 }  // namespace
 
 extern "C" {
@@ -383,6 +403,16 @@ int jvae_elbo_bwd_f32(const float* g_wmse, const float* g_cx, const float* g_tot
         hipLaunchKernelGGL(vec_sum_kernel, dim3(1), dim3(256), 0, st, (const float*)ws, gsigma, N, accumulate_sigma);
         JVAE_LAUNCH_CHECK();
     }
+    return 0;
+}
+
+// forward (x -> y) and backward (dy -> dx) are the same masked scaling for the same seed
+int jvae_dropout_f32(const float* x, float* y, long n, float p, long seed, void* stream) {
+    if (n < 0 || !(p >= 0.f && p < 1.f) || (n > 0 && (!x || !y))) return JVAE_EINVAL;
+    if (n == 0) return 0;
+    long b = (n + 255) / 256;
+    hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)(b > 8192 ? 8192 : b)), dim3(256), 0, (hipStream_t)stream, x, y, n, p, (unsigned long long)seed);
+    JVAE_LAUNCH_CHECK();
     return 0;
 }
 

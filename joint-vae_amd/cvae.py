@@ -11,7 +11,7 @@ clip -> Adam — executed by hand-written gfx950 HIP kernels (libjvae_hip.so) be
     .train() / .to() / .save() / .load() / .latent_sampling / .device / .nparams
 
 What is NOT rebuilt here (raises NotImplementedError when asked for): types other than 'cvae' / 'vae' / 'jvae' (jvae: training and labelled evaluation only); resnet
-feature stacks (torchvision); dropout; coded, per-dimension or rmse sigma; the categorical output MODE (the loss
+feature stacks (torchvision); coded, per-dimension or rmse sigma; the categorical output MODE (the loss
 function exists); the accuracy / misclassification phases of train_model.  Pooling / up-sampling layer tokens, SGD,
 the `y=None` all-class evaluation with its OOD scores and the WIM fine-tuning step are built.
 There is no CPU path: calling forward/evaluate with CPU tensors raises.
@@ -32,7 +32,7 @@ from module.optimizers import Optimizer
 from module.losses import x_loss, mse_loss, categorical_loss  # noqa: F401  (import surface of the reference)
 from module.vae_layers import Encoder, Classifier, Sigma, build_de_conv_layers, find_input_shape
 from module.vae_layers import onehot_encoding, activation_layers
-from module.vae_layers.layers import HipLinear, DenseStack
+from module.vae_layers.layers import HipLinear, HipDropout, DenseStack
 
 DEFAULT_ACTIVATION = 'relu'
 DEFAULT_OUTPUT_ACTIVATION = 'linear'
@@ -200,8 +200,6 @@ class ClassificationVariationalNetwork(nn.Module):
         assert not (y_is_coded and type == 'vae')
         if output_distribution != 'gaussian':
             raise NotImplementedError('categorical output is outside the native-kernel contract')
-        if dropout:
-            raise NotImplementedError('dropout is outside the native-kernel contract')
         assert not upsampler or features, 'no upsampler without features'
 
         self.name = name
@@ -271,6 +269,8 @@ class ClassificationVariationalNetwork(nn.Module):
         shared_act = activation_layers[activation]()
         for d in decoder:
             dense += [HipLinear(width, d), shared_act]
+            if dropout:
+                dense.append(HipDropout(p=dropout))
             width = d
         self.decoder = DenseStack(*dense)
         if upsampler:

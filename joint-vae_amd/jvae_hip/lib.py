@@ -68,6 +68,7 @@ _SIGS = {
     'jvae_elbo_fwd_f32': (c_int, [P, P, P, P, c_int, P, P, P, c_int, c_int, c_int, c_float, c_float, P]),
     'jvae_elbo_bwd_f32': (c_int, [P, P, P, P, c_int, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_float, P, c_size_t, P]),
     'jvae_measures_f32': (c_int, [P, c_long, P, P, P, c_int, c_int, P, c_int, P, c_int, c_int, P, P, c_int, P, P]),
+    'jvae_dropout_f32': (c_int, [P, P, c_long, c_float, c_long, P]),
     'jvae_iws_f32': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P]),
     'jvae_xent_fwd_f32': (c_int, [P, P, P, c_int, c_int, c_int, P]),
     'jvae_xent_bwd_f32': (c_int, [P, P, P, P, c_int, c_int, c_int, P]),

@@ -546,6 +546,31 @@ def act(x, kind):
     return _Act.apply(x, kind)
 
 
+# ------------------------------------------------------------------------------------------- dropout
+class _Dropout(torch.autograd.Function):
+    """nn.Dropout(p) in train mode (layers.py:287-288): counter-based mask, regenerated in backward from the seed."""
+
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        x = _c(_f32(x, 'dropout'))
+        y = torch.empty_like(x)
+        L.check(L.load().jvae_dropout_f32(L.ptr(x), L.ptr(y), x.numel(), float(p), int(seed), L.stream_ptr()), 'dropout')
+        ctx.cfg = (float(p), int(seed))
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        p, seed = ctx.cfg
+        gy = _c(gy)
+        gx = torch.empty_like(gy)
+        L.check(L.load().jvae_dropout_f32(L.ptr(gy), L.ptr(gx), gy.numel(), p, seed, L.stream_ptr()), 'dropout_bwd')
+        return gx, None, None
+
+
+def dropout(x, p, seed):
+    return _Dropout.apply(x, p, seed)
+
+
 # ------------------------------------------------------------------------------- pooling / up-sampling
 POOL_MAX, POOL_AVG = 0, 1
 

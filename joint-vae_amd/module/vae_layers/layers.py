@@ -218,8 +218,27 @@ class DenseStack(nn.Sequential):
         return x
 
 
-def _dropout_not_supported(p):
-    raise NotImplementedError('dropout={} is outside the native-kernel contract of this build'.format(p))
+class HipDropout(nn.Module):
+    """nn.Dropout(p) (reference layers.py:287-288, cvae.py:297-298): identity in eval mode; in train mode a HIP kernel
+    with a counter-based mask.  The seed of every call is drawn from torch's default CPU generator (so torch.manual_seed
+    makes runs repeatable); the mask itself is not torch's."""
+
+    def __init__(self, p=0.5):
+        super().__init__()
+        if not 0. <= p < 1.:
+            raise ValueError('dropout probability has to be in [0, 1), got {}'.format(p))
+        self.p = float(p)
+
+    def forward(self, x):
+        if not self.training or self.p == 0.:
+            if not x.is_cuda:
+                raise ops.L.JvaeHipError('jvae_hip ops need tensors resident on the GPU (no CPU fallback)')
+            return x
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        return ops.dropout(x, self.p, seed)
+
+    def extra_repr(self):
+        return f'p={self.p}'
 
 
 class Encoder(nn.Module):
@@ -235,13 +254,12 @@ class Encoder(nn.Module):
         self.num_labels = num_labels
         self.forced_variance = forced_variance
         self._sampling_size = sampling_size
-        if dropout:
-            _dropout_not_supported(dropout)
-
         width = int(np.prod(input_shape)) + num_labels * bool(y_is_coded)
         trunk = []
         for d in intermediate_dims:
             trunk += [HipLinear(width, d), activation_layers[activation]()]
+            if dropout:
+                trunk.append(HipDropout(p=dropout))
             width = d
         self.dense_projs = DenseStack(*trunk)
         self.dense_mean = HipLinear(width, latent_dim)

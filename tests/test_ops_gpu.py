@@ -498,3 +498,46 @@ def test_categorical_loss():
     got.backward(gy.to(DEV))
     assert rel(od.grad, ref_in.grad) < 2e-5
     assert abs(float(categorical_loss(od.detach(), x.to(DEV))) - float(ref.mean())) < 1e-3
+
+
+def test_dropout_kernel_and_module():
+    """nn.Dropout of the dense trunks (reference layers.py:287-288): masked scaling, same mask in backward, identity in
+    eval mode; the random stream is the kernel's own, so the check is on the distribution."""
+    from jvae_hip import ops
+    from module.vae_layers.layers import HipDropout
+    x = torch.randn(512, 300, device=DEV).abs() + 0.1
+    for p in (0.1, 0.5):
+        xr = x.clone().requires_grad_(True)
+        y = ops.dropout(xr, p, 12345)
+        kept = y != 0
+        frac = float(kept.float().mean())
+        assert abs(frac - (1 - p)) < 0.01, (p, frac)
+        assert rel(y[kept], x[kept] / (1 - p)) < 1e-6
+        assert torch.equal(y, ops.dropout(x, p, 12345)) and not torch.equal(y, ops.dropout(x, p, 12346))
+        y.sum().backward()
+        assert torch.equal(xr.grad != 0, kept) and rel(xr.grad[kept], torch.full_like(xr.grad[kept], 1 / (1 - p))) < 1e-6
+        # no structure along rows / columns
+        assert float(kept.float().mean(0).std()) < 0.05 and float(kept.float().mean(1).std()) < 0.06
+    m = HipDropout(0.3).to(DEV)
+    m.eval()
+    assert m(x) is x
+    m.train()
+    torch.manual_seed(7)
+    a = m(x)
+    torch.manual_seed(7)
+    assert torch.equal(a, m(x)) and abs(float((a != 0).float().mean()) - 0.7) < 0.01
+    # end to end: an MLP model with dropout in both dense trunks trains (finite, decreasing loss) and evaluates
+    from cvae import ClassificationVariationalNetwork as Net
+    torch.manual_seed(0)
+    net = Net(input_shape=(1, 28, 28), num_labels=10, type='cvae', features=None, upsampler=None, encoder=[64, 32],
+              decoder=[32, 64], classifier=[], batch_norm=False, latent_dim=8, dropout=0.2, sigma={'value': 0.5}, gamma=0.,
+              output_activation='sigmoid',
+              prior=dict(distribution='gaussian', init_mean=0., learned_means=True, var_dim='scalar', freeze_means=0),
+              optimizer=dict(optim_type='adam', lr=2e-3)).to(DEV)
+    net.train()
+    xb, yb = torch.rand(64, 1, 28, 28, device=DEV), torch.randint(0, 10, (64,), device=DEV)
+    tot = [float(net.train_step(xb, yb, batch=i)[0]['total'].mean()) for i in range(12)]
+    assert all(math.isfinite(t) for t in tot) and tot[-1] < tot[0]
+    net.eval()
+    a_, b_ = net.evaluate(xb, yb)[2]['total'], net.evaluate(xb, yb)[2]['total']
+    assert a_.shape == (64,)
