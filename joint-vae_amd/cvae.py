@@ -10,7 +10,7 @@ clip -> Adam — executed by hand-written gfx950 HIP kernels (libjvae_hip.so) be
     .train_model(...)   (hot loop :2424-2479; test / OOD phases are out of scope)                            :2081-2547
     .train() / .to() / .save() / .load() / .latent_sampling / .device / .nparams
 
-What is NOT rebuilt here (raises NotImplementedError when asked for): types other than 'cvae' / 'vae' / 'jvae' (jvae: training and labelled evaluation only); resnet
+What is NOT rebuilt here (raises NotImplementedError when asked for): type 'vib' (cvae / xvae / vae are complete, jvae: training and labelled evaluation only); resnet
 feature stacks (torchvision); coded, per-dimension or rmse sigma; the categorical output MODE (the loss
 function exists); the accuracy / misclassification phases of train_model.  Pooling / up-sampling layer tokens, SGD,
 the `y=None` all-class evaluation with its OOD scores and the WIM fine-tuning step are built.
@@ -173,18 +173,19 @@ class ClassificationVariationalNetwork(nn.Module):
     loss_components_per_type = {'cvae': ('cross_x', 'kl', 'total', 'zdist', 'var_kl', 'dzdist', 'iws',
                                          'sigma', 'wmse', 'z_logdet', 'z_tr_inv_cov'),
                                 'vae': ('cross_x', 'kl', 'zdist', 'var_kl', 'total', 'iws'),
-                                'jvae': ('cross_x', 'kl', 'cross_y', 'total')}
-    predict_methods_per_type = {'cvae': ['iws', 'closest'], 'vae': [], 'jvae': ['loss', 'esty']}
+                                'jvae': ('cross_x', 'kl', 'cross_y', 'total'),
+                                'xvae': ('cross_x', 'kl', 'total', 'zdist', 'iws')}
+    predict_methods_per_type = {'cvae': ['iws', 'closest'], 'vae': [], 'jvae': ['loss', 'esty'], 'xvae': ['loss', 'closest']}
     metrics_per_type = {'cvae': ['rmse', 'dB', 'd-mind', 'ld-norm', 'sigma'], 'vae': ['rmse', 'dB', 'sigma'],
-                        'jvae': ['rmse', 'dB', 'sigma']}
+                        'jvae': ['rmse', 'dB', 'sigma'], 'xvae': ['rmse', 'dB', 'zdist', 'd-mind', 'ld-norm', 'sigma']}
     ood_methods_per_type = {'cvae': ['iws-2s', 'iws-a-1-1', 'iws-a-4-1', 'iws', 'mse', 'elbo', 'soft',
                                      'elbo-2s', 'elbo-a-1-1', 'elbo-a-4-1', 'zdist'],
                             'vae': ['iws', 'iws-2s', 'iws-a-1-1', 'iws-a-4-1', 'elbo', 'elbo-2s', 'elbo-a-1-1',
                                     'elbo-a-4-1', 'zdist'],
-                            'jvae': ['max', 'sum', 'std']}
+                            'jvae': ['max', 'sum', 'std'], 'xvae': ['max', 'mean', 'std']}
     misclass_methods_per_type = {'cvae': ['softkl*', 'iws', 'softiws*', 'kl', 'max', 'zdist', 'softzdist*',
                                           'baseline*', 'hyz'],
-                                 'vae': [], 'jvae': []}
+                                 'vae': [], 'jvae': [], 'xvae': []}
 
     def __init__(self, input_shape, num_labels, type='cvae', y_is_coded=False, output_distribution='gaussian',
                  job_number=0, features=None, pretrained_features=None, batch_norm=False, dropout=False,
@@ -194,9 +195,9 @@ class ClassificationVariationalNetwork(nn.Module):
                  encoder_forced_variance=False, output_activation=DEFAULT_OUTPUT_ACTIVATION, sigma={'value': 1},
                  optimizer={}, shadow=False, representation='rgb', version=VERSION, *args, **kw):
         super().__init__(*args, **kw)
-        if type not in ('cvae', 'vae', 'jvae'):
-            raise NotImplementedError("types 'cvae' (class-conditional prior), 'vae' (single prior) and 'jvae' (labels coded "
-                                      "into the encoder, classifier on z) are built on the native kernels (got {!r})".format(type))
+        if type not in ('cvae', 'vae', 'jvae', 'xvae'):
+            raise NotImplementedError("types 'cvae' / 'xvae' (class-conditional prior), 'vae' (single prior) and 'jvae' (labels "
+                                      "coded into the encoder, classifier on z) are built on the native kernels (got {!r})".format(type))
         assert not (y_is_coded and type == 'vae')
         if output_distribution != 'gaussian':
             raise NotImplementedError('categorical output is outside the native-kernel contract')
@@ -205,7 +206,8 @@ class ClassificationVariationalNetwork(nn.Module):
         self.name = name
         self.job_number = job_number
         self.type = type
-        self.is_cvae, self.is_jvae, self.is_vib, self.is_vae, self.is_xvae = type == 'cvae', type == 'jvae', False, type == 'vae', False
+        self.is_cvae, self.is_jvae, self.is_vib, self.is_vae, self.is_xvae = (type == 'cvae', type == 'jvae', False, type == 'vae',
+                                                                              type == 'xvae')
         self.loss_components = self.loss_components_per_type[type]
         self.metrics = self.metrics_per_type[type]
         self.predict_methods = list(self.predict_methods_per_type[type])
@@ -258,7 +260,7 @@ class ClassificationVariationalNetwork(nn.Module):
         self.beta = beta
         self.gamma = gamma if self.y_is_decoded else None
         prior = dict(prior)
-        if self.is_cvae:                          # cvae.py:274-275: one prior component per class; 'vae': a single one
+        if self.is_cvae or self.is_xvae:          # cvae.py:274-275: one prior component per class; 'vae' / 'jvae': a single one
             prior['num_priors'] = num_labels
         self.encoder = Encoder(enc_in, num_labels, intermediate_dims=encoder, latent_dim=latent_dim,
                                y_is_coded=self.y_is_coded, dropout=dropout, sigma_output_dim=0,
@@ -546,6 +548,8 @@ class ClassificationVariationalNetwork(nn.Module):
             beta = self.beta if with_beta else 1.
             # one prior component per class: (C, N); a single prior (type 'vae'): (N,)
             losses['total'] = (cross_x.unsqueeze(0) if pr.conditional else cross_x) + beta * kd['kl']
+            if self.y_is_decoded and not (self.is_cvae or self.is_vae) and self.gamma:
+                losses['total'] = losses['total'] + self.gamma * losses['cross_y']        # cvae.py:557-563,886-889
             # importance-weighted bound: log p(x|z_l) + log p(z_l|y) - log q(z_l|x), cvae.py:672-676,793-873
             z_s = z[1:]
             if pr.conditional:

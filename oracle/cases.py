@@ -108,7 +108,12 @@ DSL_CASES['j2_n8_jvae'] = dict(net=_conv(10, type='jvae', y_is_coded=True, gamma
                                          prior=dict(distribution='gaussian', init_mean=0., var_dim='scalar')),
                                N=8, kl_var_weighting=1.0, gamma_weighting=0.5)
 
+# type='xvae': class-conditional prior as cvae, classifier on z always in the loss (cvae.py:196-199,557-563)
+DSL_CASES['x2_n8_xvae'] = dict(net=_conv(10, type='xvae', gamma=2.0, classifier=[20]), N=8, kl_var_weighting=1.0,
+                               gamma_weighting=0.5)
+
 DSL_EVAL_CASES = {
+    'ex2_n8_xvae_L2': dict(net=_conv(10, type='xvae', gamma=2.0, classifier=[20], test_latent_sampling=2), N=8),
     'ea2_n8_vae_L3': dict(net=_conv(10, type='vae', test_latent_sampling=3,
                                     prior=dict(distribution='gaussian', init_mean=0., var_dim='scalar')), N=8),
 }
