@@ -82,7 +82,8 @@ def test_conv_all_directions(cin, cout, k, s, p, op, tr, H, N):
 
 
 @pytest.mark.parametrize('cin,cout,tr,H,N', [(32, 32, True, 32, 6), (32, 64, False, 16, 9), (64, 32, True, 16, 5),
-                                             (64, 64, True, 8, 7), (48, 40, False, 16, 3), (128, 64, False, 64, 1)])
+                                             (64, 64, True, 8, 7), (48, 40, False, 16, 3), (128, 64, False, 64, 1),
+                                             (17, 33, False, 8, 1), (16, 3, True, 32, 2), (250, 32, False, 8, 3)])
 def test_split_bf16_conv_is_fp32_accurate(cin, cout, tr, H, N):
     """conv_x3.hip computes fp32 convolutions on the bf16 matrix cores (3-way exact operand split, 6 products): measured
     against an fp64 reference its error must be at the level of the fp32-MFMA kernel's own rounding (not bf16's 4e-3),
@@ -541,3 +542,35 @@ def test_dropout_kernel_and_module():
     net.eval()
     a_, b_ = net.evaluate(xb, yb)[2]['total'], net.evaluate(xb, yb)[2]['total']
     assert a_.shape == (64,)
+
+
+@pytest.mark.parametrize('cin,cout,H,N,tr', [(32, 32, 16, 5, True), (64, 64, 8, 3, True), (24, 32, 8, 1, True),
+                                             (64, 32, 32, 2, True), (32, 32, 32, 3, False), (64, 64, 16, 2, False)])
+def test_split_bf16_stride2_transposed_conv(cin, cout, H, N, tr):
+    """conv_t2_x3.hip: ConvTranspose2d(5, stride 2, padding 2, output_padding 1) forward (tr) and the dgrad of
+    Conv2d(5, stride 2, padding 2) on the bf16 matrix cores with 3-way operand splitting, against an fp64 reference
+    and against the fp32-MFMA 4-phase kernel (odd batch sizes: partially filled tiles)."""
+    from jvae_hip import lib, ops
+    L = lib.load()
+    g = torch.Generator().manual_seed(cin + cout + H + N)
+    x = torch.randn(N, cin, H, H, generator=g) * torch.exp(torch.randn(N, cin, 1, 1, generator=g))
+    if tr:       # forward of the transposed layer: small (cin) -> big (cout)
+        w = torch.randn(cin, cout, 5, 5, generator=g) / math.sqrt(cin * 25)
+        b = torch.randn(cout, generator=g)
+        ref = F.conv_transpose2d(x.double(), w.double(), b.double(), stride=2, padding=2, output_padding=1)
+        spec = ops.ConvSpec(cin, cout, 5, 2, 2, 1, True)
+        run = lambda: ops.conv_fwd_stats_raw(x.to(DEV), w.to(DEV), b.to(DEV), spec)[0]
+    else:        # dgrad of the stride-2 convolution: dy (cin = its output channels) -> dx (cout = its input channels)
+        w = torch.randn(cin, cout, 5, 5, generator=g) / math.sqrt(cin * 25)
+        ref = F.conv_transpose2d(x.double(), w.double(), stride=2, padding=2, output_padding=1)
+        spec = ops.ConvSpec(cout, cin, 5, 2, 2, 0, False)
+        run = lambda: ops.conv_dgrad_raw(x.to(DEV), w.to(DEV), spec, (N, cout, 2 * H, 2 * H))
+    old = L.jvae_conv2d_set_split_bf16(1)
+    try:
+        y1 = run()
+        L.jvae_conv2d_set_split_bf16(0)
+        y0 = run()
+    finally:
+        L.jvae_conv2d_set_split_bf16(old)
+    assert y1.shape == ref.shape
+    assert rel(y1, ref) < 3e-6 and rel(y0, ref) < 5e-6 and rel(y1, y0) < 5e-6
