@@ -214,7 +214,13 @@ def main():
                'scaling': 'weak', 'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
                'config': {'workload': WORKLOADS[a.workload][0],
                           'global_batch': world * a.batch, 'parallelism': f'dp{world}',
-                          'bn_statistics': 'synchronised over ranks' if (a.sync_bn and world > 1) else 'per-rank (local)'},
+                          'bn_statistics': 'synchronised over ranks' if (a.sync_bn and world > 1) else 'per-rank (local)',
+                          'arithmetic': ('fp32 operands, products and accumulation everywhere; the stride-1 and 4-phase 5x5 layers '
+                                         'form each fp32 product EXACTLY from 6 bf16 MFMA products of 3-way split operands '
+                                         '(csrc/conv_x3.hip; JVAE_X3=0: fp32 MFMA in every layer)'
+                                         if (a.dtype == 'f32' and os.environ.get('JVAE_X3', '1') != '0') else
+                                         ('fp32 MFMA in every layer' if a.dtype == 'f32' else
+                                          'bf16 activations / MFMA operands, fp32 accumulation, statistics, losses, optimiser'))},
                'step_mfma_frac': value / world * WORKLOADS[a.workload][1] / (MFMA_F32_PEAK if a.dtype == 'f32' else MFMA_BF16_PEAK),
                'final_loss': float(losses['total'].detach().mean())}
         if a.workload == 2 and a.dtype == 'f32':      # the roofline probe and the CPU baseline belong to the headline config
