@@ -216,7 +216,8 @@ def main():
                           'global_batch': world * a.batch, 'parallelism': f'dp{world}',
                           'bn_statistics': 'synchronised over ranks' if (a.sync_bn and world > 1) else 'per-rank (local)',
                           'arithmetic': ('fp32 operands, products and accumulation everywhere; the stride-1 and 4-phase 5x5 layers '
-                                         'form each fp32 product EXACTLY from 6 bf16 MFMA products of 3-way split operands '
+                                         'accumulate each fp32 product from 6 bf16 MFMA products of exactly 3-way split operands (dropped terms < 2^-24 of '
+                                         'the product: below fp32 rounding) '
                                          '(csrc/conv_x3.hip; JVAE_X3=0: fp32 MFMA in every layer)'
                                          if (a.dtype == 'f32' and os.environ.get('JVAE_X3', '1') != '0') else
                                          ('fp32 MFMA in every layer' if a.dtype == 'f32' else
