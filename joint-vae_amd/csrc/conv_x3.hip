@@ -9,8 +9,8 @@
 // and a product x*w is accumulated (fp32 accumulators inside the MFMA) from the six partial products whose weight is
 // >= 2^-24 of the full one: x_lo w_hi, x_hi w_lo, x_mid w_mid, x_mid w_hi, x_hi w_mid, x_hi w_hi.  Products of bf16
 // numbers are exact in fp32, the three dropped terms are <= 2^-24 |x w|: the result differs from an fp32 FMA chain
-// by less than that chain's own rounding (measured against an fp64 convolution: 2.5e-7 relative for the fp32 kernel,
-// 1e-7 for this one; tests/test_ops_gpu.py).  Six bf16 MFMAs cover K = 16 in 6*32 = 192 cycles, the fp32 MFMA needs
+// by less than that chain's own rounding (measured against an fp64 convolution on wide-dynamic-range data: 3-15e-7 of the
+// output scale for the fp32-MFMA kernel, 2-13e-7 for this one: both are the fp32 ACCUMULATION; tests/test_ops_gpu.py).  Six bf16 MFMAs cover K = 16 in 6*32 = 192 cycles, the fp32 MFMA needs
 // 8*64 = 512: the fp32-equivalent ceiling is 2.5 PFLOP/s / 6 = 417 TFLOP/s.
 //
 // Mapping (one workgroup = 4 waves = MT*128 output pixels x 32 output channels, K step = 16 input channels):
