@@ -657,7 +657,14 @@ class ClassificationVariationalNetwork(nn.Module):
                                                    kl_var_weighting=kl_var_weighting,
                                                    gamma_weighting=gamma_weighting,
                                                    current_measures=current_measures, epsilon=epsilon)
-        losses['total'].mean().backward()
+        # total.mean().backward() without the two reduction kernels of the mean nobody reads and the expand of its
+        # backward: d(mean)/d(total_i) = 1/N, handed to autograd as a cached constant (same fp32 value as torch's own)
+        tot = losses['total']
+        key = (tot.shape, tot.device)
+        if getattr(self, '_mean_grad_key', None) != key:
+            self._mean_grad = torch.ones_like(tot.detach()) / tot.numel()
+            self._mean_grad_key = key
+        torch.autograd.backward(tot, grad_tensors=self._mean_grad)
         self.optimizer.clip(self.parameters())
         self.optimizer.step()
         return losses, measures
