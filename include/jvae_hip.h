@@ -225,8 +225,9 @@ int jvae_latent_fwd_f32(const float* mu, const float* lv_raw, const float* eps, 
                         int N, int K, int L, int C, int prior, int var_dim, float tau, float alpha, float w,
                         int sampled, int has_forced, float forced_lv, void* stream);
 /* Upstream gradients (any may be NULL): gz (L+1,N,K), g_kl / g_zdist / g_vkl (N,), gmu_direct /
- * glv_direct (N,K).  gmeans (C,K) and gT (shape of T; diag/full only) are ADDED to with float atomics.
- * ws: 2*N floats for the uniform prior. */
+ * glv_direct (N,K).  gmeans (C,K) and gT (shape of T; diag/full only) are ADDED to: per-sample contributions go to
+ * the workspace and are folded per class in sample order (deterministic, no float atomics).
+ * ws: (4*N + 2*N*K) floats cover every mode. */
 int jvae_latent_bwd_f32(const float* mu, const float* lv_raw, const float* lv, const float* eps, const long long* y,
                         const float* means, const float* T,
                         const float* gz, const float* g_kl, const float* g_zdist, const float* g_vkl,

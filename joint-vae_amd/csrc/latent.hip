@@ -125,7 +125,12 @@ __global__ __launch_bounds__(256) void latent_fwd_kernel(LatentP p, float* __res
 // Backward.  Upstream: gz (L+1,N,K) [may be null], g_kl, g_zdist, g_vkl (N,) [each may be null],
 // gmu_direct / glv_direct (N,K) [may be null: gradients reaching mu / clipped log_var from other consumers].
 // Outputs: gmu, glv_raw (N,K); gd_scratch (N,K) = per-sample contribution to the gradient of its class mean (reduced in a
-// fixed order by means_grad_kernel: deterministic); gT (diag / full variance only) accumulates with float atomics.
+// fixed order by means_grad_kernel: deterministic).  The gradient of the whitening factor T (diag / full variance) is
+// deterministic as well - no float atomics: diag writes the per-sample contribution to gt_scratch (N,K), folded per class
+// in sample order by means_grad_kernel; full writes wd = tril(T).d to gt_scratch and (g_dist, g_var) to gpair (N,2), from
+// which gT_full_kernel rebuilds the rank-one terms per class in sample order.
+// Full variance: d and wd of the wave's sample are staged in LDS (2 K floats per wave) so that the per-sample cost is
+// O(K^2) (it was O(K^3): every lane recomputed every wd_i).
 __global__ __launch_bounds__(256) void latent_bwd_kernel(LatentP p, const float* __restrict__ lv,   // clipped
                                                          const float* __restrict__ gz, const float* __restrict__ g_kl,
                                                          const float* __restrict__ g_zdist, const float* __restrict__ g_vkl,
@@ -133,10 +138,13 @@ __global__ __launch_bounds__(256) void latent_bwd_kernel(LatentP p, const float*
                                                          const float* __restrict__ glv_direct,
                                                          const float* __restrict__ kl_fwd_terms,   // uniform: (N,2) = (elogq+nel, vk)
                                                          float* __restrict__ gmu, float* __restrict__ glv_raw,
-                                                         float* gd_scratch, float* gT) {
+                                                         float* gd_scratch, float* gt_scratch, float* gpair) {
+    extern __shared__ float lds_dw[];          // full variance only: per wave d[K] then wd[K]
     const int lane = threadIdx.x & 63;
-    const int n = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (n >= p.N) return;
+    const int wv = threadIdx.x >> 6;
+    const int n_raw = blockIdx.x * (blockDim.x >> 6) + wv;
+    const bool valid = n_raw < p.N;
+    const int n = valid ? n_raw : p.N - 1;     // out-of-range waves shadow the last sample and store nothing
     const int K = p.K;
     const long long cls = p.y[n];
     const float* m = p.means + (long)cls * K;
@@ -159,6 +167,24 @@ __global__ __launch_bounds__(256) void latent_bwd_kernel(LatentP p, const float*
     } else {
         uni_first = kl_fwd_terms[2 * n] >= kl_fwd_terms[2 * n + 1];
     }
+
+    const bool full = p.prior != PRIOR_UNIFORM && p.var_dim == VAR_FULL;
+    float* d_s = lds_dw + (size_t)wv * 2 * K;
+    float* wd_s = d_s + K;
+    if (full) {                                // uniform over the block: every wave takes the barriers
+        const float* Tc = p.T + (long)cls * K * K;
+        for (int k = lane; k < K; k += 64) d_s[k] = p.mu[row + k] - m[k];
+        __syncthreads();
+        for (int k = lane; k < K; k += 64) {   // wd_k = sum_{j<=k} T_kj d_j  (the forward's summation order)
+            float wd = 0.f;
+            for (int j = 0; j <= k; ++j) wd += Tc[(long)k * K + j] * d_s[j];
+            wd_s[k] = wd;
+            if (valid && gt_scratch) gt_scratch[row + k] = wd;
+        }
+        __syncthreads();
+        if (valid && gpair && lane == 0) { gpair[2 * n] = g_dist; gpair[2 * n + 1] = g_var; }
+    }
+    if (!valid) return;
 
     for (int k = lane; k < K; k += 64) {
         const float mu = p.mu[row + k];
@@ -203,24 +229,16 @@ __global__ __launch_bounds__(256) void latent_bwd_kernel(LatentP p, const float*
                 const float t = p.T[(long)cls * K + k];
                 Td = t * t * d;
                 g_lv += g_var * (__expf(lvk) * t * t - 1.f);
-                if (gT) atomicAdd(&gT[(long)cls * K + k],
-                                  g_dist * 2.f * t * d * d + g_var * (2.f * __expf(lvk) * t - 2.f / t));
+                if (gt_scratch) gt_scratch[row + k] = g_dist * 2.f * t * d * d + g_var * (2.f * __expf(lvk) * t - 2.f / t);
             } else {
                 const float* Tc = p.T + (long)cls * K * K;
-                // wd_i = sum_{j<=i} T_ij d_j ;  (T^T wd)_k = sum_{i>=k} T_ik wd_i
+                // (T^T wd)_k = sum_{i>=k} T_ik wd_i ;  pd_k = sum_{i>=k} T_ik^2
                 Td = 0.f;
                 float pd = 0.f;
                 for (int i = k; i < K; ++i) {
-                    float wdi = 0.f;
-                    for (int j = 0; j <= i; ++j) wdi += Tc[(long)i * K + j] * (p.mu[row + j] - m[j]);
                     const float t = Tc[(long)i * K + k];
-                    Td += t * wdi;
+                    Td += t * wd_s[i];
                     pd += t * t;
-                    if (gT) {
-                        float g = g_dist * 2.f * wdi * d + g_var * 2.f * __expf(lvk) * t;
-                        if (i == k) g += g_var * (-2.f / t);
-                        atomicAdd(&gT[((long)cls * K + i) * K + k], g);
-                    }
                 }
                 g_lv += g_var * (__expf(lvk) * pd - 1.f);
             }
@@ -233,6 +251,33 @@ __global__ __launch_bounds__(256) void latent_bwd_kernel(LatentP p, const float*
         const bool pass = p.has_forced ? false : (raw >= -20.f && raw <= 20.f);
         glv_raw[row + k] = pass ? g_lv : 0.f;
     }
+}
+
+// Full variance: gT[c][i][k] += sum over the samples n of class c, IN SAMPLE ORDER, of
+//   2 g_dist_n wd_ni d_nk + 2 g_var_n exp(lv_nk) T_cik - [i == k] 2 g_var_n / T_ckk          (i >= k: lower triangle)
+// One block = 256 (i, k) cells of one class; every thread walks the N samples (the class test is block-uniform).
+__global__ __launch_bounds__(256) void gT_full_kernel(const float* __restrict__ mu, const float* __restrict__ lv,
+                                                      const long long* __restrict__ y, const float* __restrict__ means,
+                                                      const float* __restrict__ T, const float* __restrict__ wd,
+                                                      const float* __restrict__ gpair, float* __restrict__ gT,
+                                                      int N, int K) {
+    const int cls = blockIdx.y;
+    const int cell = blockIdx.x * 256 + threadIdx.x;
+    if (cell >= K * K) return;
+    const int i = cell / K, k = cell % K;
+    if (i < k) return;
+    const float t = T[((long)cls * K + i) * K + k];
+    const float mk = means[(long)cls * K + k];
+    float acc = 0.f;
+    for (int n = 0; n < N; ++n) {
+        if ((int)y[n] != cls) continue;
+        const float g_dist = gpair[2 * n], g_var = gpair[2 * n + 1];
+        const float d = mu[(long)n * K + k] - mk;
+        float g = g_dist * 2.f * wd[(long)n * K + i] * d + g_var * 2.f * __expf(lv[(long)n * K + k]) * t;
+        if (i == k) g += g_var * (-2.f / t);
+        acc += g;
+    }
+    gT[((long)cls * K + i) * K + k] += acc;
 }
 
 // gmeans[cls][k] += sum over the samples n of class cls of gd[n][k]: 16 contiguous sample chunks per output are summed
@@ -355,7 +400,7 @@ int jvae_latent_fwd_f32(const float* mu, const float* lv_raw, const float* eps, 
     return 0;
 }
 
-// ws: 2*N floats (uniform prior only)
+// ws: 4*N + 2*N*K floats cover every mode (uniform terms, mean contributions, T contributions)
 int jvae_latent_bwd_f32(const float* mu, const float* lv_raw, const float* lv, const float* eps, const long long* y,
                         const float* means, const float* T,
                         const float* gz, const float* g_kl, const float* g_zdist, const float* g_vkl,
@@ -376,16 +421,35 @@ int jvae_latent_bwd_f32(const float* mu, const float* lv_raw, const float* lv, c
         hipLaunchKernelGGL(uniform_terms_kernel, dim3(cdiv(N, 4)), dim3(256), 0, st, p, lv, terms);
         JVAE_LAUNCH_CHECK();
     }
+    // workspace layout (floats): [2N uniform terms][N*K mean contributions][N*K T contributions / wd][2N (g_dist, g_var)]
+    const size_t NK = (size_t)N * K;
     float* gd = nullptr;
-    if (gmeans) {                                   // per-sample scratch behind the 2N floats of the uniform prior's terms
-        if (!ws || ws_bytes < sizeof(float) * ((size_t)2 * N + (size_t)N * K)) return JVAE_EWORKSPACE;
+    if (gmeans) {
+        if (!ws || ws_bytes < sizeof(float) * ((size_t)2 * N + NK)) return JVAE_EWORKSPACE;
         gd = (float*)ws + (size_t)2 * N;
     }
-    hipLaunchKernelGGL(latent_bwd_kernel, dim3(cdiv(N, 4)), dim3(256), 0, st, p, lv, gz, g_kl, g_zdist, g_vkl,
-                       gmu_direct, glv_direct, terms, gmu, glv_raw, gd, gT);
+    float *gts = nullptr, *gpair = nullptr;
+    const bool needT = gT && prior == PRIOR_GAUSS && var_dim != VAR_SCALAR;
+    if (needT) {
+        if (!ws || ws_bytes < sizeof(float) * ((size_t)4 * N + 2 * NK)) return JVAE_EWORKSPACE;
+        gts = (float*)ws + (size_t)2 * N + NK;
+        gpair = gts + NK;
+    }
+    const size_t lds = (prior != PRIOR_UNIFORM && var_dim == VAR_FULL) ? sizeof(float) * 4 * 2 * (size_t)K : 0;
+    if (lds > 64 * 1024) return JVAE_ENOTSUP;
+    hipLaunchKernelGGL(latent_bwd_kernel, dim3(cdiv(N, 4)), dim3(256), lds, st, p, lv, gz, g_kl, g_zdist, g_vkl,
+                       gmu_direct, glv_direct, terms, gmu, glv_raw, gd, gts, gpair);
     JVAE_LAUNCH_CHECK();
     if (gmeans) {
         hipLaunchKernelGGL(means_grad_kernel, dim3(cdiv((long)C * K, 64)), dim3(1024), 0, st, (const float*)gd, y, gmeans, N, C, K);
+        JVAE_LAUNCH_CHECK();
+    }
+    if (needT && var_dim == VAR_DIAG) {
+        hipLaunchKernelGGL(means_grad_kernel, dim3(cdiv((long)C * K, 64)), dim3(1024), 0, st, (const float*)gts, y, gT, N, C, K);
+        JVAE_LAUNCH_CHECK();
+    } else if (needT) {
+        hipLaunchKernelGGL(gT_full_kernel, dim3(cdiv((long)K * K, 256), C), dim3(256), 0, st, mu, lv, y, means, T,
+                           (const float*)gts, (const float*)gpair, gT, N, K);
         JVAE_LAUNCH_CHECK();
     }
     return 0;

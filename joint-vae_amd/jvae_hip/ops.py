@@ -687,7 +687,7 @@ class _Latent(torch.autograd.Function):
         need_T = ctx.needs_input_grad[5] and var_dim != 0
         gmeans = torch.zeros_like(means) if need_means else None
         gT = torch.zeros_like(T) if need_T else None
-        nb = 8 * N + 4 * N * mu.shape[-1]
+        nb = 16 * N + 8 * N * mu.shape[-1]
         ws = L.workspace(nb, dev)
 
         def opt(t):

@@ -119,7 +119,23 @@ DSL_EVAL_CASES = {
 }
 
 
+# Full-size workloads of BASELINE.json (configs[1], configs[2] and the per-rank batch of configs[4]): the reference runs
+# them in seconds on the CPU; the goldens are COMPACT (per-sample losses, measures, per-tensor gradient norms, small
+# gradients, parameter norms after the step - a few hundred KB) and pin the headline workload to the reference itself.
+FULL_CASES = {
+    'c2_n512': dict(net=_conv(10), N=512, kl_var_weighting=1.0, gamma_weighting=1.0),
+    'c3_n512': dict(net=_conv(100), N=512, kl_var_weighting=1.0, gamma_weighting=1.0),
+    'c3_n512_diag': dict(net=_conv(100, prior=dict(distribution='gaussian', init_mean=0., learned_means=True,
+                                                     var_dim='diag', freeze_means=0)),
+                         N=512, kl_var_weighting=1.0, gamma_weighting=1.0),
+    'c5_n256': dict(net=dict(_conv(20, K=200), input_shape=(3, 64, 64), features='conv32+', upsampler='deconv32+'),
+                    N=256, kl_var_weighting=1.0, gamma_weighting=1.0),
+}
+
+
 def get_case(name):
+    if name in FULL_CASES:
+        return copy.deepcopy(FULL_CASES[name])
     if name in DSL_EVAL_CASES:
         return copy.deepcopy(DSL_EVAL_CASES[name])
     if name in DSL_CASES:

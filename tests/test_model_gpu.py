@@ -10,7 +10,7 @@ import pytest
 import torch
 
 from oracle import jvae_oracle as O
-from oracle.cases import CASES, DSL_CASES, get_case, full_config
+from oracle.cases import CASES, DSL_CASES, FULL_CASES, get_case, full_config
 from oracle.det_init import det_inputs, load_det_state
 
 pytestmark = pytest.mark.gpu
@@ -100,6 +100,77 @@ def test_train_step_matches_reference_golden(name, golden_dir):
             assert rel(bufs[f[13:]].double(), g[f]) < 2e-5, f
 
 
+@pytest.mark.parametrize('name', list(FULL_CASES))
+def test_full_size_step_matches_reference_golden(name, golden_dir):
+    """BASELINE.json's full-size workloads (configs[1] / configs[2] at N = 512, the per-rank batch of configs[4] at
+    N = 256 in fp32) against the REFERENCE's own training step at that size (compact goldens of oracle/gen_golden.py):
+    every per-sample loss <= 1e-4 relative, labels bit-exact, the global gradient norm <= 1e-4, per-tensor gradient norms
+    <= 1e-3, and every stored gradient no further from the reference's fp64 gradient than 3 x the reference's own fp32
+    gradient is (see the comment at the backward bar)."""
+    g = np.load(os.path.join(golden_dir, name + '.npz'))
+    case = get_case(name)
+    net = build(case)
+    kw = case['net']
+    N = case['N']
+    x, y, eps = det_inputs(N, kw['input_shape'], kw['num_labels'], net.latent_sampling, kw['latent_dim'])
+    x, y, eps = x.to(DEV), y.to(DEV), eps.to(DEV)
+    net.optimizer.zero_grad()
+    x_reco, y_est, losses, meas, mu, log_var, z = net.evaluate(
+        x, y, batch=0, with_beta=True, kl_var_weighting=case['kl_var_weighting'],
+        gamma_weighting=case['gamma_weighting'], z_output=True, epsilon=eps)
+    assert rel(mu, g['mu']) < RTOL and rel(log_var, g['log_var']) < RTOL
+    xr = x_reco.detach().double().flatten(2)
+    assert rel(xr.mean(-1), g['x_reco_mean']) < RTOL and rel(xr.norm(dim=-1), g['x_reco_norm']) < RTOL
+    assert rel(z.detach().double().norm(dim=-1), g['z_norm']) < RTOL
+    for k in [f[5:] for f in g.files if f.startswith('loss.')]:
+        if np.abs(g['loss.' + k]).max() == 0:
+            assert float(losses[k].abs().max()) == 0.
+            continue
+        assert tuple(losses[k].shape) == g['loss.' + k].shape, k
+        assert rel(losses[k], g['loss.' + k]) < RTOL, k
+    for k in [f[8:] for f in g.files if f.startswith('measure.')]:
+        ref = float(g['measure.' + k])
+        assert abs(meas[k] - ref) <= 2e-4 * max(1.0, abs(ref)), (k, meas[k], ref)
+    losses['total'].mean().backward()
+    tot = float(g['total_grad_norm'])
+    got = {n: p.grad for n, p in net.named_parameters() if p.grad is not None}
+    assert set(g['grad_names']) <= set(got)
+    # The backward bar.  The goldens also hold the reference's own backward in DOUBLE precision (gen_golden.py): its
+    # fp32 gradients sit 1e-4 ... 1.5e-3 (relative L2 per tensor, largest at the first encoder layer, the far end of the
+    # chain) from the fp64 ones because ReLU pre-activations within fp32 rounding of zero take the other branch.  An
+    # independent fp32 implementation cannot be closer to the reference's fp32 gradient than both are to the exact one,
+    # so each tensor must be (a) within 1e-3 of the reference's fp32 norm, (b) for every stored tensor, element-wise L2:
+    # no further from the reference's fp64 gradient than max(3 x the reference's own fp32 distance, 3e-4).  Measured
+    # (tests/diagnostics/full_grad_diag.py): 0.7-2.0 x the reference's distance at N = 512 (worst 2.4e-3 vs 1.2e-3 on
+    # features.1.bias), 0.75-1.3 x on the 64x64 geometry; norms within 6.6e-4.
+    worst, worst_ref = 0., 0.
+    for k in g['grad_names']:
+        ref32, ref64 = float(g['gnorm.' + k]), float(g['gnorm64.' + k])
+        mine = float(got[k].double().norm())
+        if dead_bias(k, g['state_keys']):       # exact-zero gradient: the reference holds rounding noise, we hold 0
+            assert mine <= max(1e-6 * tot, 2 * ref32), k
+            continue
+        assert abs(mine - ref32) <= 1e-3 * max(ref32, 1e-3 * tot), (k, mine, ref32)
+        if 'grad64.' + k in g.files:
+            g64 = g['grad64.' + k].astype(np.float64)
+            d_ref = np.linalg.norm(g['grad.' + k].astype(np.float64) - g64) / max(ref64, 1e-4 * tot)
+            d = np.linalg.norm(got[k].detach().double().cpu().numpy() - g64) / max(ref64, 1e-4 * tot)
+            worst, worst_ref = max(worst, d), max(worst_ref, d_ref)
+            assert d <= max(3 * d_ref, 3e-4), (k, d, d_ref)
+    assert abs(tot - float(g['total_grad_norm64'])) <= 1e-5 * tot        # the reference's fp32 / fp64 norms agree ...
+    net.optimizer.clip(net.parameters())
+    assert abs(float(net.optimizer.grad_norm()) - tot) <= 1e-4 * tot
+    net.optimizer.step()
+    for n_, p in net.named_parameters():
+        ref = float(g['pnorm_after.' + n_])
+        assert abs(float(p.detach().double().norm()) - ref) <= 1e-5 * max(ref, 1.0), n_
+    bufs = dict(net.named_buffers())
+    for f in g.files:
+        if f.startswith('buffer_after.'):
+            assert rel(bufs[f[13:]].double(), g[f]) < 2e-5, f
+    print(f'{name}: worst per-tensor distance to the fp64 gradient: ours {worst:.2e}, reference fp32 {worst_ref:.2e}')
+
+
 @pytest.mark.parametrize('which,N', [(2, 64), (3, 48)])
 def test_three_steps_against_oracle(which, N):
     """Three consecutive optimiser steps on a larger batch: losses track the CPU oracle step by step."""
@@ -174,12 +245,10 @@ def test_checkpoint_roundtrip(tmp_path):
     la, _ = net.train_step(x, y, epsilon=eps)
     lb, _ = other.train_step(x, y, epsilon=eps)
     assert rel(la['total'], lb['total']) < 1e-6          # same state, same batch -> same forward
-    # after the step: a few kernels combine partial sums with float atomics (split-K of the 1x1 -> 8x8 layer's dgrad,
-    # channel sums), so two runs differ at 1e-6 in the gradients; Adam turns that into +-lr on the few weights whose
-    # gradient is ~0.  Compare in L2 and through the next forward.
+    # no float atomics on the training path (test_training_step_is_bit_reproducible): the restored model takes the
+    # SAME step bit for bit
     for (n1, p1), (n2, p2) in zip(net.named_parameters(), other.named_parameters()):
-        d = float((p1 - p2).double().norm() / (p2.double().norm() + 1e-12))
-        assert d < 2e-2, (n1, d)
+        assert torch.equal(p1, p2), n1
     _, _, l1, _ = net.evaluate(x, y, with_beta=True, epsilon=eps)
     _, _, l2, _ = other.evaluate(x, y, with_beta=True, epsilon=eps)
     assert abs(float(l1['total'].mean()) - float(l2['total'].mean())) < 2e-3 * float(l2['total'].mean())
@@ -318,14 +387,16 @@ def test_wim_finetune_step_matches_reference_golden(golden_dir):
             assert rel(bufs[f[13:]].double(), g[f]) < 2e-5, f
 
 
-def test_training_step_is_bit_reproducible():
+@pytest.mark.parametrize('name', ['c2_n8', 'c3_n8_diag', 'c3_n8_full', 'c2_n8_gamma'])
+def test_training_step_is_bit_reproducible(name):
     """Two identical models on the same batch / epsilon: gradients after the first backward and parameters after two
     optimiser steps are BIT-identical (no float atomics anywhere on the path: K-sliced products and channel / class /
-    norm reductions are folded in a fixed order; weight gradients on the side stream write disjoint slots)."""
-    case = get_case('c2_n8')
+    norm reductions are folded in a fixed order; weight gradients on the side stream write disjoint slots; the gradient of
+    a diag / full prior whitening factor is folded per class in sample order)."""
+    case = get_case(name)
     kw = case['net']
     a, b = build(case), build(case)
-    x, y, eps = (t.to(DEV) for t in det_inputs(8, kw['input_shape'], kw['num_labels'], 1, kw['latent_dim']))
+    x, y, eps = (t.to(DEV) for t in det_inputs(case['N'], kw['input_shape'], kw['num_labels'], 1, kw['latent_dim']))
     for step in range(2):
         for net in (a, b):
             net.optimizer.zero_grad()

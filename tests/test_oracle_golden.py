@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from oracle import jvae_oracle as O
-from oracle.cases import CASES, EVAL_CASES, EVAL_OOD_METHODS, WIM_CASES, get_case
+from oracle.cases import CASES, EVAL_CASES, EVAL_OOD_METHODS, FULL_CASES, WIM_CASES, get_case
 from oracle.det_init import det_inputs
 
 RTOL = 2e-5
@@ -31,7 +31,7 @@ def _dead_bias(key, state_keys):
     return nxt in set(state_keys)
 
 
-@pytest.mark.parametrize('name', list(CASES))
+@pytest.mark.parametrize('name', list(CASES) + list(FULL_CASES))
 def test_oracle_matches_reference(name, golden_dir):
     g = np.load(os.path.join(golden_dir, name + '.npz'))
     case = get_case(name)
@@ -49,8 +49,14 @@ def test_oracle_matches_reference(name, golden_dir):
     x_reco, y_est, losses, meas, mu, log_var, z = out
     _close(mu.detach(), g['mu'], what='mu')
     _close(log_var.detach(), g['log_var'], what='log_var')
-    _close(z.detach(), g['z'], what='z')
-    _close(x_reco.detach(), g['x_reco'], what='x_reco')
+    if 'x_reco' in g.files:
+        _close(z.detach(), g['z'], what='z')
+        _close(x_reco.detach(), g['x_reco'], what='x_reco')
+    else:           # compact goldens of the full-size workloads: per-image checksums of the big tensors
+        xr = x_reco.detach().double().flatten(2)
+        _close(xr.mean(-1), g['x_reco_mean'], what='x_reco_mean')
+        _close(xr.norm(dim=-1), g['x_reco_norm'], what='x_reco_norm')
+        _close(z.detach().double().norm(dim=-1), g['z_norm'], what='z_norm')
     _close(y_est.detach(), g['y_est'], rtol=1e-4, what='y_est')
     for k in [f[5:] for f in g.files if f.startswith('loss.')]:
         if k == 'var_kl' and np.abs(g['loss.var_kl']).max() == 0:
