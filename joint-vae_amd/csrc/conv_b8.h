@@ -22,7 +22,8 @@ int jvae_convt2_b8(const void* in, const float* w, const float* bias, void* out,
                    void* ws, hipStream_t st, float* stats = nullptr, int* nsplit = nullptr, const InAff* aff = nullptr);
 
 // conv_wgrad_mfma.hip
-int jvae_wgrad_slab_reduce(const float* slab, float* dw, int G, int Ca, int Cb, int accumulate, int swapflip, hipStream_t st);
+int jvae_wgrad_slab_reduce(const float* slab, float* dw, int G, int Ca, int Cb, int accumulate, int swapflip, hipStream_t st,
+                           int tapmajor = 0);
 
 // conv_wgrad_b8.hip: dW[a][b][tap] = sum Ps[n][a][u][v] Q[n][b][u*S+kh-P][v*S+kw-P] from B8 tensors
 bool jvae_conv5_wgrad_b8_ok(int Ca, int HS, int WS, int Cb, int HB, int WB, int S, int P);

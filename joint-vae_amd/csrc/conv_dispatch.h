@@ -57,6 +57,15 @@ int jvae_conv5_wgrad(const float* ps, const float* q, float* dw, int accumulate,
                      int N, int Ca, int WS, int Cb, int S, int P, float* ws, hipStream_t st,
                      const InAff* aff_p = nullptr, const InAff* aff_q = nullptr);
 
+// conv_wgrad_x3.hip: the same operator on the bf16 matrix cores (3-way exact operand split), WS in {8, 16, 32}
+bool jvae_conv5_wgrad_x3_ok(int Ca, int HS, int WS, int Cb, int HB, int WB, int S, int P);
+size_t jvae_conv5_wgrad_x3_ws_floats(int N, int Ca, int Cb, int S);
+int jvae_conv5_wgrad_x3(const float* ps, const float* q, float* dw, int accumulate, int swapflip,
+                        int N, int Ca, int WS, int Cb, int S, int P, float* ws, hipStream_t st,
+                        const InAff* aff_p = nullptr, const InAff* aff_q = nullptr);
+int jvae_wgrad_slab_reduce(const float* slab, float* dw, int G, int Ca, int Cb, int accumulate, int swapflip, hipStream_t st,
+                           int tapmajor = 0);
+
 // conv_dispatch.hip
 size_t jvae_conv_ws(const ConvGeom& g, int transposed);
 // aff (input transform, see InAff): only the implicit kernels apply it; JVAE_ENOTSUP otherwise (jvae_conv_affine_ok)

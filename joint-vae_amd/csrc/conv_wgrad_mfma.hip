@@ -201,8 +201,18 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_kernel(WgP p) {
 
 // dw[dst(i)] (+)= sum_g slab[g][i] in a fixed order (4 interleaved partial sums per output, then LDS).
 // swapflip: slab is (a, b, tap') of the role-swapped problem -> dst = (b*Ca + a)*25 + 24 - tap'.
+// tapmajor: the slab is (a, tap, b) instead of (a, b, tap) (conv_wgrad_x3.hip: lanes = channels b, coalesced slab stores).
+__device__ __forceinline__ int wgrad_dst(int i, int Ca, int Cb, int swapflip, int tapmajor) {
+    if (!swapflip && !tapmajor) return i;
+    int tap, b;
+    const int a = i / (25 * Cb);
+    if (tapmajor) { b = i % Cb; tap = (i / Cb) % 25; }
+    else { tap = i % 25; b = (i / 25) % Cb; }
+    return swapflip ? (b * Ca + a) * 25 + 24 - tap : (a * Cb + b) * 25 + tap;
+}
+
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw,
-                                                           int G, int Ca, int Cb, int accumulate, int swapflip) {
+                                                           int G, int Ca, int Cb, int accumulate, int swapflip, int tapmajor) {
     __shared__ float part[4][64];
     const int total = Ca * Cb * 25;
     const int ix = threadIdx.x & 63, gy = threadIdx.x >> 6;
@@ -214,18 +224,14 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     __syncthreads();
     if (gy != 0 || i >= total) return;
     s = (part[0][ix] + part[1][ix]) + (part[2][ix] + part[3][ix]);
-    int dst = i;
-    if (swapflip) {
-        const int tap = i % 25, b = (i / 25) % Cb, a = i / (25 * Cb);
-        dst = (b * Ca + a) * 25 + 24 - tap;
-    }
+    const int dst = wgrad_dst(i, Ca, Cb, swapflip, tapmajor);
     dw[dst] = accumulate ? dw[dst] + s : s;
 }
 
 // The same fold with 16-byte accesses (Ca*Cb*25 a multiple of 4): 16 outputs-of-4 x 16 slab lanes per workgroup, every
 // thread adds its G/16 slabs in order, the 16 partial sums are folded in a fixed order.
 __global__ __launch_bounds__(256) void wgrad_reduce4_kernel(const f32x4* __restrict__ slab, float* __restrict__ dw,
-                                                            int G, int Ca, int Cb, int accumulate, int swapflip) {
+                                                            int G, int Ca, int Cb, int accumulate, int swapflip, int tapmajor) {
     __shared__ f32x4 part[16][16];
     const int total4 = Ca * Cb * 25 / 4;
     const int ix = threadIdx.x & 15, gy = threadIdx.x >> 4;
@@ -242,12 +248,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce4_kernel(const f32x4* __restr
     s = (t[0] + t[1]) + (t[2] + t[3]);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        const int i = i4 * 4 + e;
-        int dst = i;
-        if (swapflip) {
-            const int tap = i % 25, b = (i / 25) % Cb, a = i / (25 * Cb);
-            dst = (b * Ca + a) * 25 + 24 - tap;
-        }
+        const int dst = wgrad_dst(i4 * 4 + e, Ca, Cb, swapflip, tapmajor);
         dw[dst] = accumulate ? dw[dst] + s[e] : s[e];
     }
 }
@@ -277,13 +278,14 @@ inline int pick_cb(int S, int WS, int Cb) {
 }  // namespace
 
 // dw (+)= sum over the G slabs (a, b, tap) in a fixed order; shared with the bf16 path (conv_wgrad_b8.hip)
-int jvae_wgrad_slab_reduce(const float* slab, float* dw, int G, int Ca, int Cb, int accumulate, int swapflip, hipStream_t st) {
+int jvae_wgrad_slab_reduce(const float* slab, float* dw, int G, int Ca, int Cb, int accumulate, int swapflip, hipStream_t st,
+                           int tapmajor) {
     const int total = Ca * Cb * 25;
     if (total % 4 == 0 && (reinterpret_cast<uintptr_t>(slab) & 15) == 0)
         hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3(cdiv(total / 4, 16)), dim3(256), 0, st, (const f32x4*)slab, dw, G, Ca, Cb,
-                           accumulate, swapflip);
+                           accumulate, swapflip, tapmajor);
     else
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 64)), dim3(256), 0, st, slab, dw, G, Ca, Cb, accumulate, swapflip);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 64)), dim3(256), 0, st, slab, dw, G, Ca, Cb, accumulate, swapflip, tapmajor);
     JVAE_LAUNCH_CHECK();
     return 0;
 }
@@ -309,13 +311,17 @@ static int slab_count(int N, int Ca, int Cb, int S, int WS) {
 }
 
 size_t jvae_conv5_wgrad_ws_floats(int N, int Ca, int Cb, int S, int WS) {
-    return (size_t)slab_count(N, Ca, Cb, S, WS) * Ca * Cb * 25;
+    const size_t f32 = (size_t)slab_count(N, Ca, Cb, S, WS) * Ca * Cb * 25;
+    const size_t x3 = jvae_conv5_wgrad_x3_ok(Ca, WS, WS, Cb, WS * S, WS * S, S, 2) ? jvae_conv5_wgrad_x3_ws_floats(N, Ca, Cb, S) : 0;
+    return f32 > x3 ? f32 : x3;
 }
 
 // dW (+)= ... ; swapflip: the caller passed the role-swapped problem (see wgrad_reduce_kernel).
 int jvae_conv5_wgrad(const float* ps, const float* q, float* dw, int accumulate, int swapflip,
                      int N, int Ca, int WS, int Cb, int S, int P, float* ws, hipStream_t st,
                      const InAff* aff_p, const InAff* aff_q) {
+    if (jvae_conv5_wgrad_x3_ok(Ca, WS, WS, Cb, WS * S, WS * S, S, P))      // split-bf16 arithmetic (conv_wgrad_x3.hip)
+        return jvae_conv5_wgrad_x3(ps, q, dw, accumulate, swapflip, N, Ca, WS, Cb, S, P, ws, st, aff_p, aff_q);
     const InAff none{nullptr, nullptr, 0};
     WgP p{ps, q, ws, N, Ca, Cb, P, slab_count(N, Ca, Cb, S, WS), aff_p ? *aff_p : none, aff_q ? *aff_q : none};
     int rc = JVAE_ENOTSUP;

@@ -1,0 +1,371 @@
+// Weight gradient of the 5x5 (transposed) convolutions, fp32 in / fp32 out, on the bf16 matrix cores by exact 3-way
+// operand splitting (the arithmetic of conv_x3.hip; the operator, roles and slab reduction of conv_wgrad_mfma.hip).
+//
+//   dW[a][b][kh][kw] = sum_{n,u,v} Ps[n][a][u][v] * Q[n][b][u*S + kh - P][v*S + kw - P]
+//
+// (Ps = tensor on the folded "small" grid, Q = the unfolded "big" one.  Reference: autograd of nn.Conv2d /
+// nn.ConvTranspose2d, module/vae_layers/conv.py:186-196.)
+//
+// The contraction runs over PIXELS.  Both tensors are fp32 NCHW in HBM; while a tile is staged into LDS every value is
+// (optionally) put through the deferred BatchNorm(+ReLU) of the layer input, split EXACTLY into three bf16 terms
+// (v = hi + mid + lo, conv_x3.h) and stored as three planes of 16-byte units = 8 channels of one pixel - the pixel-major
+// layout of conv_x3.hip / conv_wgrad_b8.hip.  In that layout both MFMA operands are k-major, which is what gfx950's
+// ds_read_b64_tr_b16 is made for: per 16 lanes it reads 4 pixels x 16 channels and returns them column-major, so a lane
+// receives 4 consecutive pixels of ITS channel; two such reads are one operand of v_mfma_f32_32x32x16_bf16 and a tap
+// shift is a plain 16-byte-aligned unit offset (a bf16 NCHW patch would put the tap shift at a 2-byte granularity).
+// Each fp32 product is accumulated from the six bf16 products that weigh >= 2^-24 of it (small ones first).
+//
+// A workgroup owns 32 channels `a` x one column group of (b, tap) and loops over its share of the images in tiles of
+// TPIX pixels (full rows); its 4 waves split the column tiles of 32:
+//   MODE 0 (S = 1, Cb >= 9): tile = 32 channels b x 1 tap   -> 25 tiles (wave w: taps w, w+4, ...)
+//   MODE 2 (S = 2, Cb >= 9): tile = 16 channels b x 2 taps  -> 13 tiles (the stride-2 patch is 4x the pixels: 16 channels
+//                                                              keep two workgroups per CU)
+//   MODE 1 (Cb <= 8):        tile = 8 channels b x 4 taps   ->  7 tiles (3-channel image side of the first / last layer)
+// The A fragments (3 planes x 2 transposed reads per 16 pixels) are shared by all tiles of a wave; every tile needs its
+// own B fragments.  Accumulators stay in registers over the whole image loop; each workgroup writes one fp32 slab,
+// reduced in a fixed order by jvae_wgrad_slab_reduce (deterministic, no float atomics).
+#include <stdlib.h>
+#include "common.h"
+#include "jvae_internal.h"
+#include "conv_dispatch.h"
+#include "conv_x3.h"
+
+namespace {
+
+typedef x3_bf16x8 bf16x8;
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef x3_u32x4 u32x4;
+typedef x3_f32x2 f32x2;
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+
+struct WgX3P {
+    const float* ps;     // (N, Ca, HS, WS)
+    const float* q;      // (N, Cb, HB, WB)
+    float* slab;         // (G, Ca, 25, Cb)
+    int N, Ca, Cb, P, G;
+    InAff aff_p, aff_q;  // deferred BatchNorm(+ReLU) of ps / q (whichever is the layer input; sc == nullptr: none)
+};
+
+template <int S, int WS, int MODE>
+struct WgX3Geom {
+    static constexpr int HS = WS;
+    static constexpr int TPIX = (S == 1 && WS >= 16) ? 128 : 64;
+    static constexpr int TH = TPIX / WS;
+    static constexpr int TILES = HS * WS / TPIX;
+    static constexpr int ROWS = (TH - 1) * S + 5;
+    static constexpr int WB = WS * S;
+    // patch row: image column x is padded column P + x (P halo columns on the left), so a tap reads padded column
+    // v*S + kw whatever the padding: WP = (WS-1)*S + 5 columns per row; the host checks P + WB <= WP.  Stride 2 stores the
+    // columns de-interleaved (even ones first: slot = (col & 1)*WPH + col/2) so that the pixels v, v+1, .. of one tap are
+    // consecutive slots as for stride 1.  The NCBQ channel blocks of a slot are adjacent units ([row][slot][block]): the 32
+    // lanes of one transposed read (4 pixels x NCBQ blocks x 2 halves) then cover distinct banks (a [block][row][slot]
+    // layout put all blocks on the same banks: 4-way conflicts, LDS-bound; profiles/r02_wgrad_x3_pmc_v1.json).
+    static constexpr int WP = (WS - 1) * S + 5;
+    static constexpr int WPH = (WP + 1) / 2;
+    static constexpr int WPS = S == 1 ? WP : 2 * WPH;          // slots per row
+    static constexpr int CH = ROWS * WPS;                      // slots per plane
+    static constexpr int NCBQ = MODE == 0 ? 4 : (MODE == 2 ? 2 : 1);   // 8-channel blocks of Q staged per item
+    static constexpr int QS = NCBQ * CH;                       // units per plane
+    static constexpr int PS = 4 * TPIX;                        // units per plane (32 channels a): [pixel][block]
+    static constexpr int NTILE = MODE == 0 ? 25 : (MODE == 2 ? 13 : 7);
+    static constexpr int NBT = (NTILE + 3) / 4;                // per wave
+    static constexpr int LDS_BYTES = 3 * (QS + PS) * 16;
+    static constexpr int QITEMS = NCBQ * ROWS * (WB / 2);      // staging items: 2 pixels x 8 channels
+    static constexpr int PITEMS = 4 * (TPIX / 2);
+};
+
+// HI = byte distance of 4 pixels (4 slots x the channel blocks per slot x 16 bytes)
+template <int HI>
+__device__ __forceinline__ bf16x8 tr_pair(const unsigned char* base, int off) {
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(base + off));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(base + off + HI));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+template <int S, int WS, int MODE, bool AFF>
+__global__ __launch_bounds__(256, 2) void conv5_wgrad_x3_kernel(WgX3P p) {
+    using G = WgX3Geom<S, WS, MODE>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    u32x4* Qs = reinterpret_cast<u32x4*>(lds_raw);             // [3 planes][QS]
+    u32x4* Pt = Qs + 3 * G::QS;                                // [3 planes][PS]
+    const unsigned char* Qb = lds_raw;
+    const unsigned char* Pb = lds_raw + 3 * G::QS * 16;
+    constexpr int NT8 = 8 * (G::NCBQ + 4);
+    __shared__ float ctab[AFF ? 2 * NT8 : 1];                  // (scale, shift) of this workgroup's q / ps channels
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int a0 = blockIdx.y * 32;
+    const int cbq0 = blockIdx.z * G::NCBQ;                     // first 8-channel block of Q of this workgroup
+
+    // halo columns are zeroed once and never written again (rows are rewritten per item, with zeros outside the image)
+    for (int i = tid; i < 3 * G::QS; i += 256) Qs[i] = u32x4{0u, 0u, 0u, 0u};
+    if (AFF && tid < NT8) {
+        constexpr int NQ = 8 * G::NCBQ;
+        const bool isq = tid < NQ;
+        const InAff& a = isq ? p.aff_q : p.aff_p;
+        const int ch = isq ? cbq0 * 8 + tid : a0 + (tid - NQ);
+        const bool ok = a.sc && ch < (isq ? p.Cb : p.Ca);
+        ctab[tid] = ok ? a.sc[ch] : 0.f;
+        ctab[NT8 + tid] = ok ? a.sh[ch] : 0.f;
+    }
+
+    // transposed-read roles of this lane: row (pixel) q4 of the 4x16 block, channel quad pp; cg = 16-column group
+    const int cg = (lane >> 4) & 1, q4 = (lane & 15) >> 2, pp = lane & 3;
+    const int pl = 8 * half + q4;                              // pixel of this lane inside a 16-pixel K step
+    const int aoff = (pl * 4 + cg * 2 + (pp >> 1)) * 16 + (pp & 1) * 8;
+    const int lane_pix = (pl / WS) * S * G::WPS + (pl % WS);             // slot; WS = 8: the K step spans two rows
+    static_assert(WS >= 8, "a lane's 8 pixels must lie in one row");
+
+    int boff[G::NBT];
+#pragma unroll
+    for (int t = 0; t < G::NBT; ++t) {
+        const int tile = wave + 4 * t;
+        int tap, cbl;
+        const int sub = pp & 1;
+        if (MODE == 0) { tap = tile; cbl = cg * 2 + (pp >> 1); }
+        else if (MODE == 2) { tap = tile * 2 + cg; cbl = pp >> 1; }
+        else { tap = tile * 4 + cg * 2 + (pp >> 1); cbl = 0; }
+        if (tap > 24) tap = 24;                                // unused slots: any valid address
+        const int kw = tap % 5;
+        const int tslot = S == 1 ? kw : (kw & 1) * G::WPH + (kw >> 1);
+        boff[t] = ((lane_pix + (tap / 5) * G::WPS + tslot) * G::NCBQ + cbl) * 16 + sub * 8;
+    }
+
+    f32x16 acc[G::NBT];
+#pragma unroll
+    for (int t = 0; t < G::NBT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    const int per = (p.N + p.G - 1) / p.G;
+    const int n_beg = blockIdx.x * per, n_end = min(p.N, n_beg + per);
+    constexpr int QU = (G::QITEMS + 255) / 256, PU = (G::PITEMS + 255) / 256;
+    constexpr int HB = G::HS * S;
+    constexpr int W2 = G::WB / 2;
+    const long qcs = (long)HB * G::WB, pcs = (long)G::HS * WS;  // channel strides
+    f32x2 rq[QU][8], rp[PU][8];
+
+    // Loads are unconditional (out-of-range items read a valid stand-in address and are zeroed when they are stored to
+    // LDS) so that the compiler can count the loads in flight.
+    auto gload = [&](int item) {
+        const int n = item / G::TILES, tile = item % G::TILES;
+        const int row0 = tile * G::TH;
+        const int in_row0 = row0 * S - p.P;
+#pragma unroll
+        for (int k = 0; k < QU; ++k) {
+            const int u = tid + k * 256;
+            const int c = u % G::NCBQ;                         // channel block fastest: adjacent lanes -> adjacent LDS units
+            const int xp = (u / G::NCBQ) % W2;
+            const int lr = u / (G::NCBQ * W2);
+            const int ir = in_row0 + lr, ch0 = (cbq0 + c) * 8;
+            const bool ok = u < G::QITEMS && ir >= 0 && ir < HB;
+            const float* src = p.q + (((long)n * p.Cb + ch0) * HB + (ok ? ir : 0)) * G::WB + 2 * xp;
+#pragma unroll
+            for (int ci = 0; ci < 8; ++ci)
+                rq[k][ci] = *reinterpret_cast<const f32x2*>((ok && ch0 + ci < p.Cb) ? src + ci * qcs : p.q);
+        }
+#pragma unroll
+        for (int k = 0; k < PU; ++k) {
+            const int u = tid + k * 256;
+            const int c = u % 4, px2 = u / 4;
+            const int ch0 = a0 + c * 8;
+            const bool ok = u < G::PITEMS;
+            const float* src = p.ps + (((long)n * p.Ca + ch0) * G::HS + row0) * WS + 2 * px2;
+#pragma unroll
+            for (int ci = 0; ci < 8; ++ci)
+                rp[k][ci] = *reinterpret_cast<const f32x2*>((ok && ch0 + ci < p.Ca) ? src + ci * pcs : p.ps);
+        }
+    };
+    // 2 pixels x 8 channels of fp32 -> [deferred BatchNorm] -> three bf16 planes, two 16-byte units each
+    auto split_store = [&](const f32x2 (&r)[8], bool live, int nch, const float* sc, const float* sh, int relu,
+                           bool aff, u32x4* dst0, u32x4* dst1, int plane_stride) {
+        bf16x8 s[2][3];
+#pragma unroll
+        for (int ci = 0; ci < 8; ++ci) {
+            f32x2 v = (live && ci < nch) ? r[ci] : f32x2{0.f, 0.f};
+            if (AFF && aff && live && ci < nch) {
+                v[0] = fmaf(v[0], sc[ci], sh[ci]);
+                v[1] = fmaf(v[1], sc[ci], sh[ci]);
+                if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); }
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                __bf16 a, b, c;
+                x3_split(v[j], a, b, c);
+                s[j][0][ci] = a; s[j][1][ci] = b; s[j][2][ci] = c;
+            }
+        }
+#pragma unroll
+        for (int plane = 0; plane < 3; ++plane) {
+            dst0[plane * plane_stride] = __builtin_bit_cast(u32x4, s[0][plane]);
+            dst1[plane * plane_stride] = __builtin_bit_cast(u32x4, s[1][plane]);
+        }
+    };
+    auto lstore = [&](int item) {                  // item: the work item whose data sits in rq / rp
+        const int in_row0 = (item % G::TILES) * G::TH * S - p.P;
+#pragma unroll
+        for (int k = 0; k < QU; ++k) {
+            const int u = tid + k * 256;
+            if (u < G::QITEMS) {
+                const int c = u % G::NCBQ;
+                const int xp = (u / G::NCBQ) % W2;
+                const int lr = u / (G::NCBQ * W2);
+                const int ir = in_row0 + lr;
+                const bool live = ir >= 0 && ir < HB;          // padding rows / missing channels stay exact zeros
+                const int c0 = p.P + 2 * xp, c1 = c0 + 1;      // padded columns of the two pixels
+                const int s0 = S == 1 ? c0 : (c0 & 1) * G::WPH + (c0 >> 1), s1 = S == 1 ? c1 : (c1 & 1) * G::WPH + (c1 >> 1);
+                split_store(rq[k], live, p.Cb - (cbq0 + c) * 8, AFF ? &ctab[c * 8] : ctab, AFF ? &ctab[NT8 + c * 8] : ctab, p.aff_q.relu,
+                            p.aff_q.sc != nullptr, &Qs[(lr * G::WPS + s0) * G::NCBQ + c], &Qs[(lr * G::WPS + s1) * G::NCBQ + c], G::QS);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < PU; ++k) {
+            const int u = tid + k * 256;
+            if (u < G::PITEMS) {
+                const int c = u % 4, px2 = u / 4;
+                split_store(rp[k], true, p.Ca - (a0 + c * 8), AFF ? &ctab[(G::NCBQ + c) * 8] : ctab, AFF ? &ctab[NT8 + (G::NCBQ + c) * 8] : ctab,
+                            p.aff_p.relu, p.aff_p.sc != nullptr, &Pt[(2 * px2) * 4 + c], &Pt[(2 * px2 + 1) * 4 + c], G::PS);
+            }
+        }
+    };
+
+    const int item_beg = n_beg * G::TILES, item_end = n_end * G::TILES;
+    if (item_beg < item_end) gload(item_beg);
+    for (int item = item_beg; item < item_end; ++item) {
+        __syncthreads();                           // every wave is past the fragments of the previous item
+        lstore(item);
+        __syncthreads();
+        if (item + 1 < item_end) gload(item + 1);
+        // Software-pipelined over the (K step, tile) sequence: the fragments of the NEXT slot are read before the six
+        // MFMAs of the current one are issued (hipcc would otherwise place every read right in front of its consumer and
+        // wait for it with the matrix pipe idle).  Slots beyond a wave's tiles read a valid stand-in address.
+        constexpr int KS = G::TPIX / 16;
+        bf16x8 a[2][3], b[2][3];
+        auto read_a = [&](int ks, bf16x8 (&d)[3]) {
+#pragma unroll
+            for (int plane = 0; plane < 3; ++plane) d[plane] = tr_pair<256>(Pb + plane * G::PS * 16, aoff + ks * 16 * 64);
+        };
+        auto read_b = [&](int ks, int t, bf16x8 (&d)[3]) {
+            const int pix0 = ks * 16;
+            const int qoff = ((pix0 / WS) * S * G::WPS + (pix0 % WS)) * G::NCBQ * 16;    // compile-time after unrolling
+#pragma unroll
+            for (int plane = 0; plane < 3; ++plane) d[plane] = tr_pair<64 * G::NCBQ>(Qb + plane * G::QS * 16, boff[t] + qoff);
+        };
+        read_a(0, a[0]);
+        read_b(0, 0, b[0]);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+            for (int t = 0; t < G::NBT; ++t) {
+                const int cur = (ks * G::NBT + t) & 1;
+                if (t + 1 < G::NBT) read_b(ks, t + 1, b[cur ^ 1]);
+                else if (ks + 1 < KS) { read_a(ks + 1, a[(ks + 1) & 1]); read_b(ks + 1, 0, b[cur ^ 1]); }
+                __builtin_amdgcn_sched_barrier(0);
+                if (wave + 4 * t < G::NTILE) {                                     // wave-uniform
+                    // (Ps plane, Q plane): the three small products first, then the large ones
+                    constexpr int APL[6] = {0, 2, 1, 0, 1, 0}, BPL[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+                    for (int m = 0; m < 6; ++m)
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks & 1][APL[m]], b[cur][BPL[m]], acc[t], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+
+    // slab[g][a][tap][b] (b contiguous over the lanes: coalesced); lane holds column l31, rows a = (r&3) + 8*(r>>2) + 4*half
+    float* slab = p.slab + (long)blockIdx.x * p.Ca * (p.Cb * 25);
+#pragma unroll
+    for (int t = 0; t < G::NBT; ++t) {
+        const int tile = wave + 4 * t;
+        if (tile >= G::NTILE) continue;
+        int b, tap;
+        if (MODE == 0) { b = cbq0 * 8 + l31; tap = tile; }
+        else if (MODE == 2) { b = cbq0 * 8 + (l31 & 15); tap = tile * 2 + (l31 >> 4); }
+        else { b = l31 & 7; tap = tile * 4 + (l31 >> 3); }
+        if (b >= p.Cb || tap > 24) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int a = a0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (a < p.Ca) slab[((long)a * 25 + tap) * p.Cb + b] = acc[t][r];
+        }
+    }
+}
+
+template <int S, int WS, int MODE>
+int launch_wgx3(const WgX3P& p, hipStream_t st) {
+    using G = WgX3Geom<S, WS, MODE>;
+    static_assert(G::LDS_BYTES + 2048 <= 80 * 1024, "two workgroups per CU must fit the 160 KB LDS");
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_wgrad_x3_kernel<S, WS, MODE, false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_wgrad_x3_kernel<S, WS, MODE, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    dim3 grid(p.G, (p.Ca + 31) / 32, (p.Cb + 8 * G::NCBQ - 1) / (8 * G::NCBQ));
+    if (MODE == 1) grid.z = 1;
+    if (p.aff_p.sc || p.aff_q.sc)
+        hipLaunchKernelGGL((conv5_wgrad_x3_kernel<S, WS, MODE, true>), grid, dim3(256), G::LDS_BYTES, st, p);
+    else
+        hipLaunchKernelGGL((conv5_wgrad_x3_kernel<S, WS, MODE, false>), grid, dim3(256), G::LDS_BYTES, st, p);
+    JVAE_LAUNCH_CHECK();
+    return 0;
+}
+
+inline int x3_mode(int S, int Cb) { return Cb <= 8 ? 1 : (S == 2 ? 2 : 0); }
+
+int slab_count_x3(int N, int Ca, int Cb, int S) {
+    const int mode = x3_mode(S, Cb);
+    const int gz = mode == 1 ? 1 : (mode == 2 ? (Cb + 15) / 16 : (Cb + 31) / 32);
+    const int per = ((Ca + 31) / 32) * gz;
+    int target = 512 / per;                       // ~512 workgroups in total (2 per CU), equal image counts per slab
+    if (target < 1) target = 1;
+    int imgs = (N + target - 1) / target;
+    if (imgs < 1) imgs = 1;
+    return (N + imgs - 1) / imgs;
+}
+
+int g_wgx3 = -1;             // JVAE_WGRAD_X3=0: weight gradients stay on the fp32 matrix-core kernel (A/B switch)
+
+}  // namespace
+
+bool jvae_conv5_wgrad_x3_ok(int Ca, int HS, int WS, int Cb, int HB, int WB, int S, int P) {
+    if (g_wgx3 < 0) { const char* e = getenv("JVAE_WGRAD_X3"); g_wgx3 = (e && e[0] == '0') ? 0 : 1; }
+    if (!g_wgx3 || !jvae_conv5_x3_enabled()) return false;
+    if (S != 1 && S != 2) return false;
+    if (HS != WS || HB != WB || WB != WS * S) return false;
+    if (WS != 8 && WS != 16 && WS != 32) return false;
+    if (P < 0 || P > 4 || Ca < 16 || Cb < 1) return false;
+    if (P + WB > (WS - 1) * S + 5) return false;               // the patch row holds P halo columns + the image row
+    return true;
+}
+
+size_t jvae_conv5_wgrad_x3_ws_floats(int N, int Ca, int Cb, int S) { return (size_t)slab_count_x3(N, Ca, Cb, S) * Ca * Cb * 25; }
+
+// dW (+)= ...; ps / q: fp32 NCHW; swapflip: the caller passed the role-swapped problem (dst = (b*Ca + a)*25 + 24 - tap)
+int jvae_conv5_wgrad_x3(const float* ps, const float* q, float* dw, int accumulate, int swapflip,
+                        int N, int Ca, int WS, int Cb, int S, int P, float* ws, hipStream_t st,
+                        const InAff* aff_p, const InAff* aff_q) {
+    const InAff none{nullptr, nullptr, 0};
+    WgX3P p{ps, q, ws, N, Ca, Cb, P, slab_count_x3(N, Ca, Cb, S), aff_p ? *aff_p : none, aff_q ? *aff_q : none};
+    int rc = JVAE_ENOTSUP;
+    const int mode = x3_mode(S, Cb);
+#define WGX3_CASE(S_, WS_, M_) case WS_: rc = launch_wgx3<S_, WS_, M_>(p, st); break;
+    if (mode == 1 && S == 1) {
+        switch (WS) { WGX3_CASE(1, 8, 1) WGX3_CASE(1, 16, 1) WGX3_CASE(1, 32, 1) }
+    } else if (mode == 1) {
+        switch (WS) { WGX3_CASE(2, 8, 1) WGX3_CASE(2, 16, 1) WGX3_CASE(2, 32, 1) }
+    } else if (mode == 0) {
+        switch (WS) { WGX3_CASE(1, 8, 0) WGX3_CASE(1, 16, 0) WGX3_CASE(1, 32, 0) }
+    } else {
+        switch (WS) { WGX3_CASE(2, 8, 2) WGX3_CASE(2, 16, 2) WGX3_CASE(2, 32, 2) }
+    }
+#undef WGX3_CASE
+    if (rc) return rc;
+    return jvae_wgrad_slab_reduce(ws, dw, p.G, Ca, Cb, accumulate, swapflip, st, 1);
+}

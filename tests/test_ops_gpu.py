@@ -129,6 +129,55 @@ def test_split_bf16_conv_is_fp32_accurate(cin, cout, tr, H, N):
     assert rel(out[1][2], out[0][2]) < 5e-6 and rel(out[1][3], out[0][3]) < 5e-6
 
 
+@pytest.mark.parametrize('cin,cout,s,tr,H,N', [(32, 32, 1, True, 32, 6), (32, 64, 1, False, 16, 9), (64, 32, 1, True, 16, 5),
+                                               (64, 64, 1, True, 8, 7), (32, 32, 2, False, 32, 5), (64, 64, 2, True, 8, 6),
+                                               (3, 32, 1, False, 32, 4), (32, 3, 1, False, 32, 4), (48, 40, 2, False, 16, 3),
+                                               (17, 33, 1, False, 8, 2)])
+def test_split_bf16_wgrad_is_fp32_accurate(cin, cout, s, tr, H, N):
+    """conv_wgrad_x3.hip computes the fp32 weight gradient on the bf16 matrix cores (both operands split exactly 3-way,
+    6 products, pixel-major LDS planes read with ds_read_b64_tr_b16).  Against an fp64 reference on data with a wide
+    dynamic range its error must sit at the fp32-MFMA kernel's own rounding level (not bf16's 4e-3); the two kernels agree
+    to 5e-6; with a deferred BatchNorm(+ReLU) on the layer input as well; run-to-run bit-identical."""
+    from jvae_hip import lib, ops
+    L = lib.load()
+    g = torch.Generator().manual_seed(cin * 7 + cout + H + s)
+    x = torch.randn(N, cin, H, H, generator=g) * torch.exp(2 * torch.randn(N, cin, 1, 1, generator=g))
+    wshape = (cin, cout, 5, 5) if tr else (cout, cin, 5, 5)
+    op = 1 if (tr and s == 2) else 0
+    sc = torch.rand(cin, generator=g) + 0.5
+    sh = torch.randn(cin, generator=g) * 0.5
+    spec = ops.ConvSpec(cin, cout, 5, s, 2, op, tr)
+    res = {}
+    for aff in (None, (sc, sh, True)):
+        a = x.double() if aff is None else torch.relu(x.double() * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1))
+        w64 = torch.zeros(wshape, dtype=torch.float64, requires_grad=True)
+        y64 = (F.conv_transpose2d(a, w64, None, stride=s, padding=2, output_padding=op) if tr
+               else F.conv2d(a, w64, None, stride=s, padding=2))
+        gy = torch.randn(y64.shape, generator=torch.Generator().manual_seed(5)) * \
+            torch.exp(torch.randn(N, y64.shape[1], 1, 1, generator=torch.Generator().manual_seed(6)))
+        y64.backward(gy.double())
+        affd = None if aff is None else (sc.to(DEV), sh.to(DEV), True)
+        if affd is not None and not ops.conv_affine_ok(spec, N, H, H):
+            continue
+        old = L.jvae_conv2d_set_split_bf16(1)
+        try:
+            out = {}
+            for mode in (1, 0):
+                L.jvae_conv2d_set_split_bf16(mode)
+                gw, _ = ops.conv_wgrad_raw(x.to(DEV), gy.to(DEV), spec, wshape, False, aff=affd)
+                gw2, _ = ops.conv_wgrad_raw(x.to(DEV), gy.to(DEV), spec, wshape, False, aff=affd)
+                assert torch.equal(gw, gw2)
+                out[mode] = (rel(gw, w64.grad), gw)
+        finally:
+            L.jvae_conv2d_set_split_bf16(old)
+        assert out[1][0] < 3e-6, (aff is not None, out[1][0], out[0][0])      # split bf16
+        assert out[0][0] < 5e-6, (aff is not None, out[0][0])                  # fp32 MFMA (k-ordered fmaf chain)
+        assert out[1][0] < 2 * out[0][0] + 2e-7, (out[1][0], out[0][0])
+        assert rel(out[1][1], out[0][1]) < 5e-6
+        res[aff is not None] = (out[1][0], out[0][0])
+    print(f'wgrad {cin}->{cout} s{s} tr={tr} H={H}: error vs fp64 split-bf16 / fp32-MFMA: {res}')
+
+
 @pytest.mark.parametrize('N,C,P,relu', [(8, 32, 1024, True), (5, 3, 1024, False), (16, 200, 4, True), (2, 64, 63, True)])
 def test_batchnorm_train(N, C, P, relu):
     from jvae_hip import ops
