@@ -238,19 +238,28 @@ int jvae_latent_bwd_f32(const float* mu, const float* lv_raw, const float* lv, c
 
 /* ---- reconstruction term ---------------------------------------------------------------------------
  * wmse[l][n] = mean_D((x_reco[l+1][n] - x[n])^2) / sigma^2   (mse_loss, module/losses.py:8-27, called at
- * cvae.py:649-652 on x_reco[1:]/sigma, x/sigma).  sigma: 1 float on the device, log(sigma) if sigma_is_log
- * (learned sigma, layers.py:84-89).  Backward fills ALL L+1 rows of g_x_reco (row 0 with zeros). */
+ * cvae.py:649-652 on x_reco[1:]/sigma, x/sigma).  `sigma_is_log` selects the kind of sigma (cvae.py:626-670):
+ *   0  sigma = 1 float on the device (fixed / decayed value)      1  the float is log(sigma) (learned, layers.py:84-89)
+ *   2  sigma = N floats, log sigma_n coded by the encoder         3  sigma follows each sample's own rmse: no division here
+ *      (cvae.py:631-634)                                             (the ELBO kernels normalise, cvae.py:662-666)
+ * Backward fills ALL L+1 rows of g_x_reco (row 0 with zeros); gsigma (may be NULL): 1 float (modes 0/1) or N floats (2).
+ * sigma_fwd (mode 0, may be NULL): the value sigma had in the forward pass - the reference's decay rule changes the
+ * parameter in place between forward and backward and its backward divides by sigma_fwd * sigma_now (layers.py:168). */
 int jvae_recon_fwd_f32(const float* x_reco, const float* x, const float* sigma, int sigma_is_log,
                        float* wmse, int L, int N, int D, void* stream);
-int jvae_recon_bwd_f32(const float* x_reco, const float* x, const float* sigma, int sigma_is_log,
+int jvae_recon_bwd_f32(const float* x_reco, const float* x, const float* sigma, int sigma_is_log, const float* sigma_fwd,
                        const float* g_wmse, const float* wmse, float* g_x_reco, float* gsigma, int accumulate_sigma,
                        int L, int N, int D, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- ELBO assembly (cvae.py:773-791,887-902): wmse = mean_l wmse_s; cross_x = D/2 (2 log sigma + wmse + log 2pi);
  * total = cross_x + cw * ce + beta * kl   (ce may be NULL).  Backward takes the upstream gradients of the three
- * outputs (any may be NULL) and returns g_wmse_s (L,N), g_kl, g_ce (N,) and d/d sigma of the 2 log sigma term. */
+ * outputs (any may be NULL) and returns g_wmse_s (L,N), g_kl, g_ce (N,) and d/d sigma of the 2 log sigma term.
+ * sigma_is_log: the kinds of jvae_recon_fwd_f32; kind 3 divides wmse_s by the sample's mean over l (sigma_n^2) and uses
+ * log sigma_n = log(mean)/2; its backward takes the forward's wmse_s in the `sigma` argument.  mse (N, may be NULL)
+ * receives wmse * sigma^2 per sample (the `mse` measure). */
 int jvae_elbo_fwd_f32(const float* wmse_s, const float* kl, const float* ce, const float* sigma, int sigma_is_log,
-                      float* wmse, float* cross_x, float* total, int L, int N, int D, float beta, float cw, void* stream);
+                      float* wmse, float* cross_x, float* total, float* mse, int L, int N, int D, float beta, float cw,
+                      void* stream);
 int jvae_elbo_bwd_f32(const float* g_wmse, const float* g_cx, const float* g_tot, const float* sigma, int sigma_is_log,
                       float* g_wmse_s, float* g_kl, float* g_ce, float* gsigma, int accumulate_sigma,
                       int L, int N, int D, float beta, float cw, void* ws, size_t ws_bytes, void* stream);
@@ -259,6 +268,10 @@ int jvae_elbo_bwd_f32(const float* g_wmse, const float* g_cx, const float* g_tot
  * y[i] = keep(seed, i) ? x[i] / (1 - p) : 0 with a counter-based mask (the backward pass calls it on dy with the same
  * seed).  The random stream is the kernel's own; the reference draws from torch's global generator. */
 int jvae_dropout_f32(const float* x, float* y, long n, float p, long seed, void* stream);
+/* the same with the seed in DEVICE memory (mask seed = *seed_dev + salt): nothing about the call depends on host state that
+ * changes from step to step, so a captured HIP graph draws a fresh mask at every replay once the caller advances *seed_dev
+ * on the stream. */
+int jvae_dropout_dev_f32(const float* x, float* y, long n, float p, const long long* seed_dev, long salt, void* stream);
 
 /* ---- importance-weighted bound of the evaluation path (cvae.py:672-676,793-873): li[l][c][n] = log p(x|z_l) +
  * log p(z_l|c) - log q(z_l|x) with log p(x|z_l) = -D/2 (wmse_s + 2 log sigma + log 2pi), -log q = (|eps_l|^2 + sum_k
@@ -272,7 +285,8 @@ int jvae_iws_f32(const float* wmse_s, const float* eps, const float* log_var, co
  * dict_min_distance layers.py:323-348): out[16]: [0..9] = sigma, mean x^2, mean mse, rmse, mean zdist, mean var_kl, ld-norm,
  * imut-zy, d-mind, optimiser non-finite flag; [10..15] = running means over `batch`+1 calls of xpow, mse, rmse, dB,
  * zdist, var_kl (prev = the previous call's out, NULL at batch 0); wmse has N entries, zdist / var_kl Nz (= N, or C*N
- * for the all-class evaluation).  sumsq_x = sum(x^2) from jvae_sqnorm_accum_f32; means may be NULL. */
+ * for the all-class evaluation).  sumsq_x = sum(x^2) from jvae_sqnorm_accum_f32; means may be NULL.  sigma_is_log >= 2
+ * (coded / rmse sigma): `wmse` holds the per-sample MSE itself and sigma[0] the rms value to report. */
 int jvae_measures_f32(const float* sumsq_x, long nx, const float* wmse, const float* zdist, const float* var_kl, int N, int Nz,
                       const float* sigma, int sigma_is_log, const float* means, int C, int K, const int* flag,
                       const float* prev, int batch, float* out, void* stream);

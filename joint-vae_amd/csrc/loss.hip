@@ -8,9 +8,18 @@
 
 namespace {
 
+// sigma_mode (cvae.py:626-670): 0 = one value, 1 = one log value (learned), 2 = log sigma per sample (coded by the
+// encoder: sigma[n]), 3 = sigma follows each sample's own rmse (the division happens in the ELBO kernels: 1 here)
+enum { SIG_VALUE = 0, SIG_LOG = 1, SIG_CODED = 2, SIG_RMSE = 3 };
+__device__ __forceinline__ float sigma_inv2(const float* sigma, int mode, int n) {
+    if (mode == SIG_RMSE) return 1.f;
+    const float sg = sigma[mode == SIG_CODED ? n : 0];
+    return mode == SIG_VALUE ? 1.f / (sg * sg) : __expf(-2.f * sg);
+}
+
 // one block per (l, n); x_reco row l+1 is compared with x[n]
 __global__ __launch_bounds__(256) void recon_fwd_kernel(const float* __restrict__ xr, const float* __restrict__ x,
-                                                        const float* __restrict__ sigma, int sigma_is_log,
+                                                        const float* __restrict__ sigma, int sigma_mode,
                                                         float* __restrict__ wmse, int L, int N, int D) {
     __shared__ float red[17];
     const int n = blockIdx.x, l = blockIdx.y;
@@ -27,16 +36,16 @@ __global__ __launch_bounds__(256) void recon_fwd_kernel(const float* __restrict_
         for (int i = threadIdx.x; i < D; i += blockDim.x) { const float d = a[i] - b[i]; s += d * d; }
     }
     s = block_sum(s, red);
-    if (threadIdx.x == 0) {
-        const float sg = sigma[0];
-        const float inv2 = sigma_is_log ? __expf(-2.f * sg) : 1.f / (sg * sg);
-        wmse[(long)l * N + n] = s / D * inv2;
-    }
+    if (threadIdx.x == 0) wmse[(long)l * N + n] = s / D * sigma_inv2(sigma, sigma_mode, n);
 }
 
 // gxr[l+1][n][:] = g[l][n] * 2 (xr - x) / (sigma^2 D);   gxr[0] = 0;   gsigma_partial[l*N+n] = g * dwmse/dsigma
+// sigma_fwd (mode 0 only, may be null): the value sigma had in the forward pass.  The reference's decay rule changes
+// `sigma.data` IN PLACE between forward and backward (layers.py:168, called at cvae.py:769) and autograd's saved divisor is
+// that very tensor, so its backward is 2 (x_reco - x) / (D sigma_fwd sigma_now): reproduced here (golden c2_n8_decay).
 __global__ __launch_bounds__(256) void recon_bwd_kernel(const float* __restrict__ xr, const float* __restrict__ x,
-                                                        const float* __restrict__ sigma, int sigma_is_log,
+                                                        const float* __restrict__ sigma, int sigma_mode,
+                                                        const float* __restrict__ sigma_fwd,
                                                         const float* __restrict__ g, const float* __restrict__ wmse,
                                                         float* __restrict__ gxr, float* __restrict__ gsig_part,
                                                         int L, int N, int D) {
@@ -48,8 +57,8 @@ __global__ __launch_bounds__(256) void recon_bwd_kernel(const float* __restrict_
     }
     const float* a = xr + ((long)l * N + n) * D;
     const float* b = x + (long)n * D;
-    const float sg = sigma[0];
-    const float inv2 = sigma_is_log ? __expf(-2.f * sg) : 1.f / (sg * sg);
+    float inv2 = sigma_inv2(sigma, sigma_mode, n);
+    if (sigma_mode == SIG_VALUE && sigma_fwd) inv2 = 1.f / (sigma_fwd[0] * sigma[0]);
     const float gv = g[(long)(l - 1) * N + n];
     const float c = gv * 2.f * inv2 / D;
     if ((D & 3) == 0) {
@@ -65,7 +74,7 @@ __global__ __launch_bounds__(256) void recon_bwd_kernel(const float* __restrict_
     }
     if (threadIdx.x == 0 && gsig_part) {
         const float wv = wmse[(long)(l - 1) * N + n];
-        gsig_part[(long)(l - 1) * N + n] = sigma_is_log ? gv * (-2.f * wv) : gv * (-2.f * wv / sg);
+        gsig_part[(long)(l - 1) * N + n] = sigma_mode == SIG_VALUE ? gv * (-2.f * wv / sigma[0]) : gv * (-2.f * wv);
     }
 }
 
@@ -76,6 +85,16 @@ __global__ __launch_bounds__(256) void vec_sum_kernel(const float* __restrict__ 
     for (int i = threadIdx.x; i < n; i += blockDim.x) s += v[i];
     s = block_sum(s, red);
     if (threadIdx.x == 0) out[0] = accumulate ? out[0] + s : s;
+}
+
+// out[n] (+)= sum_l part[l][n]   (coded sigma: per-sample gradient of log sigma_n)
+__global__ __launch_bounds__(256) void rows_fold_kernel(const float* __restrict__ part, float* __restrict__ out, int L, int N,
+                                                        int accumulate) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float s = accumulate ? out[n] : 0.f;
+    for (int l = 0; l < L; ++l) s += part[(long)l * N + n];
+    out[n] = s;
 }
 
 // one wave per row r of logits (R, C); target y[r % N]
@@ -133,35 +152,59 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
 //   wmse = mean_l wmse_s ; cross_x = D/2 (2 log sigma + wmse + log 2pi) ; total = cross_x + cw*ce + beta*kl
 __global__ __launch_bounds__(256) void elbo_fwd_kernel(const float* __restrict__ wmse_s, const float* __restrict__ kl,
                                                        const float* __restrict__ ce, const float* __restrict__ sigma,
-                                                       int sigma_is_log, float* __restrict__ wmse, float* __restrict__ cross_x,
-                                                       float* __restrict__ total, int L, int N, float D, float beta, float cw) {
+                                                       int sigma_mode, float* __restrict__ wmse, float* __restrict__ cross_x,
+                                                       float* __restrict__ total, float* __restrict__ mse,
+                                                       int L, int N, float D, float beta, float cw) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
     float s = 0.f;
     for (int l = 0; l < L; ++l) s += wmse_s[(long)l * N + n];
     s /= L;
-    const float ls = sigma_is_log ? sigma[0] : __logf(sigma[0]);
+    float ls, sig2;
+    if (sigma_mode == SIG_RMSE) {              // sigma_n^2 = the sample's mse over its L draws (cvae.py:662-666)
+        const float m = s;
+        float t = 0.f;
+        for (int l = 0; l < L; ++l) t += wmse_s[(long)l * N + n] / m;
+        s = t / L;                             // = 1 up to rounding, as the reference computes it
+        ls = 0.5f * __logf(m);
+        sig2 = m;
+    } else {
+        const float sg = sigma[sigma_mode == SIG_CODED ? n : 0];
+        ls = sigma_mode == SIG_VALUE ? __logf(sg) : sg;
+        sig2 = sigma_mode == SIG_VALUE ? sg * sg : __expf(2.f * sg);
+    }
     const float cx = 0.5f * D * (2.f * ls + s + 1.8378770664093453f);
     wmse[n] = s;
     cross_x[n] = cx;
     total[n] = cx + (ce ? cw * ce[n] : 0.f) + beta * kl[n];
+    if (mse) mse[n] = s * sig2;
 }
 
 // upstream g_wmse / g_cx / g_tot (N,) (any may be null) -> g_wmse_s (L,N), g_kl, g_ce (N,), gsig_part (N,)
+// sigma_mode 3: `sigma` points to the forward's wmse_s (L,N) (the per-sample mse the normalisation needs)
 __global__ __launch_bounds__(256) void elbo_bwd_kernel(const float* __restrict__ g_wmse, const float* __restrict__ g_cx,
                                                        const float* __restrict__ g_tot, const float* __restrict__ sigma,
-                                                       int sigma_is_log, float* __restrict__ g_wmse_s, float* __restrict__ g_kl,
+                                                       int sigma_mode, float* __restrict__ g_wmse_s, float* __restrict__ g_kl,
                                                        float* __restrict__ g_ce, float* __restrict__ gsig_part,
                                                        int L, int N, float D, float beta, float cw) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
     const float gt = g_tot ? g_tot[n] : 0.f;
     const float gc = (g_cx ? g_cx[n] : 0.f) + gt;
-    const float gw = ((g_wmse ? g_wmse[n] : 0.f) + gc * 0.5f * D) / L;
+    float gw;
+    if (sigma_mode == SIG_RMSE) {
+        // wmse = mean_l(w_l / m) with m = mean_l w_l is constant (= 1): only log sigma_n = log(m) / 2 carries gradient
+        float m = 0.f;
+        for (int l = 0; l < L; ++l) m += sigma[(long)l * N + n];
+        m /= L;
+        gw = gc * 0.5f * D / (m * L);
+    } else {
+        gw = ((g_wmse ? g_wmse[n] : 0.f) + gc * 0.5f * D) / L;
+    }
     for (int l = 0; l < L; ++l) g_wmse_s[(long)l * N + n] = gw;
     if (g_kl) g_kl[n] = beta * gt;
     if (g_ce) g_ce[n] = cw * gt;
-    if (gsig_part) gsig_part[n] = sigma_is_log ? gc * D : gc * D / sigma[0];
+    if (gsig_part) gsig_part[n] = sigma_mode == SIG_VALUE ? gc * D / sigma[0] : gc * D;
 }
 
 // ---- packed measures (cvae.py:619-624,689-724,747-762 + layers.py:323-348): ONE device buffer, ONE read-back -----
@@ -176,7 +219,10 @@ __global__ __launch_bounds__(256) void measures_kernel(const float* __restrict__
                                                        int batch, float* __restrict__ out) {
     __shared__ float red[17];
     const int tid = threadIdx.x;
-    const float sg = sigma_is_log ? __expf(sigma[0]) : sigma[0];
+    // sigma_mode 0 / 1: `wmse` holds wmse, sigma the (log) value; >= 2 (coded / rmse sigma): `wmse` holds the per-sample
+    // MSE already and sigma[0] the rms value to report
+    const float sg = sigma_is_log == 1 ? __expf(sigma[0]) : sigma[0];
+    const float mse_scale = sigma_is_log >= 2 ? 1.f : sg * sg;
     float a = 0.f, b = 0.f, c = 0.f;
     for (int i = tid; i < N; i += blockDim.x) a += wmse[i];
     for (int i = tid; i < Nz; i += blockDim.x) { b += zdist[i]; c += var_kl[i]; }
@@ -226,7 +272,7 @@ __global__ __launch_bounds__(256) void measures_kernel(const float* __restrict__
         }
     }
     if (tid == 0) {
-        const float mse = a / N * sg * sg;
+        const float mse = a / N * mse_scale;
         out[0] = sg;
         out[1] = sumsq_x[0] / nx;
         out[2] = mse;
@@ -273,9 +319,19 @@ __global__ __launch_bounds__(256) void iws_rows_kernel(const float* __restrict__
     }
     s = wave_sum(s);
     if (lane == 0) {
-        const float log_sigma = sigma_is_log ? sigma[0] : logf(sigma[0]);
+        float w = wmse_s[row], log_sigma;
+        if (sigma_is_log == SIG_RMSE) {        // sigma_n^2 = mean over the draws of the sample's mse
+            float m = 0.f;
+            for (int l = 0; l < L; ++l) m += wmse_s[(long)l * N + n];
+            m /= L;
+            w /= m;
+            log_sigma = 0.5f * logf(m);
+        } else {
+            const float sg = sigma[sigma_is_log == SIG_CODED ? n : 0];
+            log_sigma = sigma_is_log == SIG_VALUE ? logf(sg) : sg;
+        }
         const float LOG2PI = 1.8378770664093453f;
-        rows[row] = -0.5f * D * (wmse_s[row] + 2.f * log_sigma + LOG2PI) + 0.5f * s + 0.5f * (float)K * LOG2PI;
+        rows[row] = -0.5f * D * (w + 2.f * log_sigma + LOG2PI) + 0.5f * s + 0.5f * (float)K * LOG2PI;
     }
 }
 
@@ -305,8 +361,11 @@ __device__ __forceinline__ unsigned dropout_hash(unsigned long long seed, unsign
     return (unsigned)(z >> 32);
 }
 
+// seed_dev (may be null): the seed lives in device memory (advanced by the caller on the stream: graph-capturable, no host
+// read-back); the mask seed is seed + *seed_dev
 __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, long n, float p,
-                                                      unsigned long long seed) {
+                                                      unsigned long long seed, const long long* __restrict__ seed_dev) {
+    if (seed_dev) seed += (unsigned long long)seed_dev[0];
     const unsigned thr = (unsigned)fminf(p * 4294967296.f, 4294967295.f);
     const float scale = 1.f / (1.f - p);
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
@@ -319,7 +378,7 @@ extern "C" {
 
 int jvae_recon_fwd_f32(const float* x_reco, const float* x, const float* sigma, int sigma_is_log,
                        float* wmse, int L, int N, int D, void* stream) {
-    if (!x_reco || !x || !sigma || !wmse || L < 0 || N < 0 || D <= 0) return JVAE_EINVAL;
+    if (!x_reco || !x || !sigma || !wmse || L < 0 || N < 0 || D <= 0 || sigma_is_log < 0 || sigma_is_log > 3) return JVAE_EINVAL;
     if (N == 0 || L == 0) return 0;
     hipLaunchKernelGGL(recon_fwd_kernel, dim3(N, L), dim3(256), 0, (hipStream_t)stream, x_reco, x, sigma, sigma_is_log,
                        wmse, L, N, D);
@@ -327,18 +386,23 @@ int jvae_recon_fwd_f32(const float* x_reco, const float* x, const float* sigma, 
     return 0;
 }
 
-// gsigma (1 float, may be null) receives sum over (l,n) of g * dwmse/dsigma; ws: L*N floats when gsigma != null
-int jvae_recon_bwd_f32(const float* x_reco, const float* x, const float* sigma, int sigma_is_log,
+// gsigma (may be null): modes 0 / 1: 1 float = sum over (l,n) of g * dwmse/dsigma; mode 2: N floats (per-sample log sigma);
+// mode 3: must be null.  ws: L*N floats when gsigma != null.  sigma_fwd: see recon_bwd_kernel (mode 0, may be null).
+int jvae_recon_bwd_f32(const float* x_reco, const float* x, const float* sigma, int sigma_is_log, const float* sigma_fwd,
                        const float* g_wmse, const float* wmse, float* g_x_reco, float* gsigma, int accumulate_sigma,
                        int L, int N, int D, void* ws, size_t ws_bytes, void* stream) {
     if (!x_reco || !x || !sigma || !g_wmse || !wmse || !g_x_reco || L < 0 || N < 0 || D <= 0) return JVAE_EINVAL;
+    if (sigma_is_log < 0 || sigma_is_log > 3 || (sigma_is_log == SIG_RMSE && gsigma)) return JVAE_EINVAL;
     if (gsigma && (!ws || ws_bytes < sizeof(float) * (size_t)L * N)) return JVAE_EWORKSPACE;
     if (N == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(recon_bwd_kernel, dim3(N, L + 1), dim3(256), 0, st, x_reco, x, sigma, sigma_is_log, g_wmse, wmse,
-                       g_x_reco, gsigma ? (float*)ws : nullptr, L, N, D);
+    hipLaunchKernelGGL(recon_bwd_kernel, dim3(N, L + 1), dim3(256), 0, st, x_reco, x, sigma, sigma_is_log, sigma_fwd, g_wmse,
+                       wmse, g_x_reco, gsigma ? (float*)ws : nullptr, L, N, D);
     JVAE_LAUNCH_CHECK();
-    if (gsigma) {
+    if (gsigma && sigma_is_log == SIG_CODED) {
+        hipLaunchKernelGGL(rows_fold_kernel, dim3(cdiv(N, 256)), dim3(256), 0, st, (const float*)ws, gsigma, L, N, accumulate_sigma);
+        JVAE_LAUNCH_CHECK();
+    } else if (gsigma) {
         hipLaunchKernelGGL(vec_sum_kernel, dim3(1), dim3(256), 0, st, (const float*)ws, gsigma, L * N, accumulate_sigma);
         JVAE_LAUNCH_CHECK();
     }
@@ -379,27 +443,34 @@ int jvae_act_bwd_f32(const float* dy, const float* y, float* dx, long n, int kin
 }
 
 int jvae_elbo_fwd_f32(const float* wmse_s, const float* kl, const float* ce, const float* sigma, int sigma_is_log,
-                      float* wmse, float* cross_x, float* total, int L, int N, int D, float beta, float cw, void* stream) {
+                      float* wmse, float* cross_x, float* total, float* mse, int L, int N, int D, float beta, float cw,
+                      void* stream) {
     if (!wmse_s || !kl || !sigma || !wmse || !cross_x || !total || L < 1 || N < 0 || D <= 0) return JVAE_EINVAL;
+    if (sigma_is_log < 0 || sigma_is_log > 3) return JVAE_EINVAL;
     if (N == 0) return 0;
     hipLaunchKernelGGL(elbo_fwd_kernel, dim3(cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, wmse_s, kl, ce, sigma,
-                       sigma_is_log, wmse, cross_x, total, L, N, (float)D, beta, cw);
+                       sigma_is_log, wmse, cross_x, total, mse, L, N, (float)D, beta, cw);
     JVAE_LAUNCH_CHECK();
     return 0;
 }
 
-// gsigma (1 float, may be null): sum_n (g_cx + g_tot) * D [/ sigma]; ws: N floats when gsigma != null
+// gsigma (may be null): modes 0 / 1: 1 float = sum_n (g_cx + g_tot) * D [/ sigma]; mode 2: N floats, ADDED to when
+// accumulate_sigma; mode 3: must be null and `sigma` points to the forward's wmse_s (L,N).  ws: N floats when gsigma != null
 int jvae_elbo_bwd_f32(const float* g_wmse, const float* g_cx, const float* g_tot, const float* sigma, int sigma_is_log,
                       float* g_wmse_s, float* g_kl, float* g_ce, float* gsigma, int accumulate_sigma,
                       int L, int N, int D, float beta, float cw, void* ws, size_t ws_bytes, void* stream) {
     if (!sigma || !g_wmse_s || L < 1 || N < 0 || D <= 0) return JVAE_EINVAL;
+    if (sigma_is_log < 0 || sigma_is_log > 3 || (sigma_is_log == SIG_RMSE && gsigma)) return JVAE_EINVAL;
     if (gsigma && (!ws || ws_bytes < sizeof(float) * (size_t)N)) return JVAE_EWORKSPACE;
     if (N == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(elbo_bwd_kernel, dim3(cdiv(N, 256)), dim3(256), 0, st, g_wmse, g_cx, g_tot, sigma, sigma_is_log,
                        g_wmse_s, g_kl, g_ce, gsigma ? (float*)ws : nullptr, L, N, (float)D, beta, cw);
     JVAE_LAUNCH_CHECK();
-    if (gsigma) {
+    if (gsigma && sigma_is_log == SIG_CODED) {
+        hipLaunchKernelGGL(rows_fold_kernel, dim3(cdiv(N, 256)), dim3(256), 0, st, (const float*)ws, gsigma, 1, N, accumulate_sigma);
+        JVAE_LAUNCH_CHECK();
+    } else if (gsigma) {
         hipLaunchKernelGGL(vec_sum_kernel, dim3(1), dim3(256), 0, st, (const float*)ws, gsigma, N, accumulate_sigma);
         JVAE_LAUNCH_CHECK();
     }
@@ -411,7 +482,18 @@ int jvae_dropout_f32(const float* x, float* y, long n, float p, long seed, void*
     if (n < 0 || !(p >= 0.f && p < 1.f) || (n > 0 && (!x || !y))) return JVAE_EINVAL;
     if (n == 0) return 0;
     long b = (n + 255) / 256;
-    hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)(b > 8192 ? 8192 : b)), dim3(256), 0, (hipStream_t)stream, x, y, n, p, (unsigned long long)seed);
+    hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)(b > 8192 ? 8192 : b)), dim3(256), 0, (hipStream_t)stream, x, y, n, p,
+                       (unsigned long long)seed, (const long long*)nullptr);
+    JVAE_LAUNCH_CHECK();
+    return 0;
+}
+
+int jvae_dropout_dev_f32(const float* x, float* y, long n, float p, const long long* seed_dev, long salt, void* stream) {
+    if (n < 0 || !(p >= 0.f && p < 1.f) || !seed_dev || (n > 0 && (!x || !y))) return JVAE_EINVAL;
+    if (n == 0) return 0;
+    long b = (n + 255) / 256;
+    hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)(b > 8192 ? 8192 : b)), dim3(256), 0, (hipStream_t)stream, x, y, n, p,
+                       (unsigned long long)salt, seed_dev);
     JVAE_LAUNCH_CHECK();
     return 0;
 }

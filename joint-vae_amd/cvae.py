@@ -252,9 +252,12 @@ class ClassificationVariationalNetwork(nn.Module):
             self.sigma = Sigma(**sigma)
         else:
             self.sigma = Sigma(value=sigma)
-        if self.sigma.coded or self.sigma.per_dim or self.sigma.is_rmse:
-            raise NotImplementedError('coded / per-dimension / rmse sigma are outside the native-kernel contract '
-                                      '(fixed, decayed and learned scalar sigma are built)')
+        if self.sigma.per_dim:
+            # The reference itself cannot run one: cvae.py:649 divides (L,N,C,H,W) by a (C,H,W) sigma but cvae.py:789 adds
+            # its (C,H,W) log to the (N,) wmse - `RuntimeError: The size of tensor a (N) must match ...` for a learned and for
+            # a coded per-dimension sigma alike (probed on the reference in the build container).  Same outcome here, earlier.
+            raise NotImplementedError('per-dimension sigma: the reference fails on it as well (shape mismatch at '
+                                      'cvae.py:789); scalar fixed / decayed / learned / rmse / coded sigma are built')
 
         test_latent_sampling = test_latent_sampling or latent_sampling
         self.beta = beta
@@ -263,7 +266,8 @@ class ClassificationVariationalNetwork(nn.Module):
         if self.is_cvae or self.is_xvae:          # cvae.py:274-275: one prior component per class; 'vae' / 'jvae': a single one
             prior['num_priors'] = num_labels
         self.encoder = Encoder(enc_in, num_labels, intermediate_dims=encoder, latent_dim=latent_dim,
-                               y_is_coded=self.y_is_coded, dropout=dropout, sigma_output_dim=0,
+                               y_is_coded=self.y_is_coded, dropout=dropout,
+                               sigma_output_dim=self.sigma.output_dim if self.sigma.coded else 0,        # cvae.py:283
                                forced_variance=encoder_forced_variance, sampling_size=latent_sampling, prior=prior,
                                activation=activation, sampling=latent_sampling > 1 or beta > 0)
 
@@ -412,6 +416,16 @@ class ClassificationVariationalNetwork(nn.Module):
             x_features = self._features_of(x)
         return self.forward_from_features(x_features, None if y is None else y.view(*lead), x, **kw)
 
+    def _dump_after_encoder_error(self, err, x, y):
+        """cvae.py:476-488: a ValueError out of the encoder saves the model and the offending batch under
+        log/dump-<job_number> and is re-raised.  (The reference's own NaN probe that used to raise it is commented out,
+        layers.py:381-386; the contract is kept for encoders / priors that do raise.)"""
+        where = os.path.join('log', 'dump-{}'.format(self.job_number))
+        self.save(where)
+        torch.save(x, os.path.join(where, 'x.pt'))
+        torch.save(y, os.path.join(where, 'y.pt'))
+        logging.error('Error %s, net dumped in %s', str(err), where)
+
     def _decode(self, z):
         u = self.decoder(z)
         x_ = self.imager(u.reshape(-1, *self.imager.input_shape))
@@ -427,7 +441,11 @@ class ClassificationVariationalNetwork(nn.Module):
         lead = x_features.shape[:x_features.dim() - len(self.encoder.input_shape)]
         flat = x_features.reshape(*lead, -1)
         y1h = None if (y is None or not self.y_is_coded) else onehot_encoding(y, self.num_labels).float()
-        mu, log_var, z, eps, sigma = self.encoder(flat, y1h, epsilon=epsilon)
+        try:
+            mu, log_var, z, eps, sigma = self.encoder(flat, y1h, epsilon=epsilon)
+        except ValueError as err:
+            self._dump_after_encoder_error(err, x, y)
+            raise
         x_, logits = self._decode(z)
         out = (x_.view(self.latent_sampling + 1, *lead, *self.input_shape), logits)
         if z_output:
@@ -464,20 +482,24 @@ class ClassificationVariationalNetwork(nn.Module):
 
         feats = self._features_of(x).reshape(N, -1)
         y1h = onehot_encoding(y, self.num_labels).float() if self.y_is_coded else None
-        mu, log_var, z, eps, _, terms = self.encoder.encode(feats, y1h, y, kl_var_weighting, epsilon)
+        try:
+            mu, log_var, z, eps, sigma_coded, terms = self.encoder.encode(feats, y1h, y, kl_var_weighting, epsilon)
+        except ValueError as err:
+            self._dump_after_encoder_error(err, x, y)
+            raise
         if self.training and self.optimizer._world > 1 and z.requires_grad:
             # data-parallel: the decoder's gradients are final once d(loss)/dz exists -> start their all-reduce there
             z.register_hook(self._early_reduce_hook)
         x_, logits = self._decode(z)
         x_reco = x_.view(L + 1, N, *self.input_shape)
 
-        s = self.sigma
-        wmse_s = ops.recon_wmse(x_reco, x, s, s.is_log)                     # (L, N)
+        s, s_kind, sigma_rms = self._sigma_operand(sigma_coded, N)
+        wmse_s = ops.recon_wmse(x_reco, x, s, s_kind, snapshot=bool(self.training and self.sigma.decay))     # (L, N)
         ce = None
         if self.y_is_decoded:
             ce = x_loss(y, logits, batch_mean=False)                         # all L+1 rows, as cvae.py:738 does
-        wmse, cross_x, total = ops.elbo(wmse_s, terms['kl'], ce if cross_y_weight else None, s, s.is_log, D,
-                                        self.beta if with_beta else 1., float(cross_y_weight or 0.))
+        wmse, cross_x, total, mse = ops.elbo(wmse_s, terms['kl'], ce if cross_y_weight else None, s, s_kind, D,
+                                             self.beta if with_beta else 1., float(cross_y_weight or 0.), with_mse=True)
         losses = {'kl': terms['kl'], 'zdist': terms['distance'], 'var_kl': terms['var_kl']}
         dictionary = self.encoder.prior.mean if self.encoder.prior.conditional else None
         if dictionary is not None:
@@ -490,7 +512,7 @@ class ClassificationVariationalNetwork(nn.Module):
 
         prev = current_measures._dev if isinstance(current_measures, Measures) else self._upload_measures(
             current_measures, x.device) if (current_measures and batch) else None
-        packed = self._pack_measures(x, wmse, terms, dictionary, prev, batch)
+        packed = self._pack_measures(x, wmse, terms, dictionary, prev, batch, mse=mse, sigma_rms=sigma_rms, sigma_t=s)
         if self.training:
             if self.sigma.decay and not self.sigma.learned:                  # the decay rule computes with the rmse now
                 from jvae_hip import lib as _lib
@@ -526,15 +548,15 @@ class ClassificationVariationalNetwork(nn.Module):
         with torch.no_grad():
             feats = self._features_of(x).reshape(N, -1)
             dummy = torch.zeros(N, dtype=torch.int64, device=x.device)
-            mu, log_var, z, eps, _, _ = self.encoder.encode(feats, None, dummy, 1., epsilon)
+            mu, log_var, z, eps, sigma_coded, _ = self.encoder.encode(feats, None, dummy, 1., epsilon)
             x_, logits = self._decode(z)
             x_reco = x_.view(L + 1, N, *self.input_shape)
-            s = self.sigma
-            wmse_s = ops.recon_wmse(x_reco, x, s, s.is_log)                               # (L, N)
+            s, s_kind, sigma_rms = self._sigma_operand(sigma_coded, N)
+            wmse_s = ops.recon_wmse(x_reco, x, s, s_kind)                                 # (L, N)
             y_all = torch.arange(C, device=x.device).unsqueeze(1).expand(C, N)
             kd = pr.kl(mu, log_var, y=y_all if pr.conditional else None)                  # (C, N) each
             zero_kl = torch.zeros(N, device=x.device)
-            wmse, cross_x, _ = ops.elbo(wmse_s, zero_kl, None, s, s.is_log, D, 1., 0.)
+            wmse, cross_x, _, mse = ops.elbo(wmse_s, zero_kl, None, s, s_kind, D, 1., 0., with_mse=True)
             losses = {'kl': kd['kl'], 'zdist': kd['distance'], 'var_kl': kd['var_kl']}
             dictionary = pr.mean if pr.conditional else None
             terms = {'distance': kd['distance'].reshape(-1), 'var_kl': kd['var_kl'].reshape(-1)}
@@ -559,9 +581,9 @@ class ClassificationVariationalNetwork(nn.Module):
             else:
                 log_pz = pr.log_density(z_s, None)                                        # (L, N)
             # rows + max / mean-exp fold over the L samples in one kernel pair (jvae_iws_f32)
-            losses['iws'] = ops.iws(wmse_s, eps, log_var, log_pz, s, s.is_log, D)
+            losses['iws'] = ops.iws(wmse_s, eps, log_var, log_pz, s, s_kind, D)
             prev = current_measures._dev if isinstance(current_measures, Measures) else None
-            packed = self._pack_measures(x, wmse, terms, dictionary, prev, batch)
+            packed = self._pack_measures(x, wmse, terms, dictionary, prev, batch, mse=mse, sigma_rms=sigma_rms, sigma_t=s)
         measures = Measures(packed, dictionary is not None, _grad_nan_exit)
         out = (x_reco, logits[1:].mean(0), losses, measures)
         if z_output:
@@ -632,8 +654,36 @@ class ClassificationVariationalNetwork(nn.Module):
             t[i] = float(current.get(k, 0.))
         return t.to(device, non_blocking=True)
 
-    def _pack_measures(self, x, wmse, terms, dictionary, prev, batch):
+    def _sigma_operand(self, sigma_coded, N):
+        """What the loss kernels get as `sigma` (cvae.py:626-646): (tensor, kind, rms) - rms is the device scalar reported
+        as the `sigma` measure for the coded / rmse kinds (the parameter's value BEFORE this batch updates it: cvae.py:624),
+        None otherwise (the measures kernel derives it from the parameter).  A coded sigma is also stored into the
+        parameter (batch mean of the coded log sigma: Sigma.update(v=...), cvae.py:631-634)."""
+        sg = self.sigma
+        if not (sg.coded or sg.is_rmse):
+            return sg, (ops.SIGMA_LOG if sg.is_log else ops.SIGMA_VALUE), None
+        with torch.no_grad():
+            d = sg.data
+            rms = ((2 * d).exp() if sg.is_log else d * d).mean().sqrt().reshape(1)
+        if sg.is_rmse:
+            return sg, ops.SIGMA_RMSE, rms
+        per_sample = sigma_coded.reshape(-1, *sg.output_dim)
+        sg.update(v=per_sample.detach())
+        return per_sample.reshape(N), ops.SIGMA_CODED, rms
+
+    def _pack_measures(self, x, wmse, terms, dictionary, prev, batch, mse=None, sigma_rms=None, sigma_t=None):
         """Every scalar evaluate() reports, computed by one kernel into one 16-float device buffer."""
+        if sigma_rms is not None:
+            if self.sigma.coded:
+                # sic (cvae.py:668): wmse (N,) times sigma^2 (N,1,1,1) broadcasts to (N,1,1,N) in the reference; the mean of
+                # that - the only use of `mse` with a coded sigma - is mean(wmse) * mean(sigma^2), reproduced here
+                with torch.no_grad():
+                    mse = (wmse.detach().mean() * (2 * sigma_t.detach()).exp().mean()).expand(wmse.numel()).contiguous()
+            return self._pack_measures_raw(x, mse.detach(), terms, dictionary, prev, batch, sigma_rms, 2)
+        return self._pack_measures_raw(x, wmse.detach(), terms, dictionary, prev, batch, self.sigma.detach(),
+                                       int(self.sigma.is_log))
+
+    def _pack_measures_raw(self, x, wmse, terms, dictionary, prev, batch, sigma_t, sigma_kind):
         from jvae_hip import lib as _lib
         with torch.no_grad():
             if getattr(self, '_scratch', None) is None or self._scratch.device != x.device:
@@ -641,9 +691,9 @@ class ClassificationVariationalNetwork(nn.Module):
             # logging only: off the critical path -> side stream (the C x C dictionary diagnostics take ~0.2 ms at C = 100)
             main, side = torch.cuda.current_stream(x.device), _lib.side_stream(x.device)
             side.wait_stream(main)
-            args = (x, wmse.detach(), terms['distance'].detach(), terms['var_kl'].detach(), self.sigma.detach())
+            args = (x, wmse, terms['distance'].detach(), terms['var_kl'].detach(), sigma_t)
             with torch.cuda.stream(side):
-                packed = ops.measures(*args, self.sigma.is_log, None if dictionary is None else dictionary.detach(),
+                packed = ops.measures(*args, sigma_kind, None if dictionary is None else dictionary.detach(),
                                       self.optimizer.nonfinite_flag(), self._scratch, prev, batch)
             for t in args:
                 t.record_stream(side)
@@ -719,10 +769,12 @@ class ClassificationVariationalNetwork(nn.Module):
                     batch_size=100, test_batch_size=100, validation=4096, device=None, testset=None, oodsets=None,
                     acc_methods=None, fine_tuning=False, warmup=[0, 0], warmup_gamma=[0, 0], latent_sampling=None,
                     validation_sample_size=1024, full_test_every=10, ood_detection_every=10, train_accuracy=False,
-                    save_dir=None, outputs=None, signal_handler=None):
+                    save_dir=None, outputs=None, signal_handler=None, report_every=10):
         """Training loop with the reference's signature (cvae.py:2081-2104).  `trainset` is any map-style dataset of
         (x in [0,1] float tensor, int label); the periodic accuracy / OOD phases of the reference are out of
-        scope and skipped."""
+        scope and skipped.  `outputs.results` gets the running batch-mean losses the reference prints
+        (cvae.py:2463-2479), refreshed from the device every `report_every` batches (extra keyword, default 10) so that
+        the loop does not synchronise per batch."""
         if isinstance(trainset, str):
             raise NotImplementedError('named torchvision datasets are host-side plumbing outside this build: '
                                       'pass a torch.utils.data.Dataset')
@@ -744,22 +796,31 @@ class ClassificationVariationalNetwork(nn.Module):
             w_kl = max(0., min(1., (epoch + 1 - warmup[0]) / (warmup[1] + 1)))
             w_gamma = max(0., min(1., (epoch + 1 - warmup_gamma[0]) / (warmup_gamma[1] + 1)))
             t0 = time.time()
-            measures, sums, nb = None, {}, 0
+            measures, nb = None, 0
+            keys, acc = None, None          # running sums of the batch means of every loss: ONE device vector
+            shown = {}
             for i, (x, y) in enumerate(loader):
                 x, y = x.to(device), y.to(device)
                 losses, measures = self.train_step(x, y, batch=i, current_measures=measures,
                                                    kl_var_weighting=w_kl, gamma_weighting=w_gamma)
-                for k, v in losses.items():
-                    sums[k] = v.detach().mean() + sums.get(k, 0.)
+                if keys is None:
+                    keys = list(losses)
+                    acc = torch.zeros(len(keys), device=x.device)
+                # one small kernel per batch (stack of means) instead of the reference's .item() per loss (cvae.py:2463-2469)
+                acc += torch.stack([losses[k].detach().mean() for k in keys])
                 nb = i + 1
                 if outputs is not None and hasattr(outputs, 'results'):
+                    if i % report_every == 0 or i + 1 == len(loader):
+                        host = (acc / nb).tolist()                    # the only read-back of the loop: every k batches
+                        shown = dict(zip(keys, host))
                     outputs.results(i, len(loader), epoch + 1, epochs, preambule='train',
-                                    losses={k: float('nan') for k in self.loss_components},
-                                    metrics={k: measures[k] for k in self.metrics},
+                                    losses={k: shown.get(k, float('nan')) for k in self.loss_components},
+                                    metrics={k: measures[k] for k in self.metrics} if (i % report_every == 0 or i + 1 == len(loader))
+                                    else {k: float('nan') for k in self.metrics},
                                     accuracy={k: np.nan for k in self.predict_methods},
                                     time_per_i=(time.time() - t0) / (i + 1), batch_size=batch_size, end_of_epoch='\n')
             self.eval()
-            mean_loss = {k: (v / max(nb, 1)).item() for k, v in sums.items()}
+            mean_loss = dict(zip(keys or [], (acc / max(nb, 1)).tolist() if acc is not None else []))
             self.train_history[epoch] = {'train_loss': mean_loss, 'train_measures': dict(measures or {}),
                                          'lr': self.optimizer.lr}
             self.train_history['epochs'] += 1
@@ -793,14 +854,21 @@ class ClassificationVariationalNetwork(nn.Module):
         return dir_name
 
     @classmethod
-    def load(cls, dir_name, build_module=True, load_state=True, load_net=True, load_test=True, strict=True,
+    def load(cls, dir_name, build_module=True, load_state=True, load_train=True, load_test=True, strict=True,
              device=None, **kw):
         """Rebuild a model from a job directory written by save() of this class OR of the reference
         (cvae.py:2677-2857): params.json + train_params.json give the constructor arguments, state.pth /
-        optimizer.pth the tensors."""
-        def read(name):
-            with open(os.path.join(dir_name, name)) as f:
-                return json.load(f)
+        optimizer.pth the tensors; history.json / test.json / ood.json the training record (`trained` =
+        history['epochs'], and the learning-rate schedule is fast-forwarded by that many epochs: cvae.py:2815-2851)."""
+        def read(name, int_keys=False, default=None):
+            path = os.path.join(dir_name, name)
+            if default is not None and not os.path.exists(path):
+                return default
+            with open(path) as f:
+                d = json.load(f)
+            if int_keys:                         # utils/save_load/misc.py:58-66 (presumed_type=int)
+                d = {(int(k) if k.lstrip('-').isdigit() else k): v for k, v in d.items()}
+            return d
         arch = read('params.json')
         tp = read('train_params.json')
         ctor = {k: arch[k] for k in ('input_shape', 'num_labels', 'type', 'output_distribution', 'representation',
@@ -826,11 +894,19 @@ class ClassificationVariationalNetwork(nn.Module):
         net = cls(**ctor)
         net.training_parameters.update({k: v for k, v in tp.items() if k not in ('sigma', 'optimizer')})
         net.saved_dir = dir_name
+        history = read('history.json', int_keys=True, default={'epochs': 0})
+        net.train_history = history
+        net.trained = int(history.get('epochs', 0))
+        if load_test:
+            tested = read('test.json', int_keys=True, default={})
+            if tested:
+                net.testing.update(tested)
+            net.ood_results = read('ood.json', int_keys=True, default={})
         if device is not None:
             net.to(device)
-        if load_state and os.path.exists(os.path.join(dir_name, 'state.pth')):
+        if load_state and build_module and os.path.exists(os.path.join(dir_name, 'state.pth')):
             net.load_weights(dir_name, strict=strict)
-            net.trained = max(net.trained, int(tp.get('epochs', 0)) or 1)
+            net.optimizer.update_scheduler_from_epoch(net.trained)
         return net
 
     def load_weights(self, dir_name, strict=True, with_optimizer=True):

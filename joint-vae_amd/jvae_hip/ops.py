@@ -548,14 +548,20 @@ def act(x, kind):
 
 # ------------------------------------------------------------------------------------------- dropout
 class _Dropout(torch.autograd.Function):
-    """nn.Dropout(p) in train mode (layers.py:287-288): counter-based mask, regenerated in backward from the seed."""
+    """nn.Dropout(p) in train mode (layers.py:287-288): counter-based mask, regenerated in backward from the seed.
+    `seed`: a Python int, or a 1-element int64 DEVICE tensor (graph-capturable: no host value enters the launch)."""
 
     @staticmethod
     def forward(ctx, x, p, seed):
         x = _c(_f32(x, 'dropout'))
         y = torch.empty_like(x)
-        L.check(L.load().jvae_dropout_f32(L.ptr(x), L.ptr(y), x.numel(), float(p), int(seed), L.stream_ptr()), 'dropout')
-        ctx.cfg = (float(p), int(seed))
+        if torch.is_tensor(seed):
+            L.check(L.load().jvae_dropout_dev_f32(L.ptr(x), L.ptr(y), x.numel(), float(p), L.ptr(seed), 0, L.stream_ptr()),
+                    'dropout')
+        else:
+            seed = int(seed)
+            L.check(L.load().jvae_dropout_f32(L.ptr(x), L.ptr(y), x.numel(), float(p), seed, L.stream_ptr()), 'dropout')
+        ctx.cfg = (float(p), seed)
         return y
 
     @staticmethod
@@ -563,7 +569,11 @@ class _Dropout(torch.autograd.Function):
         p, seed = ctx.cfg
         gy = _c(gy)
         gx = torch.empty_like(gy)
-        L.check(L.load().jvae_dropout_f32(L.ptr(gy), L.ptr(gx), gy.numel(), p, seed, L.stream_ptr()), 'dropout_bwd')
+        if torch.is_tensor(seed):
+            L.check(L.load().jvae_dropout_dev_f32(L.ptr(gy), L.ptr(gx), gy.numel(), p, L.ptr(seed), 0, L.stream_ptr()),
+                    'dropout_bwd')
+        else:
+            L.check(L.load().jvae_dropout_f32(L.ptr(gy), L.ptr(gx), gy.numel(), p, seed, L.stream_ptr()), 'dropout_bwd')
         return gx, None, None
 
 
@@ -710,24 +720,36 @@ def latent(mu, lv_raw, eps, y, means, T, *, prior='gaussian', var_dim='scalar', 
 
 
 # ------------------------------------------------------------------------------------------- losses
+SIGMA_VALUE, SIGMA_LOG, SIGMA_CODED, SIGMA_RMSE = 0, 1, 2, 3      # kinds of sigma the loss kernels know (csrc/loss.hip)
+
+
+def _check_sigma(sigma, mode, N):
+    want = N if mode == SIGMA_CODED else 1
+    if mode not in (SIGMA_VALUE, SIGMA_LOG, SIGMA_CODED, SIGMA_RMSE) or (mode != SIGMA_RMSE and sigma.numel() != want):
+        raise L.JvaeHipError('sigma must be one value, one log value, N coded log values or the rmse kind; per-dimension '
+                             'sigma is not built (the reference itself fails on it: cvae.py:649 / 789 shapes)')
+
+
 class _Recon(torch.autograd.Function):
-    """wmse (L,N) of x_reco[1:] against x with a scalar sigma (losses.py:8-27; cvae.py:649-652)."""
+    """wmse (L,N) of x_reco[1:] against x (losses.py:8-27; cvae.py:649-652); sigma kinds: csrc/loss.hip."""
 
     @staticmethod
-    def forward(ctx, x_reco, x, sigma, sigma_is_log):
+    def forward(ctx, x_reco, x, sigma, mode, snapshot):
         x_reco = _c(_f32(x_reco, 'recon'))
         x = _c(x)
         sigma = _c(sigma)
-        if sigma.numel() != 1:
-            raise L.JvaeHipError('per-dimension sigma is outside the native-kernel contract')
+        mode = int(mode)
         Lp1, N = x_reco.shape[0], x_reco.shape[1]
+        _check_sigma(sigma, mode, N)
         D = x.numel() // max(N, 1)
         wmse = torch.empty((Lp1 - 1, N), device=x.device, dtype=torch.float32)
-        rc = L.load().jvae_recon_fwd_f32(L.ptr(x_reco), L.ptr(x), L.ptr(sigma), int(sigma_is_log), L.ptr(wmse),
+        rc = L.load().jvae_recon_fwd_f32(L.ptr(x_reco), L.ptr(x), L.ptr(sigma), mode, L.ptr(wmse),
                                          Lp1 - 1, N, D, L.stream_ptr())
         L.check(rc, 'jvae_recon_fwd_f32')
+        # snapshot: the caller's decay rule will change `sigma` in place before backward (see recon_bwd_kernel)
+        ctx.sigma_fwd = sigma.detach().clone() if (snapshot and mode == SIGMA_VALUE) else None
         ctx.save_for_backward(x_reco, x, sigma, wmse)
-        ctx.is_log = sigma_is_log
+        ctx.mode = mode
         ctx.dims = (Lp1 - 1, N, D)
         return wmse
 
@@ -737,57 +759,64 @@ class _Recon(torch.autograd.Function):
         Ls, N, D = ctx.dims
         g = _c(g)
         gxr = torch.empty_like(x_reco)
-        gs = torch.empty_like(sigma) if ctx.needs_input_grad[2] else None
+        gs = torch.empty_like(sigma) if (ctx.needs_input_grad[2] and ctx.mode != SIGMA_RMSE) else None
         ws = L.workspace(4 * Ls * N + 16, x.device)
-        rc = L.load().jvae_recon_bwd_f32(L.ptr(x_reco), L.ptr(x), L.ptr(sigma), int(ctx.is_log), L.ptr(g), L.ptr(wmse),
-                                         L.ptr(gxr), L.ptr(gs), 0, Ls, N, D, L.ptr(ws), ws.numel(), L.stream_ptr())
+        rc = L.load().jvae_recon_bwd_f32(L.ptr(x_reco), L.ptr(x), L.ptr(sigma), ctx.mode, L.ptr(ctx.sigma_fwd), L.ptr(g),
+                                         L.ptr(wmse), L.ptr(gxr), L.ptr(gs), 0, Ls, N, D, L.ptr(ws), ws.numel(),
+                                         L.stream_ptr())
         L.check(rc, 'jvae_recon_bwd_f32')
-        return gxr, None, gs, None
+        return gxr, None, gs, None, None
 
 
-def recon_wmse(x_reco, x, sigma, sigma_is_log):
-    return _Recon.apply(x_reco, x, sigma, sigma_is_log)
+def recon_wmse(x_reco, x, sigma, sigma_is_log, snapshot=False):
+    """sigma_is_log: bool, or one of SIGMA_VALUE / SIGMA_LOG / SIGMA_CODED / SIGMA_RMSE."""
+    return _Recon.apply(x_reco, x, sigma, int(sigma_is_log), snapshot)
 
 
 class _Elbo(torch.autograd.Function):
-    """wmse_s (L,N), kl (N,), ce (N,)|None, sigma -> (wmse, cross_x, total) (cvae.py:773-791,887-902)."""
+    """wmse_s (L,N), kl (N,), ce (N,)|None, sigma -> (wmse, cross_x, total, mse) (cvae.py:662-670,773-791,887-902)."""
 
     @staticmethod
-    def forward(ctx, wmse_s, kl, ce, sigma, sigma_is_log, D, beta, cw):
+    def forward(ctx, wmse_s, kl, ce, sigma, mode, D, beta, cw):
         wmse_s, kl, sigma = _c(wmse_s), _c(kl), _c(sigma)
         ce = None if ce is None else _c(ce)
+        mode = int(mode)
         Ls, N = wmse_s.shape
-        wmse, cx, tot = (torch.empty(N, device=kl.device, dtype=torch.float32) for _ in range(3))
-        rc = L.load().jvae_elbo_fwd_f32(L.ptr(wmse_s), L.ptr(kl), L.ptr(ce), L.ptr(sigma), int(sigma_is_log), L.ptr(wmse),
-                                        L.ptr(cx), L.ptr(tot), Ls, N, int(D), float(beta), float(cw), L.stream_ptr())
+        _check_sigma(sigma, mode, N)
+        wmse, cx, tot, mse = (torch.empty(N, device=kl.device, dtype=torch.float32) for _ in range(4))
+        rc = L.load().jvae_elbo_fwd_f32(L.ptr(wmse_s), L.ptr(kl), L.ptr(ce), L.ptr(sigma), mode, L.ptr(wmse),
+                                        L.ptr(cx), L.ptr(tot), L.ptr(mse), Ls, N, int(D), float(beta), float(cw),
+                                        L.stream_ptr())
         L.check(rc, 'jvae_elbo_fwd_f32')
-        ctx.save_for_backward(sigma)
-        ctx.cfg = (sigma_is_log, Ls, N, int(D), float(beta), float(cw), ce is not None)
+        ctx.save_for_backward(wmse_s if mode == SIGMA_RMSE else sigma)
+        ctx.cfg = (mode, Ls, N, int(D), float(beta), float(cw), ce is not None)
         ctx.set_materialize_grads(False)
-        return wmse, cx, tot
+        ctx.mark_non_differentiable(mse)
+        return wmse, cx, tot, mse
 
     @staticmethod
-    def backward(ctx, g_wmse, g_cx, g_tot):
-        sigma, = ctx.saved_tensors
-        is_log, Ls, N, D, beta, cw, has_ce = ctx.cfg
+    def backward(ctx, g_wmse, g_cx, g_tot, _g_mse):
+        sigma, = ctx.saved_tensors                  # kind 3: the forward's wmse_s
+        mode, Ls, N, D, beta, cw, has_ce = ctx.cfg
         dev = sigma.device
         g_ws = torch.empty((Ls, N), device=dev, dtype=torch.float32)
         g_kl = torch.empty(N, device=dev, dtype=torch.float32)
         g_ce = torch.empty(N, device=dev, dtype=torch.float32) if has_ce else None
-        gs = torch.empty_like(sigma) if ctx.needs_input_grad[3] else None
+        gs = torch.empty_like(sigma) if (ctx.needs_input_grad[3] and mode != SIGMA_RMSE) else None
         ws = L.workspace(4 * N + 16, dev)
 
         def opt(t):
             return None if t is None else _c(t)
-        rc = L.load().jvae_elbo_bwd_f32(L.ptr(opt(g_wmse)), L.ptr(opt(g_cx)), L.ptr(opt(g_tot)), L.ptr(sigma), int(is_log),
+        rc = L.load().jvae_elbo_bwd_f32(L.ptr(opt(g_wmse)), L.ptr(opt(g_cx)), L.ptr(opt(g_tot)), L.ptr(sigma), mode,
                                         L.ptr(g_ws), L.ptr(g_kl), L.ptr(g_ce), L.ptr(gs), 0, Ls, N, D, beta, cw,
                                         L.ptr(ws), ws.numel(), L.stream_ptr())
         L.check(rc, 'jvae_elbo_bwd_f32')
         return g_ws, g_kl, g_ce, gs, None, None, None, None
 
 
-def elbo(wmse_s, kl, ce, sigma, sigma_is_log, D, beta, cw):
-    return _Elbo.apply(wmse_s, kl, ce, sigma, sigma_is_log, D, beta, cw)
+def elbo(wmse_s, kl, ce, sigma, sigma_is_log, D, beta, cw, with_mse=False):
+    wmse, cx, tot, mse = _Elbo.apply(wmse_s, kl, ce, sigma, int(sigma_is_log), D, beta, cw)
+    return (wmse, cx, tot, mse) if with_mse else (wmse, cx, tot)
 
 
 def iws(wmse_s, eps, log_var, log_pz, sigma, sigma_is_log, D):

@@ -113,7 +113,11 @@ class Optimizer:
         if self.lr_decay:
             old = self._lr
             self._epochs_decayed += 1
-            self._lr = self.init_lr * (1 - self.lr_decay) ** self._epochs_decayed
+            # the chainable form of torch's ExponentialLR.step() (lr <- lr * gamma), which is what the reference runs
+            # (optimizers.py:50-53,123-127): bit-identical lr sequence, and after load_state_dict() - which restores the
+            # decayed lr - update_scheduler_from_epoch(n) multiplies n MORE times, as the reference's resume does (sic:
+            # cvae.py:2851; pinned by tests/golden/ckpt_ref_e2)
+            self._lr = self._lr * (1 - self.lr_decay)
             self._sync_device_lr()
             logging.debug(f'lr updated from {old:.4e} to {self._lr:.4e}')
 

@@ -38,6 +38,53 @@ def build_prior(dim, distribution='gaussian', **kw):
     return cls(dim, **kw)
 
 
+class _KLTerms(dict):
+    """The dictionary GaussianPrior.kl returns (priors.py:287-324): keys trace, log_det_prior, log_det, distance, var_kl,
+    kl in the reference's order.  distance / var_kl / kl come out of the fused kernel; the three terms var_kl is made of
+    are diagnostics nobody on the training / evaluation path reads, so they are derived on first access (from the prior's
+    public helpers, as the reference does) instead of costing three more passes per call."""
+
+    _LAZY = ('trace', 'log_det_prior', 'log_det')
+
+    def __init__(self, prior, log_var, y, distance, var_kl, kl):
+        super().__init__()
+        self._src = (prior, log_var, y)
+        for k in self._LAZY:
+            dict.__setitem__(self, k, None)
+        dict.__setitem__(self, 'distance', distance)
+        dict.__setitem__(self, 'var_kl', var_kl)
+        dict.__setitem__(self, 'kl', kl)
+
+    def _fill(self):
+        if self._src is None:
+            return
+        prior, log_var, y = self._src
+        self._src = None
+        with torch.no_grad():
+            dict.__setitem__(self, 'trace', prior.trace_prod_by_var(log_var.exp(), y))
+            ld = prior.log_det_per_class()
+            if prior.conditional:
+                ld = ld.index_select(0, y.reshape(-1)).view(y.shape)
+            dict.__setitem__(self, 'log_det_prior', ld)
+            dict.__setitem__(self, 'log_det', log_var.sum(-1))
+
+    def __getitem__(self, k):
+        if k in self._LAZY:
+            self._fill()
+        return dict.__getitem__(self, k)
+
+    def get(self, k, default=None):
+        return self[k] if k in self else default
+
+    def values(self):
+        self._fill()
+        return dict.values(self)
+
+    def items(self):
+        self._fill()
+        return dict.items(self)
+
+
 class GaussianPrior(nn.Module):
     """C class-conditional Gaussians N(m_c, (T_c^T T_c)^-1); in training `y` selects ONE component."""
 
@@ -151,7 +198,7 @@ class GaussianPrior(nn.Module):
         kl, dist, vkl = self._run(mu, log_var, y, var_weighting)
         if not output_dict:
             return kl
-        return {'distance': dist, 'var_kl': vkl, 'kl': kl}
+        return _KLTerms(self, log_var, y, dist, vkl, kl)
 
     def mahala(self, x, y=None):
         """Squared Mahalanobis distance |T_y (x - m_y)|^2, shape x.shape[:-1]."""

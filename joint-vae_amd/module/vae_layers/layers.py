@@ -19,134 +19,148 @@ from module.priors import build_prior
 from .misc import activation_layers, ACT_OF_MODULE
 
 
+def _sigma_kind(is_rmse, coded, learned, decay):
+    """Which of the five behaviours a Sigma has (first match wins, the reference's precedence: layers.py:194-215)."""
+    for kind, on in (('rmse', is_rmse), ('coded', coded), ('learned', learned), ('decayed', decay)):
+        if on:
+            return kind
+    return 'fixed'
+
+
 class Sigma(Parameter):
-    """Standard deviation of p(x|z): a Parameter that is fixed, learned (stored as log sigma), tied to
-    the running RMSE with a decay rule, or coded by the encoder.  Constructor as in the reference:
-    Sigma(value, sdim, input_dim, reach, decay, max_step, learned, is_rmse, sigma0, is_log)."""
+    """Standard deviation of p(x|z) as an nn.Parameter (reference: module/vae_layers/layers.py:73-213; used at
+    cvae.py:626-670,769).  Five kinds:
+
+      fixed    value given, never changes                          str: '0.5'
+      decayed  fixed start, pulled towards reach * rmse            str: '1->2*rmse[-0.1*<0.05]'
+      learned  stored as log sigma, receives gradient              str: '1->rmse[l] (0.98)'
+      rmse     follows the running rmse of the batch exactly       str: 'rmse (0.29)'
+      coded    log sigma is an output of the encoder               str: 'coded scalar' / 'coded mask'
+
+    The public attributes (`params` lists every one without a leading underscore) and the printed forms are what the
+    reference writes into train_params.json and into job-directory names, so they are kept verbatim; the constructor
+    keywords are the reference's: Sigma(value, sdim, input_dim, reach, decay, max_step, learned, is_rmse, sigma0, is_log).
+    """
 
     @staticmethod
-    def __new__(cls, value=None, sdim=1, input_dim=False, learned=False, is_rmse=False, is_log=False, **kw):
-        assert value is not None or is_rmse or input_dim
+    def __new__(cls, value=None, sdim=1, input_dim=False, learned=False, is_rmse=False, is_log=False, **_):
+        if value is None:
+            assert is_rmse or input_dim, 'a Sigma needs a value unless it follows the rmse or is coded'
+        stored_as_log = bool(is_log or learned or input_dim)       # coded implies learned implies log storage
         if is_rmse or (input_dim and value is None):
-            value = 0
-        log_stored = bool(is_log or learned or input_dim)
-        fill = math.log(value) if log_stored else value
-        data = torch.full((sdim,) if isinstance(sdim, int) else tuple(sdim), float(fill))
-        return super().__new__(cls, data, requires_grad=bool(learned or input_dim))
+            start = 0.
+        else:
+            start = float(value)
+        shape = (sdim,) if isinstance(sdim, int) else tuple(sdim)
+        with np.errstate(divide='ignore'):
+            init = float(np.log(start)) if stored_as_log else start
+        return super().__new__(cls, torch.full(shape, init), requires_grad=bool(learned or input_dim))
 
     def __init__(self, value=None, learned=False, is_rmse=False, sdim=1, input_dim=False, reach=1, decay=0,
                  max_step=None, sigma0=None, is_log=False):
-        assert not learned or not is_rmse
-        assert not decay or not learned
+        if learned:
+            assert not is_rmse and not decay, 'a learned sigma neither follows the rmse nor decays'
+        follows = bool(decay) or is_rmse
+        public = dict(is_rmse=is_rmse,
+                      sigma0=sigma0 if (sigma0 is not None or is_rmse) else value,
+                      learned=learned,
+                      input_dim=input_dim,
+                      is_log=learned or is_log or input_dim,
+                      decay=1 if is_rmse else decay,
+                      reach=reach if follows else None,
+                      max_step=max_step,
+                      sdim=sdim)
         self._rmse = np.nan
-        self.is_rmse = is_rmse
-        self.sigma0 = value if (sigma0 is None and not is_rmse) else sigma0
-        self.learned = learned
-        self.input_dim = input_dim
-        self.is_log = bool(learned or is_log or input_dim)
-        self.decay = 1 if is_rmse else decay
-        self.reach = reach if (decay or is_rmse) else None
-        self.max_step = max_step
-        self.sdim = sdim
-        if self.coded:
-            self._output_dim = input_dim if self.per_dim else (1,) * len(input_dim)
-        else:
-            self._output_dim = None
+        self.__dict__.update(public)                               # insertion order = key order of `params`
+        self._output_dim = None
+        if input_dim:
+            self._output_dim = input_dim if sdim != 1 else (1,) * len(input_dim)
 
     def __deepcopy__(self, memo):
-        new = Sigma.__new__(Sigma, value=1.0, sdim=self.sdim, learned=self.requires_grad)
-        new.__dict__.update(self.__dict__)
-        new.data = self.data.clone()
-        memo[id(self)] = new
-        return new
+        twin = Sigma.__new__(Sigma, value=1.0, sdim=self.sdim, learned=self.requires_grad)
+        twin.__dict__.update(self.__dict__)
+        twin.data = self.data.clone()
+        memo[id(self)] = twin
+        return twin
 
-    # -- views ------------------------------------------------------------------------------------
+    # -- read-only views --------------------------------------------------------------------------
+    coded = property(lambda self: bool(self.input_dim))
+    per_dim = property(lambda self: self.sdim != 1)
+    output_dim = property(lambda self: self._output_dim)
+    kind = property(lambda self: _sigma_kind(self.is_rmse, self.coded, self.learned, self.decay))
+
     @property
     def value(self):
-        """RMS value of sigma as a Python float (host read-back: not used inside the training step)."""
+        """Root mean square of sigma over its dimensions, as a Python float (a device read-back: the training step
+        reads it from the packed measures instead)."""
         with torch.no_grad():
-            d = self.data
-            return ((2 * d).exp() if self.is_log else d.pow(2)).mean().sqrt().item()
+            squares = (2 * self.data).exp() if self.is_log else self.data * self.data
+            return float(squares.mean().sqrt())
 
-    @property
-    def coded(self):
-        return bool(self.input_dim)
-
-    @property
-    def per_dim(self):
-        return self.sdim != 1
-
-    @property
-    def output_dim(self):
-        return self._output_dim
+    def host_params(self, value):
+        """`params` with an already known rms value (no device read-back)."""
+        listed = {k: v for k, v in vars(self).items() if k[:1] != '_'}
+        listed['value'] = value
+        return listed
 
     @property
     def params(self):
-        d = {k: v for k, v in self.__dict__.items() if not k.startswith('_')}
-        d['value'] = self.value
-        return d
+        return self.host_params(self.value)
 
-    def host_params(self, value):
-        """`params` with an already known RMS value (avoids the device read-back of `.value`)."""
-        d = {k: v for k, v in self.__dict__.items() if not k.startswith('_')}
-        d['value'] = value
-        return d
-
-    # -- updates -------------------------------------------------------------------------------------
+    # -- updates ----------------------------------------------------------------------------------
     def update(self, rmse=None, v=None):
+        """`v`: new (coded) values, averaged over the leading batch dimensions.  `rmse`: the batch rmse; a decayed /
+        rmse sigma moves by decay * (reach * rmse - sigma), at most `max_step` in magnitude."""
         assert rmse is None or v is None
         if v is not None:
-            lead = tuple(range(v.dim() - self.dim()))
-            v = v.mean(lead) if lead else v
-            assert v.dim() == self.dim()
-            self.data = v
-            return
-        if rmse is None:
-            return
-        self._rmse = rmse
-        if self.learned or not self.decay:
-            return
-        delta = self.decay * (self.reach * rmse - self.data)
-        if self.max_step and abs(delta) > self.max_step:
-            delta = self.max_step if delta > 0 else -self.max_step
-        self.data += delta
+            extra = v.dim() - self.dim()
+            assert extra >= 0
+            self.data = v.mean(tuple(range(extra))) if extra else v
+        elif rmse is not None:
+            self._rmse = rmse
+            if self.kind in ('rmse', 'decayed'):
+                step = self.decay * (self.reach * rmse - self.data)
+                if self.max_step:
+                    step = torch.clamp(torch.as_tensor(step), -self.max_step, self.max_step)
+                self.data += step
 
-    # -- printing ------------------------------------------------------------------------------------
-    def __format__(self, spec):
-        if spec.endswith(('f', 'g', 'e')):
-            return self.value.__format__(spec)
-        if spec.endswith('x'):
-            return texify_str(str(self), num=True)
-        if spec.endswith('i'):
-            if self.is_rmse:
-                return 'e'
-            if self.coded:
-                return 'C' if self.per_dim else 'c'
-            if self.learned:
-                return 'l'
-        return str(self)
+    # -- printed forms (job-directory names, train_params.json: kept as the reference prints them) ----------------
+    def _describe(self):
+        kind = self.kind
+        if kind == 'rmse':
+            return 'rmse' if self._rmse is np.nan else 'rmse ({:g})'.format(self._rmse)
+        if kind == 'coded':
+            return 'coded ' + ('mask' if self.per_dim else 'scalar')
+        if kind == 'learned':
+            return '{:g}->rmse[l] ({:g})'.format(self.sigma0, self.value)
+        if kind == 'fixed':
+            return '{:g}'.format(self.value if self.dim() and self.numel() > 1 else float(self.data))
+        target = ('' if self.reach == 1 else '{:g}*'.format(self.reach)) + 'rmse'
+        limit = '<{:g}'.format(self.max_step) if self.max_step else ''
+        return '{:g}->{}[-{:g}*{}]'.format(self.sigma0, target, self.decay, limit)
 
     def __str__(self):
-        if self.is_rmse:
-            return 'rmse' if self._rmse is np.nan else f'rmse ({self._rmse:g})'
-        if self.coded:
-            return 'coded {}'.format('mask' if self.per_dim else 'scalar')
-        if self.learned:
-            return f'{self.sigma0:g}->rmse[l] ({self.value:g})'
-        if not self.decay:
-            with torch.no_grad():
-                return f'{self.data.item():g}'
-        mult = '' if self.reach == 1 else f'{self.reach:g}*'
-        cap = f'<{self.max_step:g}' if self.max_step else ''
-        return f'{self.sigma0:g}->{mult}rmse[-{self.decay:g}*{cap}]'
+        return self._describe()
+
+    def __format__(self, spec):
+        tail = spec[-1:] if spec else ''
+        if tail in ('f', 'g', 'e'):
+            return format(self.value, spec)
+        if tail == 'x':
+            return texify_str(self._describe(), num=True)
+        if tail == 'i':
+            letter = {'rmse': 'e', 'learned': 'l', 'coded': 'C' if self.per_dim else 'c'}.get(self.kind)
+            if letter:
+                return letter
+        return self._describe()
 
     def __repr__(self):
-        if self.is_rmse:
+        if self.kind == 'rmse':
             return 'Sigma will be RMSE'
-        s = super().__repr__()
+        text = super().__repr__()
         if self.decay:
-            return s[:-1] + f', decaying to {self.reach}*mse with rate {self.decay})'
-        return s
+            text = '{}, decaying to {}*mse with rate {})'.format(text[:-1], self.reach, self.decay)
+        return text
 
 
 def draw_epsilon(sampling_size, shape, device, distribution='gaussian'):
@@ -220,22 +234,36 @@ class DenseStack(nn.Sequential):
 
 class HipDropout(nn.Module):
     """nn.Dropout(p) (reference layers.py:287-288, cvae.py:297-298): identity in eval mode; in train mode a HIP kernel
-    with a counter-based mask.  The seed of every call is drawn from torch's default CPU generator (so torch.manual_seed
-    makes runs repeatable); the mask itself is not torch's."""
+    with a counter-based mask.  The seed lives in DEVICE memory: it is drawn once from torch's default CPU generator (so
+    torch.manual_seed makes runs repeatable; data-parallel ranks are offset by their rank so that replicas draw different
+    masks) and advanced on the stream after every call - no host value enters a launch, so a captured HIP graph
+    (graph_train_step) draws a fresh mask at every replay.  The mask itself is not torch's."""
+
+    _STRIDE = 0x9E3779B97F4A7C15 & (2 ** 62 - 1)
 
     def __init__(self, p=0.5):
         super().__init__()
         if not 0. <= p < 1.:
             raise ValueError('dropout probability has to be in [0, 1), got {}'.format(p))
         self.p = float(p)
+        self._seed = None
+
+    def _next_seed(self, device):
+        if self._seed is None or self._seed.device != device:
+            first = int(torch.randint(0, 2 ** 61, (1,)))
+            if torch.distributed.is_available() and torch.distributed.is_initialized():
+                first += torch.distributed.get_rank() * 1_000_003
+            self._seed = torch.tensor([first], dtype=torch.int64, device=device)
+        now = self._seed.clone()                      # this call's seed (kept for the backward pass)
+        self._seed += self._STRIDE % (2 ** 31)        # advance on the stream
+        return now
 
     def forward(self, x):
         if not self.training or self.p == 0.:
             if not x.is_cuda:
                 raise ops.L.JvaeHipError('jvae_hip ops need tensors resident on the GPU (no CPU fallback)')
             return x
-        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
-        return ops.dropout(x, self.p, seed)
+        return ops.dropout(x, self.p, self._next_seed(x.device))
 
     def extra_repr(self):
         return f'p={self.p}'
@@ -273,9 +301,6 @@ class Encoder(nn.Module):
         prior['dim'] = latent_dim
         self.prior = build_prior(**prior)
         logging.debug('Built %s', self.prior)
-
-    def eval(self, *a):
-        print('eval', *a)
 
     @property
     def sampling_size(self):

@@ -49,6 +49,12 @@ CASES = {
                                   prior=dict(distribution='gaussian', init_mean=0., learned_means=False,
                                              var_dim='scalar', freeze_means=0)),
                         N=8, kl_var_weighting=1.0, gamma_weighting=1.0),
+    # sigma kinds beyond the scalar value (cvae.py:626-670): sigma_n = the sample's own rmse, and log sigma_n
+    # coded by one more head of the encoder; a decayed sigma with a step cap
+    'c2_n8_rmse': dict(net=_conv(10, sigma={'is_rmse': True}), N=8, kl_var_weighting=1.0, gamma_weighting=1.0),
+    'c2_n8_coded': dict(net=_conv(10, sigma={'input_dim': (3, 32, 32)}), N=8, kl_var_weighting=1.0, gamma_weighting=1.0),
+    'c2_n8_decay': dict(net=_conv(10, sigma={'value': 1.0, 'decay': 0.1, 'reach': 2, 'max_step': 0.05}), N=8,
+                        kl_var_weighting=1.0, gamma_weighting=1.0),
     # config 1: MNIST-shape MLP (784-512-256 -> 16 -> 256-512-784), gamma=1000, sigmoid output, fixed sigma
     'c1_n16_mlp': dict(net=dict(input_shape=(1, 28, 28), num_labels=10, type='cvae',
                                 features=None, upsampler=None, encoder=[512, 256], decoder=[256, 512],
@@ -73,6 +79,8 @@ EVAL_CASES = {
                                     prior=dict(distribution='gaussian', init_mean=0., learned_means=True,
                                                var_dim='diag', freeze_means=0)), N=6),
     'e2_n8_gamma_L2': dict(net=_conv(10, gamma=2.0, classifier=[20], test_latent_sampling=2), N=8),
+    'e2_n8_rmse_L2': dict(net=_conv(10, sigma={'is_rmse': True}, test_latent_sampling=2), N=8),
+    'e2_n8_coded_L2': dict(net=_conv(10, sigma={'input_dim': (3, 32, 32)}, test_latent_sampling=2), N=8),
 }
 EVAL_OOD_METHODS = ['iws', 'mse', 'elbo', 'soft', 'zdist', 'iws-2s', 'elbo-a-4-1']
 

@@ -56,5 +56,47 @@ def main():
         print(f, os.path.getsize(os.path.join(out_dir, f)))
 
 
+def main_resume():
+    """Second fixture, tests/golden/ckpt_ref_e2: lr_decay = 0.1, two 'epochs' written the way train_model does it
+    (cvae.py:2295-2296,2485-2493: history entry, epochs += 1, trained += 1, update_lr), saved by the reference, then
+    RE-LOADED by the reference's own load() (cvae.py:2677-2857) - which restores history / test / ood records, sets
+    trained = history['epochs'] and fast-forwards the lr scheduler - followed by one more step.  resume.npz holds what the
+    reference had after its load (lr, trained) and after that step."""
+    Net = import_reference()
+    out_dir = os.path.join(REPO, 'tests', 'golden', 'ckpt_ref_e2')
+    kw = dict(KW, optimizer=dict(KW['optimizer'], lr_decay=0.1))
+    net = Net(**kw)
+    load_det_state(net, 0)
+    net.train()
+    for epoch in range(2):
+        o = step(net, 100 + epoch)
+        net.train_history[epoch] = {'train_loss': {k: float(v.mean()) for k, v in o[2].items()},
+                                    'train_measures': dict(o[3]), 'lr': net.optimizer.lr}
+        net.train_history['epochs'] += 1
+        net.trained += 1
+        net.optimizer.update_lr()
+    net.testing = {0: {'iws': {'n': 7, 'epochs': 2, 'accuracy': 0.25}}}
+    net.save(out_dir)
+    lr_at_save = net.optimizer.lr
+    again = Net.load(out_dir, load_state=True)
+    again.train()
+    res = {'lr_at_save': np.float64(lr_at_save), 'lr_after_load': np.float64(again.optimizer.lr),
+           'trained_after_load': np.int64(again.trained), 'history_epochs': np.int64(again.train_history['epochs'])}
+    o = step(again, 4321)
+    for k, v in o[2].items():
+        res['loss.' + k] = v.detach().numpy()
+    for n_, p in again.named_parameters():
+        res['param_after.' + n_] = p.detach().numpy().copy()
+    again.optimizer.update_lr()
+    res['lr_after_next_epoch'] = np.float64(again.optimizer.lr)
+    np.savez_compressed(os.path.join(out_dir, 'resume.npz'), **res)
+    print({k: (float(v) if v.shape == () else v.shape) for k, v in res.items() if not k.startswith('param')})
+    for f in sorted(os.listdir(out_dir)):
+        print(f, os.path.getsize(os.path.join(out_dir, f)))
+
+
 if __name__ == '__main__':
-    main()
+    if sys.argv[1:] == ['resume']:
+        main_resume()
+    else:
+        main()

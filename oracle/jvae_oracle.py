@@ -172,8 +172,10 @@ def param_keys(sp):
         d_in = d
     K, C = sp['K'], sp['C']
     out += [('encoder.dense_mean.weight', (K, d_in)), ('encoder.dense_mean.bias', (K,)),
-            ('encoder.dense_log_var.weight', (K, d_in)), ('encoder.dense_log_var.bias', (K,)),
-            ('encoder.prior.mean', (C, K))]
+            ('encoder.dense_log_var.weight', (K, d_in)), ('encoder.dense_log_var.bias', (K,))]
+    if sp['sigma'].get('input_dim'):                       # coded sigma: one more head on the trunk (layers.py:296-298)
+        out += [('encoder.sigma.weight', (1, d_in)), ('encoder.sigma.bias', (1,))]
+    out.append(('encoder.prior.mean', (C, K)))
     vd = sp['prior'].get('var_dim', 'scalar') if sp['prior'].get('distribution', 'gaussian') == 'gaussian' else 'scalar'
     out.append(('encoder.prior._var_parameter', {'scalar': (C,), 'diag': (C, K), 'full': (C, K, K)}[vd]))
     d_in = K
@@ -202,8 +204,8 @@ def trainable(sp, key):
     leaf = key.rsplit('.', 1)[-1]
     if leaf in BUFFER_LEAVES:
         return False
-    if key == 'sigma':
-        return bool(sp['sigma'].get('learned', False))
+    if key == 'sigma':                                   # coded implies learned (layers.py:82-83), but it never gets a gradient
+        return bool(sp['sigma'].get('learned', False) or sp['sigma'].get('input_dim'))
     if key == 'encoder.prior.mean':
         return bool(sp['prior'].get('learned_means', False)) and not sp['prior'].get('freeze_means', 0) > 0
     if key == 'encoder.prior._var_parameter':
@@ -216,8 +218,14 @@ def init_state(sp, seed=0):
     P = {}
     for key, shape in param_keys(sp):
         if key == 'sigma':
-            v = float(sp['sigma'].get('value', 1))
-            P[key] = torch.full((1,), math.log(v) if sp['sigma'].get('learned') else v)   # layers.py:84-89
+            sg = sp['sigma']
+            if sg.get('is_rmse'):                           # starts at 0, then follows the batch rmse (layers.py:79-80)
+                P[key] = torch.zeros(1)
+            elif sg.get('input_dim'):                       # coded: log(0) until the first batch sets it
+                P[key] = torch.full((1,), -math.inf)
+            else:
+                v = float(sg.get('value', 1))
+                P[key] = torch.full((1,), math.log(v) if sg.get('learned') else v)   # layers.py:84-89
         elif key.endswith('num_batches_tracked'):
             P[key] = torch.zeros((), dtype=torch.int64)
         else:
@@ -319,6 +327,56 @@ def prior_kl(sp, P, mu, log_var, y, w):
     return dict(distance=distance, var_kl=var_kl, kl=0.5 * (distance + w * var_kl))
 
 
+def recon_terms(sp, P, u, x, x_reco, L, N, training):
+    """Reconstruction term for every kind of sigma (cvae.py:626-670): -> (wmse_s (L,N), wmse (N,), mse (N,), log_sigma,
+    sigma_value_reported).  Kinds: scalar value / learned log (broadcast), `is_rmse` (sigma_n^2 = the sample's own mse,
+    averaged over the L draws) and coded (log sigma_n = one more linear head on the encoder trunk)."""
+    sg = sp['sigma']
+    s = P['sigma']
+    with torch.no_grad():
+        reported = float(((2 * s).exp() if (sg.get('learned') or sg.get('input_dim') or sg.get('is_log')) else s.pow(2)).mean().sqrt())
+    diff2 = lambda sig: ((x_reco[1:] / sig - (x / sig).unsqueeze(0)) ** 2).reshape(L, N, -1).mean(-1)   # losses.py:8-27
+    if sg.get('is_rmse'):
+        raw = diff2(1.)
+        sigma2 = raw.mean(0)                                   # (N,) cvae.py:662-666
+        wmse_s = raw / sigma2.unsqueeze(0)
+        log_sigma = sigma2.sqrt().log()
+        new = None
+    elif sg.get('input_dim'):
+        s_ = F.linear(u, P['encoder.sigma.weight'], P['encoder.sigma.bias']).view(-1, *([1] * len(sp['input_shape'])))
+        sigma2 = (2 * s_).exp().reshape(N)
+        wmse_s = diff2(s_.exp())
+        log_sigma = s_.reshape(N)
+        new = s_.detach().mean(0).reshape(1) if False else s_.detach().mean(tuple(range(s_.dim() - 1)))   # Sigma.update(v=...)
+    else:
+        sigma_ = s.exp() if sg.get('learned') else s
+        log_sigma = s.squeeze() if sg.get('learned') else s.log().squeeze()
+        sigma2 = sigma_ ** 2
+        wmse_s = diff2(sigma_)
+        new = None
+    wmse = wmse_s.mean(0)
+    mse = wmse * sigma2
+    if sg.get('input_dim'):
+        # sic (cvae.py:668): wmse (N,) times sigma2_ (N,1,1,1) broadcasts to (N,1,1,N): its mean - the only use of `mse`
+        # with a coded sigma - is mean(wmse) * mean(sigma^2), not the mean of the products
+        mse = (wmse.mean() * sigma2.mean()).expand(N)
+    if training:
+        with torch.no_grad():
+            rmse = mse.mean().sqrt()
+            if new is not None:
+                P['sigma'] = new.reshape(P['sigma'].shape).clone().requires_grad_(P['sigma'].requires_grad)
+            elif sg.get('is_rmse') or (sg.get('decay') and not sg.get('learned')):
+                decay = 1. if sg.get('is_rmse') else sg['decay']
+                delta = decay * (sg.get('reach', 1) * rmse - P['sigma'])
+                if sg.get('max_step'):
+                    delta = delta.clamp(-sg['max_step'], sg['max_step'])
+                # IN PLACE, as Sigma.update does (`self.data += delta`, layers.py:168): the division x_reco / sigma saved this
+                # very tensor for backward, so the reference's backward divides by the UPDATED sigma (gradient of the
+                # reconstruction term = 2 (x_reco - x) / (D sigma_old sigma_new)); golden c2_n8_decay pins it
+                P['sigma'].data += delta
+    return wmse_s, wmse, mse, log_sigma, reported
+
+
 def evaluate(sp, P, x, y, eps, kl_var_weighting=1.0, gamma_weighting=1.0, with_beta=True, training=True, alt_prior=None):
     """Training-branch evaluate (cvae.py:523-917) -> (x_reco, y_est, losses, measures, mu, log_var, z).
     alt_prior: {'mean': (1,K), 'T': (1,)} = a NON-conditional prior swapped in for this call (WIM, ft/wim.py:54-70):
@@ -350,14 +408,7 @@ def evaluate(sp, P, x, y, eps, kl_var_weighting=1.0, gamma_weighting=1.0, with_b
         c = torch.relu(F.linear(c, P[f'classifier.{2 * j}.weight'], P[f'classifier.{2 * j}.bias']))
     logits = F.linear(c, P[f'classifier.{2 * nclf}.weight'], P[f'classifier.{2 * nclf}.bias'])
 
-    s = P['sigma']
-    if sp['sigma'].get('learned'):
-        sigma_, log_sigma = s.exp(), s.squeeze()
-    else:
-        sigma_, log_sigma = s, s.log().squeeze()
-    wmse_s = ((x_reco[1:] / sigma_ - (x / sigma_).unsqueeze(0)) ** 2).reshape(L, N, -1).mean(-1)   # losses.py:8-27
-    wmse = wmse_s.mean(0)
-    mse = wmse * sigma_ ** 2
+    wmse_s, wmse, mse, log_sigma, sigma_reported = recon_terms(sp, P, u, x, x_reco, L, N, training)
     if alt_prior is not None:
         Pa = {'encoder.prior.mean': alt_prior['mean'], 'encoder.prior._var_parameter': alt_prior['T']}
         spa = dict(sp, prior=dict(distribution='gaussian', var_dim='scalar'))
@@ -388,7 +439,7 @@ def evaluate(sp, P, x, y, eps, kl_var_weighting=1.0, gamma_weighting=1.0, with_b
         mse_m = mse.mean().item()
         cd = torch.cdist(dic, dic)
         C = sp['C']
-        meas = {'sigma': float(sigma_.pow(2).mean().sqrt()), 'xpow': xpow, 'mse': mse_m,
+        meas = {'sigma': sigma_reported, 'xpow': xpow, 'mse': mse_m,
                 'rmse': math.sqrt(mse_m), 'dB': 10 * math.log10(xpow / mse_m),
                 'zdist': kd['distance'].mean().item(), 'var_kl': kd['var_kl'].mean().item(),
                 'ld-norm': dic.pow(2).mean().item(),
@@ -428,10 +479,7 @@ def evaluate_all_classes(sp, P, x, eps):
         c = torch.relu(F.linear(c, P[f'classifier.{2 * j}.weight'], P[f'classifier.{2 * j}.bias']))
     logits = F.linear(c, P[f'classifier.{2 * nclf}.weight'], P[f'classifier.{2 * nclf}.bias'])
 
-    s = P['sigma']
-    sigma_, log_sigma = (s.exp(), s.squeeze()) if sp['sigma'].get('learned') else (s, s.log().squeeze())
-    wmse_s = ((x_reco[1:] / sigma_ - (x / sigma_).unsqueeze(0)) ** 2).reshape(L, N, -1).mean(-1)
-    wmse = wmse_s.mean(0)
+    wmse_s, wmse, mse, log_sigma, sigma_reported = recon_terms(sp, P, u, x, x_reco, L, N, False)
     log_iws = -D / 2 * (wmse_s + 2 * log_sigma + math.log(2 * math.pi))                 # (L, N)   cvae.py:672-676
     y_all = torch.arange(C).repeat_interleave(N)                                        # class-major (C*N,)
     kd = prior_kl(sp, P, mu.repeat(C, 1), log_var.repeat(C, 1), y_all, 1.0)
@@ -465,10 +513,9 @@ def evaluate_all_classes(sp, P, x, eps):
     rem = li.max(0)[0]
     losses['iws'] = (li - rem).exp().mean(0) + rem                                      # sic (cvae.py:868)
     with torch.no_grad():
-        mse = wmse * sigma_ ** 2
         xpow, mse_m = x.pow(2).mean().item(), mse.mean().item()
         cd = torch.cdist(dic, dic)
-        meas = {'sigma': float(sigma_.pow(2).mean().sqrt()), 'xpow': xpow, 'mse': mse_m, 'rmse': math.sqrt(mse_m),
+        meas = {'sigma': sigma_reported, 'xpow': xpow, 'mse': mse_m, 'rmse': math.sqrt(mse_m),
                 'dB': 10 * math.log10(xpow / mse_m), 'zdist': losses['zdist'].mean().item(),
                 'var_kl': losses['var_kl'].mean().item(), 'ld-norm': dic.pow(2).mean().item(),
                 'imut-zy': (math.log(C) - 1 / C * torch.exp(-cd.pow(2) / 4).sum(0).log().sum()).item(),

@@ -143,3 +143,43 @@ def test_sigma_and_optimizer_host_api():
     assert sgd.lr == 0.01 and f'{sgd:10}' == 'sgd--lr=0.01--momentum=0.9--weight_decay=0.0001'
     with pytest.raises(ValueError):
         Optimizer([p], optim_type='rmsprop')
+
+
+def test_sigma_matches_reference_forms(golden_dir):
+    """Sigma: printed forms, `params` keys / values, storage and the update rules against what the
+    REFERENCE's class produced for the same constructor arguments (tests/golden/sigma_forms.json, written by
+    oracle/gen_sigma_fixture.py) - fixed, decayed (reach / max_step), learned, rmse, coded scalar / mask, per-dimension."""
+    import copy
+    import json
+    import warnings
+    from module.vae_layers.layers import Sigma
+    fx = json.load(open(os.path.join(golden_dir, 'sigma_forms.json')))
+
+    def check(s, want):
+        assert str(s) == want['str'] and repr(s) == want['repr'], (str(s), want['str'], repr(s), want['repr'])
+        for f, txt in want['formats'].items():
+            assert format(s, f) == txt, (f, format(s, f), txt)
+        p = s.params
+        assert list(p) == want['param_keys']
+        for k, v in want['params'].items():
+            mine = list(p[k]) if isinstance(p[k], (tuple, list)) else p[k]
+            assert mine == pytest.approx(v) if isinstance(v, float) else mine == v, (k, mine, v)
+        assert list(s.shape) == want['shape'] and s.requires_grad == want['requires_grad']
+        assert s.data.flatten()[:4].tolist() == pytest.approx(want['data'], rel=1e-6, abs=1e-7)
+
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        for rec in fx['cases']:
+            kw = {a: (tuple(b) if isinstance(b, list) else b) for a, b in rec['kwargs'].items()}
+            s = Sigma(**kw)
+            check(s, rec['initial'])
+            if s.coded:
+                n = int(np.prod(s.output_dim))
+                s.update(v=torch.linspace(-1, 1, 5 * n).reshape(5, *s.output_dim))
+                check(s, rec['after'][0])
+            else:
+                for r, want in zip(fx['rmses'], rec['after']):
+                    s.update(rmse=torch.tensor(r))
+                    check(s, want)
+            twin = copy.deepcopy(s)
+            assert str(twin) == str(s) and torch.equal(twin.data, s.data)

@@ -573,9 +573,21 @@ def test_dropout_kernel_and_module():
     assert m(x) is x
     m.train()
     torch.manual_seed(7)
-    a = m(x)
-    torch.manual_seed(7)
-    assert torch.equal(a, m(x)) and abs(float((a != 0).float().mean()) - 0.7) < 0.01
+    a, b = m(x), m(x)
+    m2 = HipDropout(0.3).to(DEV)
+    torch.manual_seed(7)                    # same CPU-generator state -> same device seed sequence: repeatable runs
+    assert torch.equal(a, m2(x)) and torch.equal(b, m2(x)) and not torch.equal(a, b)
+    assert abs(float((a != 0).float().mean()) - 0.7) < 0.01
+    # the seed is device-resident and advanced on the stream: a captured graph draws a fresh mask at every replay
+    xs = x.clone()
+    g = torch.cuda.CUDAGraph()
+    m(xs)
+    torch.cuda.synchronize()
+    with torch.cuda.graph(g):
+        ys = m(xs)
+    g.replay(); r1 = ys.clone()
+    g.replay(); r2 = ys.clone()
+    assert not torch.equal(r1, r2) and abs(float((r2 != 0).float().mean()) - 0.7) < 0.01
     # end to end: an MLP model with dropout in both dense trunks trains (finite, decreasing loss) and evaluates
     from cvae import ClassificationVariationalNetwork as Net
     torch.manual_seed(0)
