@@ -56,10 +56,10 @@ def model_kwargs(workload):
                 optimizer=dict(_ADAM))
 
 
-def build_model(device, workload=2):
+def build_model(device, workload=2, test_latent_sampling=1):
     from cvae import ClassificationVariationalNetwork as Net
     torch.manual_seed(0)
-    net = Net(**model_kwargs(workload))
+    net = Net(**dict(model_kwargs(workload), test_latent_sampling=test_latent_sampling))
     net.to(device)
     net.train()
     return net
@@ -95,44 +95,110 @@ def dominant_kernel_roofline(device, reps=20):
     sec = e0.elapsed_time(e1) * 1e-3 / reps
     flops = 2.0 * N * H * H * C * C * 25
     x3 = os.environ.get('JVAE_X3', '1') != '0'
-    traffic = None
-    pmc = os.path.join(REPO, 'profiles', 'r01_x3_kernel_pmc.json' if x3 else 'r01_dominant_kernel_pmc.json')
-    if os.path.exists(pmc):           # HBM bytes per launch from the separate rocprofv3 --pmc passes
-        traffic = json.load(open(pmc)).get('hbm_bytes_per_launch')
+    traffic, traffic_source = None, None
+    for name in (('r02_x3_fwd_pmc.json', 'r01_x3_kernel_pmc.json') if x3 else ('r01_dominant_kernel_pmc.json',)):
+        pmc = os.path.join(REPO, 'profiles', name)
+        if os.path.exists(pmc):       # HBM bytes per launch from separate rocprofv3 --pmc passes of THIS kernel (not of this run)
+            d = json.load(open(pmc))
+            traffic = d.get('hbm_bytes_per_launch') or ((d.get('hbm_read_bytes') or 0) + (d.get('hbm_write_bytes') or 0)) or None
+            traffic_source = f'profiles/{name}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same launch (committed file, not this run)'
+            break
     if not x3:
         return {'bound': 'mfma', 'kernel': 'conv5_fwd_kernel<1,32,4,1,8,aff>: imager.15 forward (ConvT 32->32 5x5 s1, 1024x32x32x32)',
                 'achieved': flops / sec / 1e12, 'peak': MFMA_F32_PEAK / 1e12, 'unit': 'TFLOP/s',
-                'frac': flops / sec / MFMA_F32_PEAK, 'traffic': traffic, 'launch_ms': sec * 1e3}
+                'frac': flops / sec / MFMA_F32_PEAK, 'traffic': traffic, 'traffic_source': traffic_source, 'launch_ms': sec * 1e3}
     peak = MFMA_BF16_PEAK / X3_PRODUCTS
     return {'bound': 'mfma', 'kernel': 'conv5_x3_kernel<1,32,2,aff>: imager.15 forward (ConvT 32->32 5x5 s1, 1024x32x32x32), fp32 operands '
                                        'split exactly into 3 bf16 terms, 6 v_mfma_f32_32x32x16_bf16 per fp32 product tile',
             'achieved': flops / sec / 1e12, 'peak': peak / 1e12, 'unit': 'TFLOP/s', 'frac': flops / sec / peak,
-            'traffic': traffic, 'launch_ms': sec * 1e3,
+            'traffic': traffic, 'traffic_source': traffic_source, 'launch_ms': sec * 1e3,
             'peak_definition': 'dense bf16 MFMA 2500 TFLOP/s / 6 bf16 products per fp32 product',
             'bf16_mfma_achieved': X3_PRODUCTS * flops / sec / 1e12, 'vs_f32_mfma_peak': flops / sec / MFMA_F32_PEAK}
 
 
-def cpu_baseline(max_seconds=25.0):
-    """The CPU oracle (PyTorch-CPU restatement of the reference step, pinned to the reference's goldens) on the
-    host cores, bounded sample of the same workload."""
+HBM_PEAK = 8.0e12                  # MI355X HBM3E spec (6.3e12 measured achievable), MI355X_MICROARCH.md
+
+
+def bn_backward_hbm(device, reps=20):
+    """The HBM-bound side of the step (north_star asks for achieved-HBM evidence): BatchNorm(+ReLU) backward of the largest
+    activation (imager.16: 1024 x 32 x 32 x 32 fp32), launched ALONE, timed with HIP events on the launch stream.
+    Algorithmic bytes: the reduction reads dy and x (8 B/element), the apply pass reads dy and x and writes dx (12 B)."""
+    from jvae_hip import lib as L
+    lib = L.load()
+    N, C, H = 2 * BATCH_PER_GPU, 32, 32
+    x = torch.randn(N, C, H, H, device=device)
+    dy = torch.randn_like(x)
+    dx = torch.empty_like(x)
+    gamma, beta = torch.rand(C, device=device) + 0.5, torch.randn(C, device=device) * 0.1
+    mean, invstd = torch.zeros(C, device=device), torch.ones(C, device=device)
+    gg, gb = torch.empty(C, device=device), torch.empty(C, device=device)
+    ws = L.workspace(lib.jvae_bn_workspace_bytes(C), device)
+
+    def launch():
+        L.check(lib.jvae_bn_bwd_f32(L.ptr(dy), L.ptr(x), L.ptr(gamma), L.ptr(beta), L.ptr(mean), L.ptr(invstd), L.ptr(dx),
+                                    L.ptr(gg), L.ptr(gb), 0, N, C, H * H, 1, L.ptr(ws), ws.numel(), L.stream_ptr()), 'jvae_bn_bwd_f32')
+    for _ in range(3):
+        launch()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        launch()
+    e1.record()
+    torch.cuda.synchronize()
+    sec = e0.elapsed_time(e1) * 1e-3 / reps
+    nbytes = 20.0 * x.numel()
+    out = {'bound': 'hbm', 'kernel': 'bn_bwd_reduce_kernel + bn_bwd_apply_kernel: BatchNorm+ReLU backward of imager.16 (1024x32x32x32 fp32), alone',
+           'achieved': nbytes / sec / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s', 'frac': nbytes / sec / HBM_PEAK,
+           'launch_ms': sec * 1e3, 'algorithmic_bytes': nbytes}
+    prof = os.path.join(REPO, 'profiles', 'r02_bench_kernel_stats.json')
+    if os.path.exists(prof):          # the same family inside the step (two streams share the CUs): committed rocprofv3 summary
+        d = json.load(open(prof))
+        if d.get('bn_bwd_ms_per_step'):
+            out['in_step'] = {'ms_per_step': d['bn_bwd_ms_per_step'], 'achieved': 20.0 * 135.7e6 * 4 / 4 / (d['bn_bwd_ms_per_step'] * 1e-3) / 1e9,
+                              'unit': 'GB/s', 'source': 'profiles/r02_bench_kernel_stats.json (rocprofv3 --kernel-trace of bench.py)'}
+    return out
+
+
+def cpu_baseline(max_seconds=60.0):
+    """The CPU oracle (PyTorch-CPU restatement of the reference step, pinned to the reference's goldens) on the host
+    cores, bounded samples of the same workload: bs=512 (the metric's batch) and bs=32 (what the reference's unmodified
+    train.py would run: its max_batch_sizes is hard-wired to 32); median step time after warm-up steps."""
+    import platform
+    import statistics
     from oracle import jvae_oracle as O
     from oracle.cases import full_config
     from oracle.det_init import det_inputs
-    kw = full_config(2, BATCH_PER_GPU)['net']
-    sp = O.make_spec(**kw)
-    P = O.init_state(sp, seed=0)
-    opt = O.AdamState(sp)
-    x, y, eps = det_inputs(BATCH_PER_GPU, kw['input_shape'], 10, 1, 64, seed=1234)
-    O.train_step(sp, P, opt, x, y, eps)                       # warm-up
-    t0 = time.time()
-    n = 0
-    while n < 12 and time.time() - t0 < max_seconds:
-        O.train_step(sp, P, opt, x, y, eps)
-        n += 1
-    dt = time.time() - t0
-    return {'value': n * BATCH_PER_GPU / dt, 'unit': 'images/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': f'{n} train steps of bs={BATCH_PER_GPU} (config 2) with the PyTorch-CPU oracle, '
-                      f'{os.cpu_count()} logical CPUs visible'}
+    model = platform.processor() or ''
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                model = line.split(':', 1)[1].strip()
+                break
+    except OSError:
+        pass
+
+    def run(bs, steps, budget):
+        kw = full_config(2, bs)['net']
+        sp = O.make_spec(**kw)
+        P = O.init_state(sp, seed=0)
+        opt = O.AdamState(sp)
+        x, y, eps = det_inputs(bs, kw['input_shape'], 10, 1, 64, seed=1234)
+        for _ in range(2 if bs >= 256 else 3):
+            O.train_step(sp, P, opt, x, y, eps)               # warm-up
+        times, t_start = [], time.time()
+        while len(times) < steps and time.time() - t_start < budget:
+            t0 = time.time()
+            O.train_step(sp, P, opt, x, y, eps)
+            times.append(time.time() - t0)
+        med = statistics.median(times)
+        return {'batch': bs, 'steps': len(times), 'median_s_per_step': med, 'min_s_per_step': min(times), 'images_per_s': bs / med}
+    big = run(BATCH_PER_GPU, 10, max_seconds)
+    small = run(32, 20, 15.0)
+    return {'value': big['images_per_s'], 'unit': 'images/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': f'{big["steps"]} train steps of bs={BATCH_PER_GPU} (config 2) after 2 warm-up steps, median step time, with the '
+                      f'PyTorch-CPU oracle; {os.cpu_count()} logical CPUs visible, CPU: {model}',
+            'cpu_model': model, 'bs512': big, 'bs32': small}
 
 
 def _watchdog(seconds):
@@ -151,8 +217,12 @@ def main():
     ap.add_argument('--batch', type=int, default=None, help='diagnostics only: per-GPU batch (the metric is defined at 512)')
     ap.add_argument('--sync-bn', action='store_true', help='BatchNorm statistics over all ranks (default: per rank)')
     ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'], help='bf16: the mixed-precision mode of BASELINE configs[4]')
-    ap.add_argument('--workload', type=int, default=2, choices=sorted(WORKLOADS), help='diagnostics: other BASELINE configs')
+    ap.add_argument('--workload', default='2', choices=[str(k) for k in sorted(WORKLOADS)] + ['eval'],
+                    help="diagnostics: other BASELINE configs; 'eval' = the label-free evaluation pass (SURVEY.md §8f-1): config 2, "
+                         "N=512 images, L=128 latent draws (decoder batch 66 048) per step")
     a = ap.parse_args()
+    eval_mode = a.workload == 'eval'
+    a.workload = 2 if eval_mode else int(a.workload)
     fh = _watchdog(900)
     if a.batch is None:
         a.batch = 256 if a.workload == 5 else BATCH_PER_GPU
@@ -176,11 +246,11 @@ def main():
     device = torch.device('cuda', local)
     torch.cuda.set_device(device)
 
-    net = build_model(device, a.workload)
+    net = build_model(device, a.workload, test_latent_sampling=128 if eval_mode else 1)
     if a.dtype == 'bf16':
         net.set_compute_dtype('bf16')
     if world > 1:
-        net.optimizer.set_distributed(world)
+        net.set_distributed(world)          # broadcasts rank 0's state, offsets the epsilon generator per rank
         if a.sync_bn:
             net.set_sync_batchnorm(world)
     g = torch.Generator(device=device).manual_seed(1234 + rank)
@@ -194,14 +264,29 @@ def main():
             torch.cuda.synchronize()
 
     meas = None
+    if eval_mode:
+        net.eval()
+
+        def one_step(i, meas):
+            with torch.no_grad():
+                _, _, losses, meas = net.evaluate(x, batch=i, current_measures=meas)
+            return losses, meas
+    else:
+        def one_step(i, meas):
+            return net.train_step(x, y, batch=i, current_measures=meas)
     for i in range(a.warmup):
-        _, meas = net.train_step(x, y, batch=i, current_measures=meas)
+        _, meas = one_step(i, meas)
     sync()
+    # per-step HIP events on the launch stream (median / min are reported beside the contract's mean over the K steps)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
     t0 = time.time()
+    marks[0].record()
     for i in range(a.steps):
-        losses, meas = net.train_step(x, y, batch=i, current_measures=meas)
+        losses, meas = one_step(i, meas)
+        marks[i + 1].record()
     sync()
     dt = time.time() - t0
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps))
     if dist is not None:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -209,10 +294,17 @@ def main():
     value = world * a.batch * a.steps / dt
 
     if rank == 0:
-        out = {'metric': 'training_images_per_sec', 'value': value, 'unit': 'images/s', 'n_gpus': world,
-               'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': dt / a.steps * 1e3, 'higher_is_better': True,
+        out = {'metric': 'evaluation_images_per_sec (diagnostic)' if eval_mode else 'training_images_per_sec', 'value': value,
+               'unit': 'images/s', 'n_gpus': world,
+               'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': dt / a.steps * 1e3,
+               'ms_per_step_median': per_step[len(per_step) // 2], 'ms_per_step_min': per_step[0],
+               'timing': 'value / ms_per_step: wall clock over the K steps between barrier+synchronize (max over ranks); '
+                         'median / min: HIP events around every step on the launch stream of rank 0',
+               'higher_is_better': True,
                'scaling': 'weak', 'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
-               'config': {'workload': WORKLOADS[a.workload][0],
+               'config': {'workload': ('label-free evaluation pass of BASELINE configs[1] (all-class losses + importance-weighted bound), '
+                                       'N=512 images x L=128 latent draws per step, eval-mode BatchNorm, fp32'
+                                       if eval_mode else WORKLOADS[a.workload][0]),
                           'global_batch': world * a.batch, 'parallelism': f'dp{world}',
                           'bn_statistics': 'synchronised over ranks' if (a.sync_bn and world > 1) else 'per-rank (local)',
                           'arithmetic': ('fp32 operands, products and accumulation everywhere; the stride-1 and 4-phase 5x5 layers '
@@ -222,11 +314,15 @@ def main():
                                          if (a.dtype == 'f32' and os.environ.get('JVAE_X3', '1') != '0') else
                                          ('fp32 MFMA in every layer' if a.dtype == 'f32' else
                                           'bf16 activations / MFMA operands, fp32 accumulation, statistics, losses, optimiser'))},
-               'step_mfma_frac': value / world * WORKLOADS[a.workload][1] / (MFMA_F32_PEAK if a.dtype == 'f32' else MFMA_BF16_PEAK),
                'final_loss': float(losses['total'].detach().mean())}
-        if a.workload == 2 and a.dtype == 'f32':      # the roofline probe and the CPU baseline belong to the headline config
+        if not eval_mode:
+            # NOT a utilisation figure: algorithmic conv/linear FLOPs per second divided by the fp32-MFMA peak the north-star
+            # target (>= 0.5) is phrased in; most of those FLOPs run on the bf16 pipes (6 bf16 products per fp32 product)
+            out['step_throughput_vs_f32_mfma_peak'] = value / world * WORKLOADS[a.workload][1] / (MFMA_F32_PEAK if a.dtype == 'f32' else MFMA_BF16_PEAK)
+        if a.workload == 2 and a.dtype == 'f32' and not eval_mode:      # the roofline probes and the CPU baseline belong to the headline config
             out['roofline'] = dominant_kernel_roofline(device)
-        if world == 1 and not a.no_cpu_baseline and a.workload == 2 and a.dtype == 'f32':
+            out['roofline_hbm'] = bn_backward_hbm(device)
+        if world == 1 and not a.no_cpu_baseline and a.workload == 2 and a.dtype == 'f32' and not eval_mode:
             out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out))
     if dist is not None:

@@ -371,6 +371,30 @@ class ClassificationVariationalNetwork(nn.Module):
     def nparams(self):
         return sum(p.nelement() for p in self.parameters())
 
+    def set_distributed(self, world_size, process_group=None, seed_offset=True):
+        """Data-parallel replica set-up (no counterpart in the single-process reference): rank 0's
+        parameters, BatchNorm buffers and optimiser state are broadcast to every rank (replicas no longer rely on identical
+        seeding), the gradient exchange is switched on, and - seed_offset - the device generator that draws the
+        reparameterisation noise is re-seeded per rank so that ranks draw DIFFERENT epsilon (and dropout masks)."""
+        import torch.distributed as dist
+        world_size = int(world_size)
+        if world_size > 1 and dist.is_available() and dist.is_initialized():
+            with torch.no_grad():
+                for t in self.state_dict().values():
+                    if t.is_cuda and dist.get_backend(process_group) != 'nccl':
+                        h = t.cpu()
+                        dist.broadcast(h, 0, group=process_group)
+                        t.copy_(h)
+                    else:
+                        dist.broadcast(t, 0, group=process_group)
+            if seed_offset:
+                rank = dist.get_rank(process_group)
+                base = torch.initial_seed()
+                if torch.cuda.is_available():
+                    torch.cuda.manual_seed(base + 7919 * (rank + 1))
+        self.optimizer.set_distributed(world_size, process_group)
+        return self
+
     def set_sync_batchnorm(self, world_size, process_group=None):
         """Data-parallel option: BatchNorm statistics over ALL ranks, i.e. exactly what the single-process
         reference computes on the global batch (default: per-rank statistics, as DistributedDataParallel does)."""
@@ -487,7 +511,8 @@ class ClassificationVariationalNetwork(nn.Module):
         except ValueError as err:
             self._dump_after_encoder_error(err, x, y)
             raise
-        if self.training and self.optimizer._world > 1 and z.requires_grad:
+        if self.training and self.optimizer._world > 1 and z.requires_grad and not getattr(self, '_graph_capture', False) \
+                and not getattr(self.optimizer, '_external_reduce', False):
             # data-parallel: the decoder's gradients are final once d(loss)/dz exists -> start their all-reduce there
             z.register_hook(self._early_reduce_hook)
         x_, logits = self._decode(z)
@@ -537,8 +562,11 @@ class ClassificationVariationalNetwork(nn.Module):
         The heavy parts (conv stacks on (L+1)N latents, BatchNorm, latent / KL kernel on C*N rows, reconstruction,
         Mahalanobis distances of the L*C*N sampled latents, the importance-weight assembly) run on the HIP kernels."""
         if self.y_is_coded or self.is_jvae:
-            raise NotImplementedError('the all-class evaluation of models with coded labels (x repeated along the classes '
-                                      'through the encoder) is not built: pass y')
+            # The reference cannot do it either: cvae.py:593-600 builds the (C, N) label grid and forward() (cvae.py:451)
+            # then calls y.view(N) on it - "RuntimeError: shape '[N]' is invalid for input of size C*N" for conv and MLP
+            # models alike (probed on the reference in the build container).  Same outcome, clearer message.
+            raise NotImplementedError('evaluate(x) without labels is not possible for models with coded labels (the '
+                                      'reference fails on it: cvae.py:451): pass y')
         if x.dim() != self.input_dim + 1:
             x = x.reshape(-1, *self.input_shape)
         N, C, K = x.shape[0], self.num_labels, self.latent_dim
@@ -643,6 +671,85 @@ class ClassificationVariationalNetwork(nn.Module):
             out[name] = v.cpu() if to_cpu else v
         return out
 
+    def accuracy(self, testset=None, batch_size=100, num_batch='all', method='all', print_result=False,
+                 update_self_testing=True, outputs=None, sample_dirs=[], recorder=None, epoch='last', from_where='all',
+                 epoch_tolerance=0, log=True):
+        """Classification accuracy of `testset` (any map-style dataset of (x, label)) per prediction method, with the
+        reference's signature and bookkeeping (cvae.py:1187-1452): every batch goes through the label-free evaluation
+        (all-class losses, `iws`: SURVEY.md §8f-1); with a `LossRecorder` the per-sample losses, `logits.T` and the labels are
+        recorded batch by batch and written as `record-<set>.pth` into `sample_dirs` (the files test.py / results/ of the
+        reference read, §8f-3) - or, if the recorder already holds the batches, the losses are RECOVERED from it instead of
+        being computed.  Named torchvision datasets and the registry lookup of earlier results (`from_where`) are host-side
+        plumbing outside this build: pass the dataset."""
+        if testset is None or isinstance(testset, str):
+            raise NotImplementedError('named torchvision datasets are outside this build: pass a torch.utils.data.Dataset')
+        name = getattr(testset, 'name', 'testset')
+        only_one = isinstance(method, str) and method != 'all'
+        methods = list(self.predict_methods) if method == 'all' else ([method] if only_one else list(method))
+        full = int(np.ceil(len(testset) / batch_size))
+        shuffle = not (num_batch == 'all' or num_batch >= full)
+        num_batch = full if not shuffle else int(num_batch)
+        if epoch == 'last':
+            epoch = self.trained
+        recorded = recorder is not None and len(recorder) >= num_batch
+        recording = recorder is not None and not recorded
+        if recorded:
+            num_batch, batch_size = len(recorder), recorder.batch_size
+        if recording:
+            recorder.reset()
+            recorder.num_batch = num_batch
+        if recorder is not None:
+            recorder.init_seed_for_dataloader()
+        device = self.device
+        was_training = self.training
+        self.eval()
+        loader = iter(torch.utils.data.DataLoader(testset, batch_size=batch_size, num_workers=0, shuffle=shuffle))
+        errors = torch.zeros(len(methods), device=device)
+        sums, n, measures, t0 = {}, 0, None, time.time()
+        with torch.no_grad():
+            for i in range(num_batch):
+                if recorded:
+                    keys = [k for k in recorder.keys() if k in self.loss_components]
+                    losses = recorder.get_batch(i, *keys, force_dict=True)
+                    logits = recorder.get_batch(i, 'logits').T
+                    y = recorder.get_batch(i, 'y_true')
+                else:
+                    x, y = next(loader)[:2]
+                    x, y = x.to(device), y.to(device)
+                    _, logits, losses, measures = self.evaluate(x, batch=i, current_measures=measures)
+                preds = [self.predict_after_evaluate(logits, losses, method=m) for m in methods]
+                if recording:
+                    recorder.append_batch(**losses, y_true=y, logits=logits.T)
+                errors += torch.stack([(p != y).sum() for p in preds]).float()
+                for k, v in losses.items():                     # loss of the TRUE class where a loss is per class (C, N)
+                    v = v.gather(0, y.unsqueeze(0))[0] if v.dim() == 2 else v
+                    sums[k] = sums.get(k, 0.) + v.float().mean()
+                n += y.numel()
+                if print_result and outputs is not None and hasattr(outputs, 'results'):
+                    acc_now = (1 - errors / n).tolist()
+                    outputs.results(i, num_batch, 0, 0, losses={k: float(sums[k]) / (i + 1) for k in self.loss_components if k in sums},
+                                    metrics={k: (measures or {}).get(k, np.nan) for k in self.metrics},
+                                    accuracy=dict(zip(methods, acc_now)), time_per_i=(time.time() - t0) / (i + 1),
+                                    batch_size=batch_size, preambule=print_result)
+        acc = dict(zip(methods, (1 - errors / max(n, 1)).tolist()))
+        self.test_losses = {k: float(v) / max(num_batch, 1) for k, v in sums.items()}
+        if measures:
+            self.test_measures = dict(measures)
+        if recorder is not None:
+            recorder.restore_seed()
+        if recording:
+            for d in sample_dirs:
+                os.makedirs(d, exist_ok=True)
+                recorder.save(os.path.join(d, 'record-{}.pth'.format(name)))
+        if update_self_testing:
+            for m in methods:
+                if n > self.testing.get(epoch, {}).get(m, {'n': 0})['n']:
+                    self.testing.setdefault(epoch, {})[m] = {'n': n, 'epochs': epoch,
+                                                             'sampling': self._latent_samplings['eval'], 'accuracy': acc[m]}
+        if was_training:
+            self.train()
+        return acc[methods[0]] if only_one else acc
+
     def _early_reduce_hook(self, grad):
         self.optimizer.reduce_early_bucket()
         return grad
@@ -726,21 +833,31 @@ class ClassificationVariationalNetwork(nn.Module):
         enqueue work.  No counterpart in the reference (its loop is eager).  Differences from train_step(): epsilon is
         drawn inside the graph (the generator's offset advances per replay), `measures` are those of the current batch
         only (batch index 0), the `losses` tensors are the graph's own buffers (overwritten by the next replay), the
-        warm-up weights and the data-parallel exchange are not captured (single process, fixed kl / gamma weights)."""
-        if getattr(self.optimizer, '_world', 1) > 1:
-            raise NotImplementedError('graph_train_step: single-process only')
+        warm-up weights are fixed (kl / gamma weights of the call).  Data parallel (optimizer.set_distributed): see below -
+        two captured halves with the gradient all-reduce between them.  Drop every reference to the outputs of earlier EAGER
+        steps (losses, measures) before calling this: a live eager autograd graph keeps its gradient-accumulation nodes bound
+        to the default stream, which a capture must not touch."""
+        world = getattr(self.optimizer, '_world', 1)
         dev = x.device
         self.optimizer.enable_device_hyper(True)
         sx, sy = x.clone(), y.clone()
+        from jvae_hip import lib as _lib
 
-        def body():
+        def fwd_bwd():
             self.optimizer.zero_grad()
             _, _, losses, raw = self.evaluate(sx, sy, batch=0, with_beta=True, kl_var_weighting=kl_var_weighting,
                                               gamma_weighting=gamma_weighting, _raw_measures=True)
             losses['total'].mean().backward()
+            return losses, raw
+
+        def update():
             self.optimizer.clip(self.parameters())
             self.optimizer.step()
-            return losses, raw
+
+        def body():
+            out = fwd_bwd()
+            update()
+            return out
 
         s = torch.cuda.Stream(device=dev)
         s.wait_stream(torch.cuda.current_stream(dev))
@@ -749,6 +866,35 @@ class ClassificationVariationalNetwork(nn.Module):
                 body()
         torch.cuda.current_stream(dev).wait_stream(s)
         torch.cuda.synchronize(dev)
+        if world > 1:
+            # Data parallel: the step is captured in TWO graphs - [zero_grad, forward, backward] and [clip, Adam] - with the
+            # gradient exchange (ONE all-reduce of the flat buffer, any backend) issued eagerly between them: three host
+            # calls per step.  The early-bucket overlap of the eager path is given up (the exchange is ~0.1 ms of a ~4 ms step).
+            self._graph_capture = True                  # evaluate() must not launch the early-bucket hook while capturing
+            self.optimizer._external_reduce = True
+            try:
+                ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                with torch.cuda.graph(ga):
+                    losses, (packed, has_dict) = fwd_bwd()
+                    _lib.join_side_stream()             # weight gradients of the side stream: inside the captured half
+                with torch.cuda.graph(gb, pool=ga.pool()):
+                    update()
+            finally:
+                self._graph_capture = False
+            for g in self.optimizer._groups:
+                g.step -= 1
+
+            def step(xb, yb):
+                sx.copy_(xb, non_blocking=True)
+                sy.copy_(yb, non_blocking=True)
+                ga.replay()
+                self.optimizer.all_reduce_flat()
+                gb.replay()
+                self.optimizer.note_replayed_step()
+                return losses, Measures(packed, has_dict, _grad_nan_exit, from_main=True)
+
+            step.graph = (ga, gb)
+            return step
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             losses, (packed, has_dict) = body()

@@ -127,10 +127,40 @@ class Optimizer:
                 self.update_lr()
 
     # ---- data-parallel hook (no equivalent in the single-process reference) ----------
-    def set_distributed(self, world_size, process_group=None):
-        """Average gradients over `world_size` ranks (one RCCL all-reduce per flat group) before clip/step."""
+    def set_distributed(self, world_size, process_group=None, broadcast=True):
+        """Average gradients over `world_size` ranks (RCCL all-reduce of the flat gradient buffer) before clip/step.
+        broadcast: rank 0's optimiser state (Adam moments, step count, lr) replaces every other rank's, so replicas do not
+        depend on identical seeding / loading (the PARAMETERS and BatchNorm buffers are broadcast by the model:
+        ClassificationVariationalNetwork.set_distributed)."""
         self._world = int(world_size)
         self._pg = process_group
+        if self._world > 1 and broadcast:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                meta = torch.tensor([float(self._lr)] + [float(g.step) for g in self._groups], dtype=torch.float64)
+                if dist.get_backend(process_group) == 'nccl':          # RCCL moves device memory only
+                    meta = meta.to(torch.device('cuda', torch.cuda.current_device()))
+                dist.broadcast(meta, 0, group=process_group)
+                self._lr = float(meta[0])
+                staged = dist.get_backend(process_group) != 'nccl'
+                for i, g in enumerate(self._groups):
+                    g.step = int(meta[1 + i])
+                    for buf in (g.m, g.v):
+                        if staged and buf.is_cuda:                     # gloo rehearsal on a GPU: through host memory
+                            h = buf.cpu()
+                            dist.broadcast(h, 0, group=process_group)
+                            buf.copy_(h)
+                        else:
+                            dist.broadcast(buf, 0, group=process_group)
+                self._sync_device_lr()
+
+    def all_reduce_flat(self):
+        """ONE all-reduce (AVG) per flat group, eagerly, on the current stream: the exchange step between the two captured
+        halves of a data-parallel graph step (graph_train_step)."""
+        if self._world > 1:
+            import torch.distributed as dist
+            for g in self._groups:
+                dist.all_reduce(g.g, op=dist.ReduceOp.AVG, group=self._pg)
 
     def set_early_bucket(self, params):
         """Parameters whose gradients are complete first in backward (the decoder / imager): their slice of the flat
@@ -143,10 +173,17 @@ class Optimizer:
         """(group, lo, hi) of the contiguous flat range holding the early-bucket parameters, or None."""
         ids = {id(p) for p in getattr(self, '_early', [])}
         if not ids or len(self._groups) != 1:
+            if ids and self._world > 1 and not getattr(self, '_early_warned', False):
+                self._early_warned = True
+                logging.warning('data-parallel: %d flat gradient groups - the early (decoder) bucket is not overlapped',
+                                len(self._groups))
             return None
         g = self._groups[0]
         idx = [i for i, p in enumerate(g.params) if id(p) in ids]
         if not idx or idx != list(range(idx[0], idx[-1] + 1)):
+            if idx and self._world > 1 and not getattr(self, '_early_warned', False):
+                self._early_warned = True
+                logging.warning('data-parallel: the early bucket is not contiguous in the flat buffer - not overlapped')
             return None
         lo = g.offsets[idx[0]]
         hi = g.offsets[idx[-1] + 1] if idx[-1] + 1 < len(g.params) else g.numel
@@ -173,6 +210,8 @@ class Optimizer:
         self._early_range = (lo, hi)
 
     def reduce_gradients(self):
+        if getattr(self, '_external_reduce', False):     # graph step: join + exchange happen outside the captured halves
+            return
         from jvae_hip import lib as _lib
         if _lib._side_streams:
             _lib.join_side_stream()              # weight gradients written on the side stream are complete
@@ -208,6 +247,11 @@ class Optimizer:
             self._rebuild()
         known = self._flat_ids()
         fresh = [p for p in self._all if id(p) not in known and p.requires_grad and p.grad is not None]
+        early = {id(p) for p in getattr(self, '_early', [])}
+        if early:
+            # the early (decoder) bucket goes to the END of the flat buffer: the data-parallel exchange is then exactly
+            # two collectives - the bucket, launched from the hook on z, and ONE contiguous remainder
+            fresh = [p for p in fresh if id(p) not in early] + [p for p in fresh if id(p) in early]
         if fresh:
             # flattening itself is device-agnostic (the data-parallel exchange is tested on CPU with gloo);
             # clip() / step() launch HIP kernels and raise for tensors that are not on the GPU

@@ -2,8 +2,9 @@
 (utils/torch_load.py:405-426 with data_augmentation=['flip','crop'], transformer='simple'):
 RandomHorizontalFlip -> RandomCrop(size, padding=size//8, padding_mode='edge') -> ToTensor (uint8 HWC -> float CHW / 255),
 with the random decisions passed in.  torchvision 0.x semantics (torchvision.transforms.functional.hflip / pad(mode='edge')
-/ crop / to_tensor); torchvision is NOT installed in this image, so this restatement is pinned only by its own
-construction from numpy primitives (np.pad(mode='edge'), slicing): "parity unpinned" for this row.
+/ crop / to_tensor).  torchvision is NOT installed in this image; the restatement is pinned (tests/test_augment_oracle.py)
+to the torch calls torchvision's tensor code path is made of - x.flip(-1), torch.nn.functional.pad(mode='replicate'),
+slicing, .to(float32).div(255) - bit for bit on random uint8 batches.
 """
 import numpy as np
 

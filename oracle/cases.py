@@ -79,6 +79,9 @@ EVAL_CASES = {
                                     prior=dict(distribution='gaussian', init_mean=0., learned_means=True,
                                                var_dim='diag', freeze_means=0)), N=6),
     'e2_n8_gamma_L2': dict(net=_conv(10, gamma=2.0, classifier=[20], test_latent_sampling=2), N=8),
+    # the sampling the evaluation path exists for (L >> 1; x_reco kept as per-image checksums)
+    'e2_n16_L16': dict(net=_conv(10, test_latent_sampling=16), N=16),
+    'e3_n8_L32': dict(net=_conv(100, test_latent_sampling=32), N=8),
     'e2_n8_rmse_L2': dict(net=_conv(10, sigma={'is_rmse': True}, test_latent_sampling=2), N=8),
     'e2_n8_coded_L2': dict(net=_conv(10, sigma={'input_dim': (3, 32, 32)}, test_latent_sampling=2), N=8),
 }
@@ -121,6 +124,9 @@ DSL_CASES['x2_n8_xvae'] = dict(net=_conv(10, type='xvae', gamma=2.0, classifier=
                                gamma_weighting=0.5)
 
 DSL_EVAL_CASES = {
+    # NOT here: evaluate(x) without labels for models with CODED labels (jvae, y_is_coded).  The reference cannot run it:
+    # cvae.py:593-600 builds the (C, N) label grid, cvae.py:451 then does y.view(N) on it -> "RuntimeError: shape '[N]' is
+    # invalid for input of size C*N" (probed for conv and MLP models in the build container); the drop-in raises as well.
     'ex2_n8_xvae_L2': dict(net=_conv(10, type='xvae', gamma=2.0, classifier=[20], test_latent_sampling=2), N=8),
     'ea2_n8_vae_L3': dict(net=_conv(10, type='vae', test_latent_sampling=3,
                                     prior=dict(distribution='gaussian', init_mean=0., var_dim='scalar')), N=8),

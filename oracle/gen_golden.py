@@ -204,7 +204,12 @@ def run_eval_case(Net, name):
     with torch.no_grad(), inject_eps(eps):
         x_reco, y_est, losses, measures = net.evaluate(x, batch=0)
     out['L'] = np.int64(L)
-    out['x_reco'] = x_reco.numpy()
+    if L >= 8:                                # compact: per-image mean / norm of the (L+1, N, ...) reconstruction
+        xr = x_reco.double().flatten(2)
+        out['x_reco_mean'] = xr.mean(-1).numpy()
+        out['x_reco_norm'] = xr.norm(dim=-1).numpy()
+    else:
+        out['x_reco'] = x_reco.numpy()
     out['y_est'] = y_est.numpy()
     for k, v in losses.items():
         out['loss.' + k] = v.numpy()

@@ -183,3 +183,54 @@ def test_sigma_matches_reference_forms(golden_dir):
                     check(s, want)
             twin = copy.deepcopy(s)
             assert str(twin) == str(s) and torch.equal(twin.data, s.data)
+
+
+def test_loss_recorder_reads_and_writes_the_reference_format(tmp_path, golden_dir):
+    """`record-<set>.pth` (utils/save_load/recorders.py:107-174).  tests/golden/record_ref was written by
+    the REFERENCE's LossRecorder (oracle/gen_record_fixture.py).  The drop-in recorder loads both files (cut / uncut),
+    returns what the reference's accessors returned, re-records the same batches into a file with the same dictionary
+    (keys, scalars, tensors bit for bit), and merges like the reference."""
+    from jvae_compat.recorders import LossRecorder
+    src = os.path.join(golden_dir, 'record_ref')
+    exp = np.load(os.path.join(src, 'expected.npz'))
+    for name in ('record-demo.pth', 'record-demo-uncut.pth'):
+        r = LossRecorder.load(os.path.join(src, name))
+        assert len(r) == int(exp['len']) and r.recorded_samples == int(exp['recorded_samples']) and r.batch_size == 4
+        assert list(r.keys()) == ['total', 'kl', 'cross_x', 'logits', 'y_true']
+        for k in r:
+            assert np.array_equal(r[k].numpy(), exp['all.' + k]), (name, k)
+            assert np.array_equal(r.get_batch(3, k).numpy(), exp['b3.' + k]) and np.array_equal(r.get_batch(1, k).numpy(), exp['b1.' + k])
+        assert r.has_batch(3) and not r.has_batch(3, only_full=True) and not r.has_batch(4)
+    # re-record the same batches (as oracle/gen_record_fixture.py made them) and compare the files' dictionaries
+    C, B, sizes = 3, 4, [4, 4, 4, 2]
+
+    def batch(i, n):
+        g = torch.Generator().manual_seed(50 + i)
+        return dict(total=torch.randn(C, n, generator=g), kl=torch.randn(C, n, generator=g), cross_x=torch.randn(n, generator=g),
+                    logits=torch.randn(C, n, generator=g), y_true=torch.randint(0, C, (n,), generator=g))
+    mine = LossRecorder(B, **batch(0, B))
+    for i, n in enumerate(sizes):
+        mine.append_batch(**batch(i, n))
+    assert mine.num_batch == int(exp['num_batch_before_save'])
+    for cut, name in ((False, 'record-demo-uncut.pth'), (True, 'record-demo.pth')):
+        out = os.path.join(tmp_path, name)
+        mine.save(out, cut=cut)
+        a = torch.load(out, weights_only=False)
+        b = torch.load(os.path.join(src, name), weights_only=False)
+        assert set(a) == set(b), (set(a) ^ set(b))
+        for k in b:
+            if k == '_tensors':
+                assert list(a[k]) == list(b[k])
+                for t in b[k]:
+                    assert a[k][t].dtype == b[k][t].dtype and torch.equal(a[k][t], b[k][t]), (name, t)
+            elif k != '_seed':                     # the seed is random by design
+                assert a[k] == b[k], (name, k, a[k], b[k])
+    assert mine.num_batch == int(exp['num_batch_after_cut'])
+    other = LossRecorder(B, **batch(0, B))
+    other.append_batch(**batch(7, 3))
+    merged = LossRecorder.load(os.path.join(tmp_path, 'record-demo.pth'))
+    merged.merge(other)
+    assert len(merged) == int(exp['merged.len']) and merged.recorded_samples == int(exp['merged.recorded_samples'])
+    assert merged.last_batch_size == int(exp['merged.last_batch_size'])
+    assert np.array_equal(merged['total'].numpy(), exp['merged.total'])
+    assert set(LossRecorder.loadall(str(tmp_path))) == {'demo', 'demo-uncut'}

@@ -299,7 +299,12 @@ def test_eval_path_matches_reference_golden(name, golden_dir):
     assert net.latent_sampling == L
     x, y, eps = det_inputs(case['N'], kw['input_shape'], kw['num_labels'], L, kw['latent_dim'])
     x_reco, y_est, losses, meas = net.evaluate(x.to(DEV), epsilon=eps.to(DEV))
-    assert rel(x_reco, g['x_reco']) < RTOL and rel(y_est, g['y_est']) < 5e-4
+    if 'x_reco' in g.files:
+        assert rel(x_reco, g['x_reco']) < RTOL
+    else:
+        xr = x_reco.double().flatten(2)
+        assert rel(xr.mean(-1), g['x_reco_mean']) < RTOL and rel(xr.norm(dim=-1), g['x_reco_norm']) < RTOL
+    assert rel(y_est, g['y_est']) < 5e-4
     for k in [f[5:] for f in g.files if f.startswith('loss.')]:
         assert tuple(losses[k].shape) == g['loss.' + k].shape, k
         assert rel(losses[k], g['loss.' + k]) < RTOL, k
@@ -642,3 +647,82 @@ def test_encoder_value_error_dumps_model_and_batch(tmp_path, monkeypatch):
     where = os.path.join(tmp_path, 'log', 'dump-4242')
     assert {'params.json', 'state.pth', 'optimizer.pth', 'x.pt', 'y.pt'} <= set(os.listdir(where))
     assert torch.equal(torch.load(os.path.join(where, 'x.pt')).cpu(), x.cpu())
+
+
+def test_label_free_evaluation_with_coded_labels_is_refused_like_the_reference_fails():
+    """evaluate(x) without labels for a model whose labels are coded into the encoder (jvae / y_is_coded): the reference
+    raises `RuntimeError: shape '[N]' is invalid for input of size C*N` at cvae.py:451 (probed on the reference, conv and MLP
+    models); the drop-in refuses as well.  With labels the same model evaluates (golden j2_n8_jvae)."""
+    net = build(get_case('j2_n8_jvae'))
+    net.eval()
+    x, y, eps = (t.to(DEV) for t in det_inputs(8, (3, 32, 32), 10, net.latent_sampling, 64))
+    with pytest.raises(NotImplementedError):
+        net.evaluate(x)
+    out = net.evaluate(x, y, epsilon=eps)
+    assert tuple(out[2]['total'].shape) == (8,)
+
+
+def test_eval_path_at_full_size_n512_l128():
+    """SURVEY.md §8f-1 at the size it exists for: N = 512 images, L = 128 latent draws (decoder batch 129 * 512 = 66 048
+    images) in ONE evaluate(x).  Eval-mode BatchNorm makes samples independent, so (i) a subset of the batch evaluated
+    alone, with its rows of the same epsilon, must give the same per-sample losses, (ii) that subset is checked against the
+    CPU oracle at L = 128, (iii) predictions are label-valued and the importance-weighted bound is finite everywhere."""
+    case = dict(get_case('e2_n8_L3'))
+    kw = dict(case['net'], test_latent_sampling=128)
+    from cvae import ClassificationVariationalNetwork as Net
+    net = Net(**kw)
+    load_det_state(net, seed=0)
+    net.to(DEV).eval()
+    N, L, K, C = 512, 128, kw['latent_dim'], kw['num_labels']
+    x, y, eps = det_inputs(N, kw['input_shape'], C, L, K, seed=11)
+    xd, ed = x.to(DEV), eps.to(DEV)
+    with torch.no_grad():
+        x_reco, y_est, losses, meas = net.evaluate(xd, epsilon=ed)
+    assert tuple(x_reco.shape) == (L + 1, N, 3, 32, 32) and tuple(losses['iws'].shape) == (C, N)
+    assert all(bool(torch.isfinite(v).all()) for v in losses.values())
+    pick = torch.tensor([0, 7, 100, 255, 256, 300, 444, 511])
+    with torch.no_grad():
+        _, ye_s, ls, _ = net.evaluate(xd[pick.to(DEV)], epsilon=ed[:, pick.to(DEV)])
+    for k, v in losses.items():
+        sub = v[..., pick.to(DEV)]
+        assert rel(ls[k], sub) < 2e-5, k
+    assert rel(ye_s, y_est[pick.to(DEV)]) < 2e-5
+    sp = O.make_spec(**kw)
+    P = O.init_state(sp, seed=0)
+    with torch.no_grad():
+        _, ye_o, lo, _ = O.evaluate_all_classes(sp, P, x[pick], eps[:, pick])
+    for k in ('total', 'iws', 'kl', 'zdist', 'cross_x', 'wmse'):
+        assert rel(ls[k], lo[k]) < RTOL, k
+    assert np.array_equal(net.predict_after_evaluate(ye_s, ls, method='iws').cpu().numpy(), O.predict(lo, ye_o, 'iws').numpy())
+    pred = net.predict_after_evaluate(y_est, losses, method='iws')
+    assert pred.dtype == torch.int64 and int(pred.min()) >= 0 and int(pred.max()) < C
+
+
+def test_accuracy_loop_records_and_recovers(tmp_path):
+    """accuracy() (cvae.py:1187-1452) over a synthetic test set: per-method accuracies, `testing` bookkeeping, the
+    per-sample losses recorded into `record-<set>.pth` in the reference's format (the file layout itself is
+    pinned on the CPU against a reference-written file), and a second pass RECOVERED from that file giving the same numbers."""
+    from cvae import ClassificationVariationalNetwork as Net
+    from jvae_compat.recorders import LossRecorder
+    kw = dict(get_case('e2_n8_L3')['net'])
+    net = Net(**kw)
+    load_det_state(net, seed=0)
+    net.to(DEV)
+    torch.manual_seed(3)
+    data = torch.utils.data.TensorDataset(torch.rand(70, 3, 32, 32), torch.randint(0, 10, (70,)))
+    data.name = 'synth'
+    rec = LossRecorder(32)
+    torch.manual_seed(5)
+    acc = net.accuracy(data, batch_size=32, recorder=rec, sample_dirs=[str(tmp_path)])
+    assert set(acc) == set(net.predict_methods) and all(0. <= a <= 1. for a in acc.values())
+    assert net.testing[0]['iws']['n'] == 70 and net.testing[0]['iws']['accuracy'] == acc['iws']
+    path = os.path.join(tmp_path, 'record-synth.pth')
+    d = torch.load(path, weights_only=False)
+    assert {'batch_size', 'last_batch_size', '_num_batch', '_samples', '_recorded_batches', '_tensors', '_seed', 'device'} == set(d)
+    assert d['_recorded_batches'] == 3 and d['last_batch_size'] == 6 and d['batch_size'] == 32
+    assert tuple(d['_tensors']['iws'].shape) == (10, 70) and tuple(d['_tensors']['cross_x'].shape) == (70,)
+    assert tuple(d['_tensors']['logits'].shape) == (10, 70) and torch.equal(d['_tensors']['y_true'].cpu(), data.tensors[1])
+    again = LossRecorder.load(path, device=DEV)
+    acc2 = net.accuracy(data, batch_size=32, recorder=again)               # recovered from the record: nothing is evaluated
+    assert acc2 == acc
+    assert isinstance(net.accuracy(data, batch_size=32, method='closest'), float)

@@ -80,3 +80,57 @@ def test_sync_batchnorm_matches_single_process(tmp_path):
     running = [k for k in mine if k.endswith('running_var')]
     for k in running:                    # the statistics themselves: global-batch values on every rank
         assert rel(ranks[0]['params'][k], mine[k]) < 1e-5, k
+
+
+def _graph_worker(rank, port, out_dir):
+    """2 ranks (gloo, one GPU): replicas built from DIFFERENT seeds are brought together by set_distributed's broadcast;
+    the data-parallel step then runs as two captured HIP graphs with one all-reduce between them."""
+    _paths()
+    import torch.distributed as dist
+    from cvae import ClassificationVariationalNetwork as Net
+    from oracle.cases import get_case
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=WORLD)
+    torch.cuda.set_device(0)
+    torch.manual_seed(100 + rank)                       # different initial weights on purpose
+    kw = get_case('c2_n8')['net']
+    net = Net(**kw).to('cuda')
+    net.train()
+    net.set_distributed(WORLD)
+    g = torch.Generator().manual_seed(50 + rank)        # each rank its own shard
+    x = torch.rand(16, 3, 32, 32, generator=g).cuda()
+    y = torch.randint(0, 10, (16,), generator=g).cuda()
+    eager_losses, _ = net.train_step(x, y)               # one eager data-parallel step (early bucket + remainder)
+    first = float(eager_losses['total'].detach().mean())
+    del eager_losses                                    # frees the eager autograd graph (its AccumulateGrad nodes are bound to the
+    torch.cuda.synchronize()                            # default stream and must not survive into the capture)
+    step = net.graph_train_step(x, y, warmup=1)
+    assert isinstance(step.graph, tuple) and len(step.graph) == 2
+    for _ in range(6):
+        losses, meas = step(x, y)
+    torch.cuda.synchronize()
+    last = float(losses['total'].detach().mean())
+    eps_probe = torch.randn(4, device='cuda')           # the device generator was offset per rank: ranks draw different noise
+    torch.save({'params': {k: v.detach().cpu() for k, v in net.state_dict().items()}, 'first': first, 'last': last,
+                'opt_step': net.optimizer._groups[0].step, 'eps_probe': eps_probe.cpu(), 'rmse': meas['rmse']},
+               os.path.join(out_dir, f'g{rank}.pt'))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_graph_captured_data_parallel_step(tmp_path):
+    """graph_train_step() under data parallelism - [zero_grad, forward, backward] and [clip, Adam] as two
+    HIP graphs with the flat-gradient all-reduce between them.  Replicas that started from different weights are equal
+    after set_distributed() and STAY bit-identical through eager and graph steps (parameters, BatchNorm running statistics
+    excepted: those are per-rank by design), the loss falls, the optimiser's step count follows the replays."""
+    port = 29900 + os.getpid() % 1000
+    mp.spawn(_graph_worker, args=(port, str(tmp_path)), nprocs=WORLD, join=True)
+    a, b = (torch.load(os.path.join(tmp_path, f'g{r}.pt')) for r in range(WORLD))
+    for k, v in a['params'].items():
+        if 'running_' in k or 'num_batches' in k:
+            continue
+        assert torch.equal(v, b['params'][k]), k
+    assert a['opt_step'] == b['opt_step'] == 1 + 1 + 6        # eager step + warm-up + replays
+    assert a['last'] < a['first'] and b['last'] < b['first']
+    assert not torch.equal(a['eps_probe'], b['eps_probe'])
+    assert 0 < a['rmse'] < 10
