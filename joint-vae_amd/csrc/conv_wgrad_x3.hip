@@ -82,7 +82,10 @@ __device__ __forceinline__ bf16x8 tr_pair(const unsigned char* base, int off) {
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-template <int S, int WS, int MODE, bool AFF>
+// SH16: the products run on v_mfma_f32_16x16x32_bf16 (K step = 32 pixels, a 32 x 32 tile = 2 x 2 blocks of 16 x 16) instead of
+// v_mfma_f32_32x32x16_bf16: the same LDS image, the same reads and MFMA cycles per FLOP; the chip holds a higher clock under
+// the 16x16x32 shape (MI355X_MICROARCH.md, DVFS give-back item 7).  JVAE_WGRAD_SH16=0 selects the 32x32x16 form (A/B).
+template <int S, int WS, int MODE, bool AFF, bool SH16>
 __global__ __launch_bounds__(256, 2) void conv5_wgrad_x3_kernel(WgX3P p) {
     using G = WgX3Geom<S, WS, MODE>;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -132,11 +135,43 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_x3_kernel(WgX3P p) {
         boff[t] = ((lane_pix + (tap / 5) * G::WPS + tslot) * G::NCBQ + cbl) * 16 + sub * 8;
     }
 
-    f32x16 acc[G::NBT];
+    // 16x16x32 roles: 16-lane group g16 = K group (8 pixels), the lanes of a group supply (pixel q4, channel quad pp) of a
+    // 16-channel block chosen per MFMA (rb for Ps, cb for the columns)
+    const int g16 = lane >> 4, c16 = lane & 15;
+    const int pl16 = 8 * g16 + q4;                             // pixel of this lane inside a 32-pixel K step
+    const int aoff16 = (pl16 * 4 + (pp >> 1)) * 16 + (pp & 1) * 8;        // + rb * 32 bytes
+    const int lane_pix16 = (pl16 / WS) * S * G::WPS + (pl16 % WS);
+    int boff16[SH16 ? G::NBT : 1][MODE == 0 ? 1 : 2];      // MODE 0: the second column block is 2 units (32 bytes) further
+    if (SH16) {
 #pragma unroll
-    for (int t = 0; t < G::NBT; ++t)
+        for (int t = 0; t < G::NBT; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+            for (int cb = 0; cb < (MODE == 0 ? 1 : 2); ++cb) {
+                const int tile = wave + 4 * t;
+                int tap, blk;
+                if (MODE == 0) { tap = tile; blk = cb * 2 + (pp >> 1); }
+                else if (MODE == 2) { tap = tile * 2 + cb; blk = pp >> 1; }
+                else { tap = tile * 4 + cb * 2 + (pp >> 1); blk = 0; }
+                if (tap > 24) tap = 24;
+                const int kw = tap % 5;
+                const int tslot = S == 1 ? kw : (kw & 1) * G::WPH + (kw >> 1);
+                boff16[t][cb] = ((lane_pix16 + (tap / 5) * G::WPS + tslot) * G::NCBQ + blk) * 16 + (pp & 1) * 8;
+            }
+    }
+
+    f32x16 acc[SH16 ? 1 : G::NBT];
+    f32x4 acc16[SH16 ? G::NBT : 1][2][2];
+    if (SH16) {
+#pragma unroll
+        for (int t = 0; t < G::NBT; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc16[t][i >> 1][i & 1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    } else {
+#pragma unroll
+        for (int t = 0; t < G::NBT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    }
 
     const int per = (p.N + p.G - 1) / p.G;
     const int n_beg = blockIdx.x * per, n_end = min(p.N, n_beg + per);
@@ -237,6 +272,51 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_x3_kernel(WgX3P p) {
         lstore(item);
         __syncthreads();
         if (item + 1 < item_end) gload(item + 1);
+        if constexpr (SH16) {
+            // slots = (K step of 32 pixels, tile, 16-column block): the fragments of the next slot are read before the 12
+            // MFMAs (2 row blocks x 6 products) of the current one are issued
+            constexpr int KS = G::TPIX / 32, NSLOT = G::NBT * 2;
+            bf16x8 a[2][3], b[2][3];
+            auto read_a = [&](int ks) {
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                    for (int plane = 0; plane < 3; ++plane)
+                        a[rb][plane] = tr_pair<256>(Pb + plane * G::PS * 16, aoff16 + rb * 32 + ks * 32 * 64);
+            };
+            auto read_b = [&](int ks, int slot, bf16x8 (&d)[3]) {
+                const int pix0 = ks * 32;
+                const int qoff = ((pix0 / WS) * S * G::WPS + (pix0 % WS)) * G::NCBQ * 16;
+#pragma unroll
+                for (int plane = 0; plane < 3; ++plane)
+                    d[plane] = tr_pair<64 * G::NCBQ>(Qb + plane * G::QS * 16,
+                                                     (MODE == 0 ? boff16[slot >> 1][0] + (slot & 1) * 32 : boff16[slot >> 1][slot & 1]) + qoff);
+            };
+            read_a(0);
+            read_b(0, 0, b[0]);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+                for (int slot = 0; slot < NSLOT; ++slot) {
+                    const int cur = (ks * NSLOT + slot) & 1;
+                    const int t = slot >> 1, cb = slot & 1;
+                    if (slot + 1 < NSLOT) read_b(ks, slot + 1, b[cur ^ 1]);
+                    else if (ks + 1 < KS) read_b(ks + 1, 0, b[cur ^ 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (wave + 4 * t < G::NTILE) {                                 // wave-uniform
+                        constexpr int APL[6] = {0, 2, 1, 0, 1, 0}, BPL[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+                        for (int m = 0; m < 6; ++m)
+#pragma unroll
+                            for (int rb = 0; rb < 2; ++rb)
+                                acc16[t][rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[rb][APL[m]], b[cur][BPL[m]],
+                                                                                           acc16[t][rb][cb], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (slot + 1 == NSLOT && ks + 1 < KS) read_a(ks + 1);           // the Ps fragments are free again
+                }
+            }
+        } else {
         // Software-pipelined over the (K step, tile) sequence: the fragments of the NEXT slot are read before the six
         // MFMAs of the current one are issued (hipcc would otherwise place every read right in front of its consumer and
         // wait for it with the matrix pipe idle).  Slots beyond a wave's tiles read a valid stand-in address.
@@ -272,10 +352,36 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_x3_kernel(WgX3P p) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        }
     }
 
     // slab[g][a][tap][b] (b contiguous over the lanes: coalesced); lane holds column l31, rows a = (r&3) + 8*(r>>2) + 4*half
     float* slab = p.slab + (long)blockIdx.x * p.Ca * (p.Cb * 25);
+    if constexpr (SH16) {
+        // 16x16 block (rb, cb): lane holds column c16 of the block, rows 4 * g16 + r
+#pragma unroll
+        for (int t = 0; t < G::NBT; ++t) {
+            const int tile = wave + 4 * t;
+            if (tile >= G::NTILE) continue;
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                const int j = cb * 16 + c16;
+                int b, tap;
+                if (MODE == 0) { b = cbq0 * 8 + j; tap = tile; }
+                else if (MODE == 2) { b = cbq0 * 8 + c16; tap = tile * 2 + cb; }
+                else { b = j & 7; tap = tile * 4 + (j >> 3); }
+                if (b >= p.Cb || tap > 24) continue;
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int a = a0 + rb * 16 + g16 * 4 + r;
+                        if (a < p.Ca) slab[((long)a * 25 + tap) * p.Cb + b] = acc16[t][rb][cb][r];
+                    }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int t = 0; t < G::NBT; ++t) {
         const int tile = wave + 4 * t;
@@ -299,20 +405,28 @@ int launch_wgx3(const WgX3P& p, hipStream_t st) {
     static_assert(G::LDS_BYTES + 2048 <= 80 * 1024, "two workgroups per CU must fit the 160 KB LDS");
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_wgrad_x3_kernel<S, WS, MODE, false>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_wgrad_x3_kernel<S, WS, MODE, true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
-        if (e != hipSuccess) return (int)e;
+        const void* fns[4] = {reinterpret_cast<const void*>(&conv5_wgrad_x3_kernel<S, WS, MODE, false, false>),
+                              reinterpret_cast<const void*>(&conv5_wgrad_x3_kernel<S, WS, MODE, true, false>),
+                              reinterpret_cast<const void*>(&conv5_wgrad_x3_kernel<S, WS, MODE, false, true>),
+                              reinterpret_cast<const void*>(&conv5_wgrad_x3_kernel<S, WS, MODE, true, true>)};
+        for (const void* f : fns) {
+            hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+            if (e != hipSuccess) return (int)e;
+        }
         attr_set = true;
     }
     dim3 grid(p.G, (p.Ca + 31) / 32, (p.Cb + 8 * G::NCBQ - 1) / (8 * G::NCBQ));
     if (MODE == 1) grid.z = 1;
-    if (p.aff_p.sc || p.aff_q.sc)
-        hipLaunchKernelGGL((conv5_wgrad_x3_kernel<S, WS, MODE, true>), grid, dim3(256), G::LDS_BYTES, st, p);
-    else
-        hipLaunchKernelGGL((conv5_wgrad_x3_kernel<S, WS, MODE, false>), grid, dim3(256), G::LDS_BYTES, st, p);
+    static int sh16 = -1;
+    if (sh16 < 0) { const char* e = getenv("JVAE_WGRAD_SH16"); sh16 = (e && e[0] == '0') ? 0 : 1; }
+    const bool aff = p.aff_p.sc || p.aff_q.sc;
+    if (sh16) {
+        if (aff) hipLaunchKernelGGL((conv5_wgrad_x3_kernel<S, WS, MODE, true, true>), grid, dim3(256), G::LDS_BYTES, st, p);
+        else hipLaunchKernelGGL((conv5_wgrad_x3_kernel<S, WS, MODE, false, true>), grid, dim3(256), G::LDS_BYTES, st, p);
+    } else {
+        if (aff) hipLaunchKernelGGL((conv5_wgrad_x3_kernel<S, WS, MODE, true, false>), grid, dim3(256), G::LDS_BYTES, st, p);
+        else hipLaunchKernelGGL((conv5_wgrad_x3_kernel<S, WS, MODE, false, false>), grid, dim3(256), G::LDS_BYTES, st, p);
+    }
     JVAE_LAUNCH_CHECK();
     return 0;
 }

@@ -9,8 +9,10 @@
 //
 // Serves: Linear layers fwd/dgrad/wgrad (reference: nn.Linear in layers.py:283-296, cvae.py:291-326),
 // the 1x1 -> kxk first transposed conv of the upsampler, and the generic (im2col) convolution path.
+#include <stdlib.h>
 #include "common.h"
 #include "jvae_internal.h"
+#include "conv_dispatch.h"
 
 namespace {
 
@@ -202,6 +204,197 @@ int launch_tile(const GemmP& p, int batch, hipStream_t st) {
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// ---- the same product on the bf16 matrix cores: every fp32 operand split exactly into three bf16 terms, six
+// v_mfma_f32_32x32x16_bf16 per fp32 product tile (the arithmetic of conv_x3.hip: dropped terms < 2^-24 of a product).
+// 64 x 64 block tile, K step 64, 4 waves as 2 x 2 (wave tile 32 x 32).  LDS images are bf16 planes:
+//   operand contiguous along k in memory   -> [row][k]  (pitch 144 B): a fragment = one ds_read_b128, conflict-free
+//   operand contiguous along m / n         -> [k][row]  (pitch 192 B): the fragment is read TRANSPOSED with two
+//                                             ds_read_b64_tr_b16 (4 k x 16 rows per 16 lanes, returned k-major per lane)
+// so that both memory layouts are staged with 16-byte global loads and 8-byte LDS stores, no shuffles.
+typedef __bf16 gx_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 gx_bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int gx_u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int gx_u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) gx_bf16x4 gx_lds_bf16x4;
+constexpr int BKX = 32;              // K step: 32 keeps the images at 32 KB -> four workgroups per CU (the products here are
+                                     // latency-bound: few tiles, short K slices)
+
+__device__ __forceinline__ void gx_split4(const f32x4& v, gx_u32x2 (&out)[3]) {
+    gx_bf16x4 h, m, l;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const __bf16 a = (__bf16)v[j];
+        float r = v[j] - (float)a;
+        const __bf16 b = (__bf16)r;
+        r -= (float)b;
+        h[j] = a; m[j] = b; l[j] = (__bf16)r;
+    }
+    out[0] = __builtin_bit_cast(gx_u32x2, h);
+    out[1] = __builtin_bit_cast(gx_u32x2, m);
+    out[2] = __builtin_bit_cast(gx_u32x2, l);
+}
+
+template <bool KC>           // KC: the operand is k-contiguous ([row][k] image), else [k][row]
+struct GxImg {
+    static constexpr int PITCH = KC ? (BKX * 2 + 16) : (64 * 2 + 64);
+    static constexpr int ROWS = KC ? 64 : BKX;            // 64 rows of the tile, or the k of one step
+    static constexpr int BYTES = PITCH * ROWS;            // one plane
+};
+
+template <bool AK, bool BNC>
+__global__ __launch_bounds__(256, 4) void gemm_x3_kernel(GemmP p) {
+    using IA = GxImg<AK>;
+    using IB = GxImg<!BNC>;
+    constexpr int BM = 64, BN = 64, G4 = BM * BKX / 4 / 256;   // float4 groups per thread and operand
+    constexpr int KQX = BKX / 4;                               // float4 groups along k
+    extern __shared__ __attribute__((aligned(16))) unsigned char gx_lds[];
+    unsigned char* As = gx_lds;                                 // [3 planes][IA::BYTES]
+    unsigned char* Bs = gx_lds + 3 * IA::BYTES;                 // [3 planes][IB::BYTES]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int cg = (lane >> 4) & 1, q4 = (lane & 15) >> 2, pp = lane & 3;      // transposed-read roles
+    const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int batch = blockIdx.z / p.splitk, split = blockIdx.z % p.splitk;
+    const int kbeg = split * p.kchunk;
+    const int kend = min(p.K, kbeg + p.kchunk);
+    const float* A = p.A + (long)batch * p.sAb;
+    const float* B = p.B + (long)batch * p.sBb;
+    float* C = p.C + (long)batch * p.sCb + ((p.flags & 8) ? (long)split * p.sCsplit : 0L);
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    f32x4 ra[G4], rb[G4];
+
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int g = 0; g < G4; ++g) {
+            if (AK) {
+                const int kq = tid % KQX, row = tid / KQX + g * (256 / KQX);
+                const int m = m0 + row, k = k0 + kq * 4;
+                const float* src = A + (long)m * p.sAm + (long)k * p.sAk;
+                ra[g] = p.vecA ? load4<true>(src, p.sAk, k, kend, m < p.M) : load4<false>(src, p.sAk, k, kend, m < p.M);
+            } else {
+                const int mq = tid % 16, kr = tid / 16 + g * 16;
+                const int m = m0 + mq * 4, k = k0 + kr;
+                const float* src = A + (long)m * p.sAm + (long)k * p.sAk;
+                ra[g] = p.vecA ? load4<true>(src, p.sAm, m, p.M, k < kend) : load4<false>(src, p.sAm, m, p.M, k < kend);
+            }
+            if (BNC) {
+                const int nq = tid % 16, kr = tid / 16 + g * 16;
+                const int n = n0 + nq * 4, k = k0 + kr;
+                const float* src = B + (long)k * p.sBk + (long)n * p.sBn;
+                rb[g] = p.vecB ? load4<true>(src, p.sBn, n, p.N, k < kend) : load4<false>(src, p.sBn, n, p.N, k < kend);
+            } else {
+                const int kq = tid % KQX, col = tid / KQX + g * (256 / KQX);
+                const int n = n0 + col, k = k0 + kq * 4;
+                const float* src = B + (long)k * p.sBk + (long)n * p.sBn;
+                rb[g] = p.vecB ? load4<true>(src, p.sBk, k, kend, n < p.N) : load4<false>(src, p.sBk, k, kend, n < p.N);
+            }
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int g = 0; g < G4; ++g) {
+            // the contiguous direction runs fastest over the threads, as in gload
+            const int fa = AK ? tid % KQX : tid % 16, sa_ = AK ? tid / KQX + g * (256 / KQX) : tid / 16 + g * 16;
+            const int fb = BNC ? tid % 16 : tid % KQX, sb_ = BNC ? tid / 16 + g * 16 : tid / KQX + g * (256 / KQX);
+            gx_u32x2 sa[3], sb[3];
+            gx_split4(ra[g], sa);
+            gx_split4(rb[g], sb);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                *reinterpret_cast<gx_u32x2*>(As + pl * IA::BYTES + sa_ * IA::PITCH + fa * 8) = sa[pl];
+                *reinterpret_cast<gx_u32x2*>(Bs + pl * IB::BYTES + sb_ * IB::PITCH + fb * 8) = sb[pl];
+            }
+        }
+    };
+    // fragment of K step ks (16 k) for the wave's 32 rows starting at r0
+    auto frag = [&](const unsigned char* img, bool kc, int pitch, int r0, int ks) -> gx_bf16x8 {
+        if (kc)
+            return __builtin_bit_cast(gx_bf16x8, *reinterpret_cast<const gx_u32x4*>(img + (r0 + l31) * pitch + (ks * 16 + half * 8) * 2));
+        const unsigned char* q = img + (ks * 16 + half * 8 + q4) * pitch + (r0 + cg * 16 + pp * 4) * 2;
+        const gx_bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((gx_lds_bf16x4*)q);
+        const gx_bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((gx_lds_bf16x4*)(q + 4 * pitch));
+        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+
+    if (kbeg < kend) gload(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += BKX) {
+        __syncthreads();                 // previous tile's fragment reads are done
+        lstore();
+        __syncthreads();
+        if (k0 + BKX < kend) gload(k0 + BKX);   // in flight under the MFMAs below
+#pragma unroll
+        for (int ks = 0; ks < BKX / 16; ++ks) {
+            gx_bf16x8 a[3], b[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                a[pl] = frag(As + pl * IA::BYTES, AK, IA::PITCH, wm0, ks);
+                b[pl] = frag(Bs + pl * IB::BYTES, !BNC, IB::PITCH, wn0, ks);
+            }
+            constexpr int APL[6] = {0, 2, 1, 0, 1, 0}, BPL[6] = {2, 0, 1, 1, 0, 0};      // small products first
+#pragma unroll
+            for (int t = 0; t < 6; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[APL[t]], b[BPL[t]], acc, 0, 0, 0);
+        }
+    }
+
+    // epilogue (as gemm_kernel): D[i][j]: j = lane&31, i = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const bool lead = (split == 0) && !(p.flags & 8);
+    const int n = n0 + wn0 + l31;
+    if (n >= p.N) return;
+    const float bn = (p.bias_mode == 1 && lead) ? p.bias[n / p.bias_div] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (m >= p.M) continue;
+        float v = acc[r] + bn;
+        if (p.bias_mode == 2 && lead) v += p.bias[m];
+        float* dst = C + (long)m * p.sCm + (long)n * p.sCn;
+        if (p.flags & 8) {
+            *dst = v;
+        } else if (p.flags & 4) {
+            atomicAdd(dst, v);
+        } else {
+            if (p.flags & 1) v += *dst;
+            if (p.flags & 2) v = fmaxf(v, 0.f);
+            *dst = v;
+        }
+    }
+}
+
+template <bool AK, bool BNC>
+int launch_x3_variant(const GemmP& p, int batch, hipStream_t st) {
+    constexpr int LDS = 3 * (GxImg<AK>::BYTES + GxImg<!BNC>::BYTES);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x3_kernel<AK, BNC>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    dim3 grid(cdiv(p.N, 64), cdiv(p.M, 64), batch * p.splitk), block(256);
+    hipLaunchKernelGGL((gemm_x3_kernel<AK, BNC>), grid, block, LDS, st, p);
+    JVAE_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_x3(const GemmP& p, int batch, hipStream_t st) {
+    const bool ak = (p.sAk == 1), bnc = (p.sBn == 1);
+    if (ak && bnc) return launch_x3_variant<true, true>(p, batch, st);
+    if (ak) return launch_x3_variant<true, false>(p, batch, st);
+    if (bnc) return launch_x3_variant<false, true>(p, batch, st);
+    return launch_x3_variant<false, false>(p, batch, st);
+}
+
+static int g_gemm_x3 = -1;       // JVAE_GEMM_X3=0: dense products stay on the fp32 matrix-core kernel (A/B switch)
+inline bool gemm_x3_on(int K) {
+    if (g_gemm_x3 < 0) { const char* e = getenv("JVAE_GEMM_X3"); g_gemm_x3 = (e && e[0] == '0') ? 0 : 1; }
+    return g_gemm_x3 && K >= 64 && jvae_conv5_x3_enabled();
+}
+
 }  // namespace
 
 int jvae_gemm_launch(int M, int N, int K, int batch,
@@ -244,6 +437,7 @@ int jvae_gemm_launch_ex(int M, int N, int K, int batch,
     const bool ak = (sAk == 1), bnc = (sBn == 1);
     p.vecA = aligned16(A) && (sAb % 4 == 0) && (ak ? (sAm % 4 == 0) : (sAm == 1 && sAk % 4 == 0));
     p.vecB = aligned16(B) && (sBb % 4 == 0) && (bnc ? (sBk % 4 == 0) : (sBk == 1 && sBn % 4 == 0));
+    if (gemm_x3_on(K)) return launch_x3(p, batch, st);
     const long tiles128 = (long)cdiv(M, 128) * cdiv(N, 128) * batch * splitk;
     if (M > 64 && N > 64 && tiles128 >= 512) return launch_tile<128, 128>(p, batch, st);
     return launch_tile<64, 64>(p, batch, st);
@@ -277,6 +471,7 @@ int jvae_gemm_launch_part(int M, int N, int K, int batch,
     p.vecA = aligned16(A) && (sAb % 4 == 0) && (ak ? (sAm % 4 == 0) : (sAm == 1 && sAk % 4 == 0));
     p.vecB = aligned16(B) && (sBb % 4 == 0) && (bnc ? (sBk % 4 == 0) : (sBk == 1 && sBn % 4 == 0));
     *splits = splitk;
+    if (gemm_x3_on(K)) return launch_x3(p, batch, st);
     return launch_tile<64, 64>(p, batch, st);
 }
 
