@@ -44,6 +44,74 @@ __device__ __forceinline__ float half_wave_sum_hi(float v) {
     return v;
 }
 
+// Transposing reduction over the 32 lanes of each half-wave: every lane brings 32 values v[0..31]; afterwards lane l
+// holds the sum, over the 32 lanes of its half-wave, of v[l & 31].  A value-halving butterfly - at every step a lane
+// keeps half of its values and hands the other half to its partner - needs 16 + 8 + 4 + 2 + 1 additions (65 vector
+// instructions) where 32 independent all-lane reductions need 160, and leaves ONE value per lane (one LDS store instead
+// of 32 single-lane ones).  Step 1 crosses the rows of 16 lanes with gfx950's v_permlane16_swap, steps 2 / 3 use DPP adds
+// whose bank mask restricts the write to the lanes that keep the value, steps 4 / 5 (inside a quad, where no write mask
+// exists) select with v_cndmask.  All lanes must be active.  Fixed order: results are run-to-run identical.
+__device__ __forceinline__ float half_wave_reduce32(const float (&v)[32]) {
+    const int lane = threadIdx.x & 63;
+    float a[16], b[8], c[4], d[2];
+    // s_nop 1: a vector write needs two wait states before a DPP / permlane-swap read of the same register (inline asm is
+    // not covered by the compiler's hazard recogniser).  The swap is written as asm because this compiler's
+    // __builtin_amdgcn_permlane16_swap returns its first result twice.
+#pragma unroll
+    for (int i = 0; i < 16; i += 4) {   // lane bit 4: even rows keep v[i], odd rows v[i + 16]
+        float x[4], y[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { x[j] = v[i + j]; y[j] = v[i + j + 16]; }
+        // odd rows of x <-> even rows of y: afterwards x + y = (x.row0 + x.row1 | y.row0 + y.row1 | x.row2 + x.row3 | ...)
+        asm("s_nop 1\n\t"
+            "v_permlane16_swap_b32 %0, %4\n\t"
+            "v_permlane16_swap_b32 %1, %5\n\t"
+            "v_permlane16_swap_b32 %2, %6\n\t"
+            "v_permlane16_swap_b32 %3, %7"
+            : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a[i + j] = x[j] + y[j];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i += 4) {    // lane bit 3 (partner lane ^ 8 = row_ror:8): banks 0,1 keep a[i], banks 2,3 a[i + 8]
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[i + j] = a[i + j];
+        asm("s_nop 1\n\t"
+            "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+            "v_add_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+            "v_add_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+            "v_add_f32_dpp %3, %3, %3 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+            "v_add_f32_dpp %0, %4, %4 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+            "v_add_f32_dpp %1, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+            "v_add_f32_dpp %2, %6, %6 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+            "v_add_f32_dpp %3, %7, %7 row_ror:8 row_mask:0xf bank_mask:0xc"
+            : "+v"(b[i]), "+v"(b[i + 1]), "+v"(b[i + 2]), "+v"(b[i + 3])
+            : "v"(a[i + 8]), "v"(a[i + 9]), "v"(a[i + 10]), "v"(a[i + 11]));
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c[j] = b[j];
+    // lane bit 2 (partner = row_half_mirror, lane 7 - l of each 8): banks 0,2 keep b[i], banks 1,3 b[i + 4]
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %3, %3, %3 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %0, %4, %4 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %1, %5, %5 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %2, %6, %6 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %3, %7, %7 row_half_mirror row_mask:0xf bank_mask:0xa"
+        : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3])
+        : "v"(b[4]), "v"(b[5]), "v"(b[6]), "v"(b[7]));
+    const bool b1 = lane & 2, b0 = lane & 1;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {       // lane bit 1 (partner lane ^ 2)
+        const float keep = b1 ? c[i + 2] : c[i], send = b1 ? c[i] : c[i + 2];
+        d[i] = keep + jvae_dpp<0x4E, 0xf>(send);
+    }
+    const float keep = b0 ? d[1] : d[0], send = b0 ? d[0] : d[1];
+    return keep + jvae_dpp<0xB1, 0xf>(send);      // lane bit 0 (partner lane ^ 1)
+}
+
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

@@ -187,20 +187,21 @@ __global__ __launch_bounds__(256, 2) void conv5_fwd_kernel(FwdP p) {
         __syncthreads();                                      // LDS is free now
         float* red = lds;                                     // [4 waves][NT*32][2]
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+        for (int nt = 0; nt < NT; ++nt) {
+            float sv[32];                                     // [sum | sum of squares][register row]
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float s1 = 0.f, s2 = 0.f;
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) { const float v = acc[nt][mt][r]; s1 += v; s2 += v * v; }
-                s1 = half_wave_sum_hi(s1);
-                s2 = half_wave_sum_hi(s2);
-                if (l31 == JVAE_HALF_SUM_LANE) {
-                    const int ch = nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    red[(wave * G::WCOLS + ch) * 2 + 0] = s1;
-                    red[(wave * G::WCOLS + ch) * 2 + 1] = s2;
-                }
+                sv[r] = s1;
+                sv[16 + r] = s2;
             }
+            // lane l31 receives the half-wave total of sv[l31]
+            const float tot = half_wave_reduce32(sv);
+            const int r = l31 & 15, ch = nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            red[(wave * G::WCOLS + ch) * 2 + (l31 >> 4)] = tot;
+        }
         __syncthreads();
         if (tid < G::WCOLS && o0 + tid < p.CoutReal) {
             float s1 = 0.f, s2 = 0.f;

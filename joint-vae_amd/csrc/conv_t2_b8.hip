@@ -157,6 +157,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void convt2_b8_kernel(T2B
     if (p.stats) {
         __syncthreads();
         float* red = reinterpret_cast<float*>(lds_raw);         // [NW waves][32][2]
+        float sv[32];                                           // [sum | sum of squares][register row]
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             float s1 = 0.f, s2 = 0.f;
@@ -164,13 +165,13 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void convt2_b8_kernel(T2B
             for (int r = 0; r < 2; ++r)
 #pragma unroll
                 for (int q = 0; q < 2; ++q) { const float v = acc[r][q][e]; s1 += v; s2 += v * v; }
-            s1 = half_wave_sum_hi(s1);
-            s2 = half_wave_sum_hi(s2);
-            if (l31 == JVAE_HALF_SUM_LANE) {
-                const int ch = (e & 3) + 8 * (e >> 2) + 4 * half;
-                red[(wave * 32 + ch) * 2 + 0] = s1;
-                red[(wave * 32 + ch) * 2 + 1] = s2;
-            }
+            sv[e] = s1;
+            sv[16 + e] = s2;
+        }
+        {   // lane l31 receives the half-wave total of sv[l31]
+            const float tot = half_wave_reduce32(sv);
+            const int e = l31 & 15, ch = (e & 3) + 8 * (e >> 2) + 4 * half;
+            red[(wave * 32 + ch) * 2 + (l31 >> 4)] = tot;
         }
         __syncthreads();
         if (tid < 32 && o0 + tid < p.O) {

@@ -173,7 +173,8 @@ __global__ __launch_bounds__(256, NT == 1 ? 4 : 2) void convt2_kernel(T2P p) {
         __syncthreads();
         float* red = lds;                                     // [4 waves][NT*32][2]
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+        for (int t = 0; t < NT; ++t) {
+            float sv[32];                                     // [sum | sum of squares][register row]
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 float s1 = 0.f, s2 = 0.f;
@@ -181,14 +182,14 @@ __global__ __launch_bounds__(256, NT == 1 ? 4 : 2) void convt2_kernel(T2P p) {
                 for (int r = 0; r < 2; ++r)
 #pragma unroll
                     for (int q = 0; q < 2; ++q) { const float v = acc[r][q][t][e]; s1 += v; s2 += v * v; }
-                s1 = half_wave_sum_hi(s1);
-                s2 = half_wave_sum_hi(s2);
-                if (l31 == JVAE_HALF_SUM_LANE) {
-                    const int ch = t * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
-                    red[(wave * G::WCOLS + ch) * 2 + 0] = s1;
-                    red[(wave * G::WCOLS + ch) * 2 + 1] = s2;
-                }
+                sv[e] = s1;
+                sv[16 + e] = s2;
             }
+            // lane l31 receives the half-wave total of sv[l31]
+            const float tot = half_wave_reduce32(sv);
+            const int e = l31 & 15, ch = t * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+            red[(wave * G::WCOLS + ch) * 2 + (l31 >> 4)] = tot;
+        }
         __syncthreads();
         if (tid < G::WCOLS) {
             float s1 = 0.f, s2 = 0.f;

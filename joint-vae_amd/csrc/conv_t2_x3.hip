@@ -226,6 +226,7 @@ __global__ __launch_bounds__(256, 2) void convt2_x3_kernel(T2X3P p) {
 
     if (p.stats) {
         float* red = reinterpret_cast<float*>(lds_raw);       // [4 waves][32][2]; the loop ended with a barrier
+        float sv[32];                                         // [sum | sum of squares][register row]
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             float s1 = 0.f, s2 = 0.f;
@@ -233,13 +234,13 @@ __global__ __launch_bounds__(256, 2) void convt2_x3_kernel(T2X3P p) {
             for (int r = 0; r < 2; ++r)
 #pragma unroll
                 for (int q = 0; q < 2; ++q) { const float v = acc[r][q][e]; s1 += v; s2 += v * v; }
-            s1 = half_wave_sum_hi(s1);
-            s2 = half_wave_sum_hi(s2);
-            if (l31 == JVAE_HALF_SUM_LANE) {
-                const int ch = (e & 3) + 8 * (e >> 2) + 4 * half;
-                red[(wave * 32 + ch) * 2 + 0] = s1;
-                red[(wave * 32 + ch) * 2 + 1] = s2;
-            }
+            sv[e] = s1;
+            sv[16 + e] = s2;
+        }
+        {   // lane l31 receives the half-wave total of sv[l31]
+            const float tot = half_wave_reduce32(sv);
+            const int e = l31 & 15, ch = (e & 3) + 8 * (e >> 2) + 4 * half;
+            red[(wave * 32 + ch) * 2 + (l31 >> 4)] = tot;
         }
         __syncthreads();
         if (tid < 32) {

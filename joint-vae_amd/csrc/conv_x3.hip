@@ -291,18 +291,19 @@ __global__ __launch_bounds__(256, 2) void conv5_x3_kernel(X3P p) {
     // ---- optional BatchNorm statistics of this workgroup's tile (the loop ended with a barrier: LDS is free)
     if (p.stats) {
         float* red = reinterpret_cast<float*>(lds_raw);       // [4 waves][32][2]
+        float sv[32];                                         // [sum | sum of squares][register row]
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) { const float v = acc[mt][r]; s1 += v; s2 += v * v; }
-            s1 = half_wave_sum_hi(s1);
-            s2 = half_wave_sum_hi(s2);
-            if (l31 == JVAE_HALF_SUM_LANE) {
-                const int ch = (r & 3) + 8 * (r >> 2) + 4 * half;
-                red[(wave * 32 + ch) * 2 + 0] = s1;
-                red[(wave * 32 + ch) * 2 + 1] = s2;
-            }
+            sv[r] = s1;
+            sv[16 + r] = s2;
+        }
+        {   // lane l31 receives the half-wave total of sv[l31]
+            const float tot = half_wave_reduce32(sv);
+            const int r = l31 & 15, ch = (r & 3) + 8 * (r >> 2) + 4 * half;
+            red[(wave * 32 + ch) * 2 + (l31 >> 4)] = tot;
         }
         __syncthreads();
         if (tid < 32 && o0 + tid < p.CoutReal) {
