@@ -40,6 +40,36 @@ __global__ __launch_bounds__(256) void unfold_kernel(const float* __restrict__ x
     }
 }
 
+// The same unfold with 32-bit index arithmetic and 16-byte stores (the generic kernel above spends its time in 64-bit
+// divisions: 0.7 TB/s on a 105 MB buffer).  Four consecutive elements of the fastest output dimension per thread:
+// KFAST: col[q][n][k], 4 consecutive k (Kd % 4 == 0); else col[n][k][q], 4 consecutive q of one output row (Ws % 4 == 0).
+template <bool KFAST>
+__global__ __launch_bounds__(256) void unfold4_kernel(const float* __restrict__ xb, float* __restrict__ col,
+                                                      ConvGeom g, int n0, int nimg) {
+    const unsigned Kd = g.Cb * g.KH * g.KW, Ps = g.Hs * g.Ws, KK = g.KH * g.KW;
+    const unsigned inner4 = (KFAST ? Kd : Ps) / 4;
+    const unsigned total = (KFAST ? Ps * (unsigned)nimg : (unsigned)nimg * Kd) * inner4;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const unsigned row = i / inner4, e4 = (i - row * inner4) * 4;
+        unsigned n, k, q;
+        if (KFAST) { q = row / nimg; n = row - q * nimg; k = e4; }
+        else       { n = row / Kd;   k = row - n * Kd;   q = e4; }
+        unsigned cb = k / KK, t = k - cb * KK;
+        unsigned kh = t / g.KW, kw = t - kh * g.KW;
+        const unsigned hs = q / g.Ws, ws = q - hs * g.Ws;
+        const float* src = xb + (long)(n0 + n) * g.Cb * g.Hb * g.Wb;
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int hb = (int)(hs * g.S + kh) - g.P;
+            const int wb = (int)((KFAST ? ws : ws + e) * g.S + kw) - g.P;
+            v[e] = (hb >= 0 && hb < g.Hb && wb >= 0 && wb < g.Wb) ? src[((long)cb * g.Hb + hb) * g.Wb + wb] : 0.f;
+            if (KFAST && ++kw == (unsigned)g.KW) { kw = 0; if (++kh == (unsigned)g.KH) { kh = 0; ++cb; } }
+        }
+        *reinterpret_cast<f32x4*>(col + (long)i * 4) = v;        // both layouts are dense in (row, inner) order
+    }
+}
+
 // Xb[n][cb][hb][wb] (=|+=) bias[cb] + sum over taps of col(n,(cb,kh,kw),(hs,ws)) with hs*S+kh-P == hb.
 __global__ __launch_bounds__(256) void fold_kernel(const float* __restrict__ col, float* __restrict__ xb,
                                                    const float* __restrict__ bias, ConvGeom g, int n0, int nimg,
@@ -127,6 +157,27 @@ inline int grid_for(long total) {
     return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b));
 }
 
+inline int grid_for4(long total4) {
+    long b = (total4 + 255) / 256;
+    return (int)(b > 16384 ? 16384 : (b < 1 ? 1 : b));
+}
+
+// dense col buffer of `nimg` images in layout [q][n][k] (kfast) or [n][k][q]
+int launch_unfold(const float* xb, float* col, const ConvGeom& g, int n0, int nimg, bool kfast, hipStream_t st) {
+    const long Kd = (long)g.Cb * g.KH * g.KW, Ps = (long)g.Hs * g.Ws, total = (long)nimg * Kd * Ps;
+    const bool vec = total < (1L << 31) && (kfast ? Kd % 4 == 0 : g.Ws % 4 == 0) && ((uintptr_t)col & 15) == 0;
+    if (vec && kfast)
+        hipLaunchKernelGGL(unfold4_kernel<true>, dim3(grid_for4(total / 4)), dim3(256), 0, st, xb, col, g, n0, nimg);
+    else if (vec)
+        hipLaunchKernelGGL(unfold4_kernel<false>, dim3(grid_for4(total / 4)), dim3(256), 0, st, xb, col, g, n0, nimg);
+    else if (kfast)
+        hipLaunchKernelGGL(unfold_kernel, dim3(grid_for(total)), dim3(256), 0, st, xb, col, g, n0, nimg, Kd, 1L, (long)nimg * Kd, 1);
+    else
+        hipLaunchKernelGGL(unfold_kernel, dim3(grid_for(total)), dim3(256), 0, st, xb, col, g, n0, nimg, Kd * Ps, Ps, 1L, 0);
+    JVAE_LAUNCH_CHECK();
+    return 0;
+}
+
 // Small folded grids (E4 of conv32: 2x2) make per-image products degenerate: batch over positions instead.
 // (also the 6x6 / 5x5 grids of conv32+ / deconv32+: 36 / 25 positions)
 inline bool pixel_batched(const ConvGeom& g) { return g.Hs * g.Ws <= 48; }
@@ -195,9 +246,7 @@ int jvae_fold_fwd(const ConvGeom& g, const float* xb, const float* w, const floa
     if (pixel_batched(g)) {
         if (ws_bytes < (size_t)col_floats_per_image(g) * 4 * g.N) return JVAE_EWORKSPACE;
         // col[q][n][k];  Y_q[n][cs] = col_q[n][:] . W[cs][:]
-        hipLaunchKernelGGL(unfold_kernel, dim3(grid_for((long)g.N * Kd * Ps)), dim3(256), 0, st, xb, ws, g, 0, g.N,
-                           (long)Kd, 1L, (long)g.N * Kd, 1);
-        JVAE_LAUNCH_CHECK();
+        { const int rc = launch_unfold(xb, ws, g, 0, g.N, true, st); if (rc) return rc; }
         const int want = fwd_slices(g);
         if (want > 1) {
             // long K, few tiles: K pieces stored side by side (copies of the output layout), folded in a fixed order
@@ -217,9 +266,7 @@ int jvae_fold_fwd(const ConvGeom& g, const float* xb, const float* w, const floa
     if (chunk < 1) return JVAE_EWORKSPACE;
     for (int n0 = 0; n0 < g.N; n0 += chunk) {
         const int ni = (g.N - n0 < chunk) ? g.N - n0 : chunk;
-        hipLaunchKernelGGL(unfold_kernel, dim3(grid_for((long)ni * Kd * Ps)), dim3(256), 0, st, xb, ws, g, n0, ni,
-                           (long)Kd * Ps, (long)Ps, 1L, 0);
-        JVAE_LAUNCH_CHECK();
+        { const int rc = launch_unfold(xb, ws, g, n0, ni, false, st); if (rc) return rc; }
         int rc = jvae_gemm_launch(g.Cs, Ps, Kd, ni, w, Kd, 1, 0, ws, Ps, 1, (long)Kd * Ps,
                                   ys + (long)n0 * g.Cs * Ps, Ps, 1, (long)g.Cs * Ps, bias, bias ? 2 : 0, 0, 1, st);
         if (rc) return rc;
@@ -263,9 +310,7 @@ int jvae_fold_wgrad(const ConvGeom& g, const float* xb, const float* ys, float* 
     const int Kd = g.Cb * g.KH * g.KW, Ps = g.Hs * g.Ws;
     if (pixel_batched(g)) {
         if (ws_bytes < (size_t)col_floats_per_image(g) * 4 * g.N) return JVAE_EWORKSPACE;
-        hipLaunchKernelGGL(unfold_kernel, dim3(grid_for((long)g.N * Kd * Ps)), dim3(256), 0, st, xb, ws, g, 0, g.N,
-                           (long)Kd, 1L, (long)g.N * Kd, 1);
-        JVAE_LAUNCH_CHECK();
+        { const int rc = launch_unfold(xb, ws, g, 0, g.N, true, st); if (rc) return rc; }
         if (wgrad_joint(g)) {
             // dW[cs][k] += sum_{(q,n)} Yt[(q,n)][cs] col[(q,n)][k]: one product, K = Ps*N sliced over the batch
             // dimension into S partial results, folded in a fixed order
@@ -295,9 +340,7 @@ int jvae_fold_wgrad(const ConvGeom& g, const float* xb, const float* ys, float* 
     if (chunk < 1) return JVAE_EWORKSPACE;
     for (int n0 = 0; n0 < g.N; n0 += chunk) {
         const int ni = (g.N - n0 < chunk) ? g.N - n0 : chunk;
-        hipLaunchKernelGGL(unfold_kernel, dim3(grid_for((long)ni * Kd * Ps)), dim3(256), 0, st, xb, ws, g, n0, ni,
-                           (long)Kd * Ps, (long)Ps, 1L, 0);
-        JVAE_LAUNCH_CHECK();
+        { const int rc = launch_unfold(xb, ws, g, n0, ni, false, st); if (rc) return rc; }
         int rc = jvae_gemm_launch(g.Cs, Kd, Ps, ni, ys + (long)n0 * g.Cs * Ps, Ps, 1, (long)g.Cs * Ps,
                                   ws, 1, Ps, (long)Kd * Ps, dw, Kd, 1, 0, nullptr, 0, 4, 1, st);
         if (rc) return rc;

@@ -13,6 +13,7 @@ from . import lib as L
 RELU, SIGMOID, IDENT = 1, 2, 0
 OVERLAP_WGRAD = True          # weight-gradient kernels on a second HIP stream (see _Conv.backward)
 LAST_WGRAD_ON_MAIN = __import__('os').environ.get('JVAE_LAST_WGRAD_MAIN', '1') != '0'     # A/B switch, see _Conv.backward
+WGRAD_FORK_BEFORE_DGRAD = __import__('os').environ.get('JVAE_WGRAD_FORK_EARLY', '1') != '0'   # A/B switch, see _Conv.backward
 ACT_KIND = {'relu': RELU, 'sigmoid': SIGMOID, 'linear': IDENT, None: IDENT}
 
 
@@ -308,20 +309,33 @@ class _Conv(torch.autograd.Function):
         x, w = ctx.saved_tensors
         gy = _c(gy)
         gx = gw = gb = None
-        if ctx.needs_input_grad[0]:
-            gx = conv_dgrad_raw(gy, w, ctx.spec, x.shape)
         want_b = ctx.has_bias and ctx.needs_input_grad[2] and not ctx.dead_bias
+        w_slot = b_slot = None
+        on_side = False
         if ctx.needs_input_grad[1] or want_b:
             w_slot = _grad_slot(ctx.w_ref)
             b_slot = _grad_slot(ctx.b_ref) if want_b else None
             # the first layer of the model (its input needs no gradient) is the END of the backward chain: its weight
             # gradient stays on the main stream, where it runs beside the side stream's last kernels instead of behind them
-            if OVERLAP_WGRAD and (ctx.needs_input_grad[0] or not LAST_WGRAD_ON_MAIN) and w_slot is not None and (b_slot is not None or not want_b):
+            on_side = (OVERLAP_WGRAD and (ctx.needs_input_grad[0] or not LAST_WGRAD_ON_MAIN) and w_slot is not None
+                       and (b_slot is not None or not want_b))
+        if on_side and WGRAD_FORK_BEFORE_DGRAD:
+            # the weight gradient needs gy and x, not this layer's dgrad: the side stream forks off BEFORE the dgrad is
+            # queued.  In a captured graph the dgrad is then the first successor of gy's producer and stays on the
+            # launch queue (the runtime moves later successors to other queues: a 10 us hand-over per hop of the chain)
+            main = torch.cuda.current_stream(x.device)
+            side = L.side_stream(x.device)
+            side.wait_stream(main)
+        if ctx.needs_input_grad[0]:
+            gx = conv_dgrad_raw(gy, w, ctx.spec, x.shape)
+        if ctx.needs_input_grad[1] or want_b:
+            if on_side:
                 # in-place into the flat gradient buffer: nothing downstream of this node consumes the result before
                 # the optimiser, so the kernel goes to the side stream and overlaps the rest of backward
-                main = torch.cuda.current_stream(x.device)
-                side = L.side_stream(x.device)
-                side.wait_stream(main)
+                if not WGRAD_FORK_BEFORE_DGRAD:
+                    main = torch.cuda.current_stream(x.device)
+                    side = L.side_stream(x.device)
+                    side.wait_stream(main)
                 with torch.cuda.stream(side):
                     conv_wgrad_raw(x, gy, ctx.spec, w.shape, want_b, w_slot, b_slot, ctx.aff)
                 x.record_stream(side)
