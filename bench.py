@@ -216,6 +216,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--batch', type=int, default=None, help='diagnostics only: per-GPU batch (the metric is defined at 512)')
     ap.add_argument('--sync-bn', action='store_true', help='BatchNorm statistics over all ranks (default: per rank)')
+    ap.add_argument('--graph', action='store_true',
+                    help='replay the step as a captured HIP graph (ClassificationVariationalNetwork.graph_train_step: one host call per '
+                         'step, three when data parallel) instead of the eager loop: the same kernels, for hosts with few cores per GPU')
     ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'], help='bf16: the mixed-precision mode of BASELINE configs[4]')
     ap.add_argument('--workload', default='2', choices=[str(k) for k in sorted(WORKLOADS)] + ['eval'],
                     help="diagnostics: other BASELINE configs; 'eval' = the label-free evaluation pass (SURVEY.md §8f-1): config 2, "
@@ -271,6 +274,11 @@ def main():
             with torch.no_grad():
                 _, _, losses, meas = net.evaluate(x, batch=i, current_measures=meas)
             return losses, meas
+    elif a.graph:
+        replay = net.graph_train_step(x, y)
+
+        def one_step(i, meas):
+            return replay(x, y)
     else:
         def one_step(i, meas):
             return net.train_step(x, y, batch=i, current_measures=meas)
@@ -306,6 +314,7 @@ def main():
                                        'N=512 images x L=128 latent draws per step, eval-mode BatchNorm, fp32'
                                        if eval_mode else WORKLOADS[a.workload][0]),
                           'global_batch': world * a.batch, 'parallelism': f'dp{world}',
+                          'launch': 'HIP graph replay' if (a.graph and not eval_mode) else 'eager',
                           'bn_statistics': 'synchronised over ranks' if (a.sync_bn and world > 1) else 'per-rank (local)',
                           'arithmetic': ('fp32 operands, products and accumulation everywhere; the stride-1 and 4-phase 5x5 layers '
                                          'accumulate each fp32 product from 6 bf16 MFMA products of exactly 3-way split operands (dropped terms < 2^-24 of '

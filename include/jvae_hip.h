@@ -194,6 +194,26 @@ int jvae_bn_finalize_b8(const void* x, const float* gamma, const float* beta,
                         int N, int C, long HW, float momentum, float eps, int training,
                         const float* ext_stats, int ext_nsplit, const float* ext_pivot,
                         void* ws, size_t ws_bytes, void* stream);
+/* Synchronised BatchNorm on B8 tensors (data-parallel ranks share the batch statistics): the bf16 counterpart of
+ * jvae_bn_sums_f32 / jvae_bn_fwd_sync_f32 / jvae_bn_bwd_sums_f32 / jvae_bn_bwd_sync_f32 (same protocol: the host all-reduces
+ * the (C,2) sums between the two calls of each direction; reference semantics: nn.BatchNorm2d of the single-process
+ * reference on the GLOBAL batch, module/vae_layers/conv.py:214-220).  Workspace: jvae_bn_workspace_bytes_b8(C). */
+int jvae_bn_sums_b8(const void* x, const float* pivot, float* sums, int N, int C, long HW,
+                    void* ws, size_t ws_bytes, void* stream);
+int jvae_bn_fwd_sync_b8(const void* x, const float* gamma, const float* beta,
+                        float* running_mean, float* running_var, long long* num_batches_tracked,
+                        void* y, float* save_mean, float* save_invstd,
+                        int N, int C, long HW, float momentum, float eps, int relu,
+                        const float* global_sums, const float* pivot, int world,
+                        void* ws, size_t ws_bytes, void* stream);
+int jvae_bn_bwd_sums_b8(const void* dy, const void* x, const float* gamma, const float* beta,
+                        const float* save_mean, const float* save_invstd, float* local_sums,
+                        int N, int C, long HW, int relu, void* ws, size_t ws_bytes, void* stream);
+int jvae_bn_bwd_sync_b8(const void* dy, const void* x, const float* gamma, const float* beta,
+                        const float* save_mean, const float* save_invstd,
+                        const float* local_sums, const float* global_sums, int world,
+                        void* dx, float* dgamma, float* dbeta, int accumulate,
+                        int N, int C, long HW, int relu, void* ws, size_t ws_bytes, void* stream);
 int jvae_conv2d_affine_ok_b8(int N, int Cin, int H, int W, int Cout, int KH, int KW, int S, int P, int OP, int transposed);
 int jvae_conv2d_fwd_aff_b8(const void* x, const float* w, const float* bias, void* y, int y_f32, float* stats, int* nsplit,
                            const float* in_scale, const float* in_shift, int in_relu,

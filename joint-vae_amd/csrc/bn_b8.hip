@@ -49,10 +49,14 @@ __device__ __forceinline__ void block_sum8(float (&v)[8], float (*red)[8]) {
 
 // partial[c][s] = (sum(x - p), sum((x - p)^2)) over the images of split s;  p = x[0][c][0]
 __global__ __launch_bounds__(256) void bn8_stats_kernel(const bf16x8* __restrict__ x, float* __restrict__ partial,
-                                                        int N, int C, int CB, long HW, int nsplit) {
+                                                        int N, int C, int CB, long HW, int nsplit,
+                                                        const float* __restrict__ pivot) {
     __shared__ float red[4][8];
     const int cb = blockIdx.x, s = blockIdx.y;
-    const bf16x8 pv = x[(long)cb * HW];
+    bf16x8 pv = x[(long)cb * HW];
+    float pf[8];            // pivot (C) given: the same on every data-parallel rank (synchronised statistics)
+#pragma unroll
+    for (int ci = 0; ci < 8; ++ci) pf[ci] = pivot ? (cb * 8 + ci < C ? pivot[cb * 8 + ci] : 0.f) : (float)pv[ci];
     const int per = (N + nsplit - 1) / nsplit;
     const int nb = s * per, ne = min(N, nb + per);
     float s1[8], s2[8];
@@ -64,7 +68,7 @@ __global__ __launch_bounds__(256) void bn8_stats_kernel(const bf16x8* __restrict
     for (unsigned i = threadIdx.x; i < cnt; i += 256) {
         const bf16x8 v = x[ui(i)];
 #pragma unroll
-        for (int ci = 0; ci < 8; ++ci) { const float d = (float)v[ci] - (float)pv[ci]; s1[ci] += d; s2[ci] += d * d; }
+        for (int ci = 0; ci < 8; ++ci) { const float d = (float)v[ci] - pf[ci]; s1[ci] += d; s2[ci] += d * d; }
     }
     block_sum8(s1, red);
     block_sum8(s2, red);
@@ -255,6 +259,33 @@ __global__ __launch_bounds__(256) void bn8_bwd_apply_kernel(const bf16x8* __rest
     }
 }
 
+// sums[c] = fold of partial[c][0..nsplit) (fp64, fixed order): the (C,2) block the ranks all-reduce
+__global__ __launch_bounds__(64) void bn8_fold_kernel(const float* __restrict__ partial, float* __restrict__ sums, int nsplit) {
+    const int c = blockIdx.x, l = threadIdx.x;
+    double s1 = 0., s2 = 0.;
+    for (int s = l; s < nsplit; s += 64) {
+        s1 += (double)partial[((long)c * nsplit + s) * 2 + 0];
+        s2 += (double)partial[((long)c * nsplit + s) * 2 + 1];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+    if (l == 0) { sums[2 * c] = (float)s1; sums[2 * c + 1] = (float)s2; }
+}
+
+// synchronised backward: means of (g, g*xhat) over ALL ranks from the all-reduced sums; dgamma / dbeta stay the local sums
+__global__ void bn8_bwd_sync_coef_kernel(const float* __restrict__ local, const float* __restrict__ global,
+                                         float* __restrict__ coef, float* dgamma, float* dbeta, int accumulate,
+                                         double count, int C, int C8) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C8) return;
+    coef[c] = c < C ? (float)((double)global[2 * c] / count) : 0.f;
+    coef[C8 + c] = c < C ? (float)((double)global[2 * c + 1] / count) : 0.f;
+    if (c < C) {
+        if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + local[2 * c];
+        if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + local[2 * c + 1];
+    }
+}
+
 // y = relu(x) / dx = dy * [y > 0] on B8 tensors (layers without BatchNorm)
 __global__ __launch_bounds__(256) void relu8_fwd_kernel(const bf16x8* __restrict__ x, bf16x8* __restrict__ y, long n) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
@@ -323,7 +354,7 @@ int jvae_bn_fwd_b8(const void* x, const float* gamma, const float* beta,
         ns = ext_nsplit;
     } else if (training) {
         ns = pick_split(N, CB, HW);
-        hipLaunchKernelGGL(bn8_stats_kernel, dim3(CB, ns), dim3(256), 0, st, (const bf16x8*)x, (float*)ws, N, C, CB, HW, ns);
+        hipLaunchKernelGGL(bn8_stats_kernel, dim3(CB, ns), dim3(256), 0, st, (const bf16x8*)x, (float*)ws, N, C, CB, HW, ns, (const float*)nullptr);
         JVAE_LAUNCH_CHECK();
     } else if (!running_mean || !running_var) {
         return JVAE_EINVAL;
@@ -361,7 +392,7 @@ int jvae_bn_finalize_b8(const void* x, const float* gamma, const float* beta,
         ns = ext_nsplit;
     } else if (training) {
         ns = pick_split(N, CB, HW);
-        hipLaunchKernelGGL(bn8_stats_kernel, dim3(CB, ns), dim3(256), 0, st, (const bf16x8*)x, (float*)ws, N, C, CB, HW, ns);
+        hipLaunchKernelGGL(bn8_stats_kernel, dim3(CB, ns), dim3(256), 0, st, (const bf16x8*)x, (float*)ws, N, C, CB, HW, ns, (const float*)nullptr);
         JVAE_LAUNCH_CHECK();
     } else if (!running_mean || !running_var) {
         return JVAE_EINVAL;
@@ -399,6 +430,90 @@ int jvae_bn_bwd_b8(const void* dy, const void* x, const float* gamma, const floa
 }
 
 // ReLU on B8 tensors of `units` 16-byte units (backward takes the forward OUTPUT)
+// ---- synchronised BatchNorm on B8 tensors (data-parallel ranks share the batch statistics) ----------------
+// Same protocol as the fp32 entry points (bn.hip): the host all-reduces the (C,2) sums between the two calls of each
+// direction.  Statistics fp32, activations bf16.
+
+// sums[c] = (sum(x - pivot[c]), sum((x - pivot[c])^2)) over this rank's batch; pivot: (C) identical on every rank
+int jvae_bn_sums_b8(const void* x, const float* pivot, float* sums, int N, int C, long HW,
+                    void* ws, size_t ws_bytes, void* stream) {
+    if (!x || !pivot || !sums || N <= 0 || C <= 0 || HW <= 0) return JVAE_EINVAL;
+    if (ws_bytes < jvae_bn_workspace_bytes_b8(C) || !ws) return JVAE_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int CB = (C + 7) / 8;
+    const int ns = pick_split(N, CB, HW);
+    hipLaunchKernelGGL(bn8_stats_kernel, dim3(CB, ns), dim3(256), 0, st, (const bf16x8*)x, (float*)ws, N, C, CB, HW, ns, pivot);
+    JVAE_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn8_fold_kernel, dim3(C), dim3(64), 0, st, (const float*)ws, sums, ns);
+    JVAE_LAUNCH_CHECK();
+    return 0;
+}
+
+// forward from the all-reduced sums: mean = pivot + S1/n, var = S2/n - (S1/n)^2 with n = N*HW*world; y = [relu](bn(x)) in bf16
+int jvae_bn_fwd_sync_b8(const void* x, const float* gamma, const float* beta,
+                        float* running_mean, float* running_var, long long* num_batches_tracked,
+                        void* y, float* save_mean, float* save_invstd,
+                        int N, int C, long HW, float momentum, float eps, int relu,
+                        const float* global_sums, const float* pivot, int world,
+                        void* ws, size_t ws_bytes, void* stream) {
+    if (!x || !y || !global_sums || !pivot || !save_mean || !save_invstd || world < 1 || N <= 0 || C <= 0 || HW <= 0)
+        return JVAE_EINVAL;
+    if (ws_bytes < jvae_bn_workspace_bytes_b8(C) || !ws) return JVAE_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int CB = (C + 7) / 8;
+    float* coef = (float*)ws + (size_t)2 * CB * 8 * MAX_SPLIT;
+    // one "split" holding the global sums, N*world images behind them
+    hipLaunchKernelGGL(bn8_finalize_kernel, dim3(CB * 8), dim3(64), 0, st, (const bf16x8*)x, global_sums, gamma, beta,
+                       running_mean, running_var, num_batches_tracked, save_mean, save_invstd, coef, N * world, C, CB * 8, HW, 1,
+                       momentum, eps, 1, 1, pivot);
+    JVAE_LAUNCH_CHECK();
+    const int nc = pick_chunk(N, CB, HW);
+    hipLaunchKernelGGL(bn8_apply_kernel, dim3(CB, nc), dim3(256), 0, st, (const bf16x8*)x, (const float*)coef, (bf16x8*)y,
+                       N, CB, HW, nc, relu);
+    JVAE_LAUNCH_CHECK();
+    return 0;
+}
+
+// local_sums[c] = (sum g, sum g*xhat) of this rank (g = dy masked by the fused ReLU)
+int jvae_bn_bwd_sums_b8(const void* dy, const void* x, const float* gamma, const float* beta,
+                        const float* save_mean, const float* save_invstd, float* local_sums,
+                        int N, int C, long HW, int relu, void* ws, size_t ws_bytes, void* stream) {
+    if (!dy || !x || !save_mean || !save_invstd || !local_sums || N <= 0 || C <= 0 || HW <= 0) return JVAE_EINVAL;
+    if (ws_bytes < jvae_bn_workspace_bytes_b8(C) || !ws) return JVAE_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int CB = (C + 7) / 8;
+    const int ns = pick_split(N, CB, HW);
+    hipLaunchKernelGGL(bn8_bwd_reduce_kernel, dim3(CB, ns), dim3(256), 0, st, (const bf16x8*)dy, (const bf16x8*)x, gamma, beta,
+                       save_mean, save_invstd, (float*)ws, N, C, CB, HW, ns, relu);
+    JVAE_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn8_fold_kernel, dim3(C), dim3(64), 0, st, (const float*)ws, local_sums, ns);
+    JVAE_LAUNCH_CHECK();
+    return 0;
+}
+
+// dx from the all-reduced sums (means over N*HW*world elements); dgamma / dbeta (+)= the LOCAL sums (the gradient
+// all-reduce averages them like every other parameter gradient)
+int jvae_bn_bwd_sync_b8(const void* dy, const void* x, const float* gamma, const float* beta,
+                        const float* save_mean, const float* save_invstd,
+                        const float* local_sums, const float* global_sums, int world,
+                        void* dx, float* dgamma, float* dbeta, int accumulate,
+                        int N, int C, long HW, int relu, void* ws, size_t ws_bytes, void* stream) {
+    if (!dy || !x || !save_mean || !save_invstd || !local_sums || !global_sums || !dx || world < 1 || N <= 0 || C <= 0 || HW <= 0)
+        return JVAE_EINVAL;
+    if (ws_bytes < jvae_bn_workspace_bytes_b8(C) || !ws) return JVAE_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int CB = (C + 7) / 8;
+    float* coef = (float*)ws + (size_t)2 * CB * 8 * MAX_SPLIT;
+    hipLaunchKernelGGL(bn8_bwd_sync_coef_kernel, dim3(cdiv(CB * 8, 64)), dim3(64), 0, st, local_sums, global_sums, coef, dgamma, dbeta,
+                       accumulate, (double)N * (double)HW * world, C, CB * 8);
+    JVAE_LAUNCH_CHECK();
+    const int nc = pick_chunk(N, CB, HW);
+    hipLaunchKernelGGL(bn8_bwd_apply_kernel, dim3(CB, nc), dim3(256), 0, st, (const bf16x8*)dy, (const bf16x8*)x, gamma, beta,
+                       save_mean, save_invstd, (const float*)coef, (bf16x8*)dx, N, C, CB, HW, nc, relu);
+    JVAE_LAUNCH_CHECK();
+    return 0;
+}
+
 int jvae_relu_fwd_b8(const void* x, void* y, long units, void* stream) {
     if (!x || !y || units < 0) return JVAE_EINVAL;
     if (units == 0) return 0;

@@ -39,6 +39,10 @@ _SIGS = {
     'jvae_bn_fwd_b8': (c_int, [P] * 9 + [c_int, c_int, c_long, c_float, c_float, c_int, c_int, P, c_int, P, P, c_size_t, P]),
     'jvae_bn_bwd_b8': (c_int, [P] * 9 + [c_int, c_int, c_int, c_long, c_int, P, c_size_t, P]),
     'jvae_bn_finalize_b8': (c_int, [P] * 9 + [c_int, c_int, c_long, c_float, c_float, c_int, P, c_int, P, P, c_size_t, P]),
+    'jvae_bn_sums_b8': (c_int, [P, P, P, c_int, c_int, c_long, P, c_size_t, P]),
+    'jvae_bn_fwd_sync_b8': (c_int, [P] * 9 + [c_int, c_int, c_long, c_float, c_float, c_int, P, P, c_int, P, c_size_t, P]),
+    'jvae_bn_bwd_sums_b8': (c_int, [P] * 7 + [c_int, c_int, c_long, c_int, P, c_size_t, P]),
+    'jvae_bn_bwd_sync_b8': (c_int, [P] * 8 + [c_int, P, P, P, c_int, c_int, c_int, c_long, c_int, P, c_size_t, P]),
     'jvae_conv2d_affine_ok_b8': (c_int, [c_int] * 11),
     'jvae_conv2d_fwd_aff_b8': (c_int, [P, P, P, P, c_int, P, POINTER(c_int), P, P, c_int] + [c_int] * 11 + [P, c_size_t, P]),
     'jvae_conv2d_wgrad_aff_b8': (c_int, [P, P, P, P, c_int, P, P, c_int] + [c_int] * 11 + [P, c_size_t, P]),

@@ -287,6 +287,69 @@ class _BatchNormActB8(torch.autograd.Function):
         return gx, gg, gb, None, None, None, None, None, None, None, None, None
 
 
+class _SyncBatchNormActB8(torch.autograd.Function):
+    """Train-mode BatchNorm2d (+ReLU) on a B8 tensor whose statistics span all data-parallel ranks (ops._SyncBatchNormAct
+    for the bf16 layout): two (C,2) fp32 all-reduces per layer, one in forward, one in backward."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, rm, rv, nbt, relu, momentum, eps, world, group, C):
+        import torch.distributed as dist
+        x = O._c(x)
+        N, CB, H, W, _ = x.shape
+        HW = H * W
+        lib = L.load()
+        ws = L.workspace(lib.jvae_bn_workspace_bytes_b8(C), x.device)
+        pivot = rm.detach().clone()                       # identical on every rank; rm itself is updated by the kernel
+        sums = torch.empty((C, 2), device=x.device, dtype=torch.float32)
+        L.check(lib.jvae_bn_sums_b8(L.ptr(x), L.ptr(pivot), L.ptr(sums), N, C, HW, L.ptr(ws), ws.numel(), L.stream_ptr()),
+                'jvae_bn_sums_b8')
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+        y = torch.empty_like(x)
+        mean = torch.empty(C, device=x.device, dtype=torch.float32)
+        invstd = torch.empty(C, device=x.device, dtype=torch.float32)
+        rc = lib.jvae_bn_fwd_sync_b8(L.ptr(x), L.ptr(gamma), L.ptr(beta), L.ptr(rm), L.ptr(rv), L.ptr(nbt), L.ptr(y),
+                                     L.ptr(mean), L.ptr(invstd), N, C, HW, momentum, eps, int(relu), L.ptr(sums),
+                                     L.ptr(pivot), int(world), L.ptr(ws), ws.numel(), L.stream_ptr())
+        L.check(rc, 'jvae_bn_fwd_sync_b8')
+        ctx.save_for_backward(x, gamma, beta, mean, invstd)
+        ctx.cfg = (N, C, HW, relu, int(world), group)
+        ctx.g_ref, ctx.b_ref = gamma, beta
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        import torch.distributed as dist
+        x, gamma, beta, mean, invstd = ctx.saved_tensors
+        N, C, HW, relu, world, group = ctx.cfg
+        gy = O._c(gy)
+        lib = L.load()
+        ws = L.workspace(lib.jvae_bn_workspace_bytes_b8(C), x.device)
+        local = torch.empty((C, 2), device=x.device, dtype=torch.float32)
+        rc = lib.jvae_bn_bwd_sums_b8(L.ptr(gy), L.ptr(x), L.ptr(gamma), L.ptr(beta), L.ptr(mean), L.ptr(invstd),
+                                     L.ptr(local), N, C, HW, int(relu), L.ptr(ws), ws.numel(), L.stream_ptr())
+        L.check(rc, 'jvae_bn_bwd_sums_b8')
+        glob = local.clone()
+        dist.all_reduce(glob, op=dist.ReduceOp.SUM, group=group)
+        gx = torch.empty_like(x)
+        sg, sb = O._grad_slot(ctx.g_ref), O._grad_slot(ctx.b_ref)
+        inplace = sg is not None and sb is not None
+        gg = sg if inplace else torch.empty(C, device=x.device, dtype=torch.float32)
+        gb = sb if inplace else torch.empty(C, device=x.device, dtype=torch.float32)
+        rc = lib.jvae_bn_bwd_sync_b8(L.ptr(gy), L.ptr(x), L.ptr(gamma), L.ptr(beta), L.ptr(mean), L.ptr(invstd),
+                                     L.ptr(local), L.ptr(glob), world, L.ptr(gx), L.ptr(gg), L.ptr(gb), int(inplace),
+                                     N, C, HW, int(relu), L.ptr(ws), ws.numel(), L.stream_ptr())
+        L.check(rc, 'jvae_bn_bwd_sync_b8')
+        if inplace:
+            gg = gb = None
+        return gx, gg, gb, None, None, None, None, None, None, None, None, None
+
+
+def sync_batchnorm_act(x, C, gamma, beta, running_mean, running_var, num_batches_tracked, relu, momentum, eps, world, group=None):
+    """Synchronised train-mode BatchNorm(+ReLU) on a B8 tensor (statistics over all data-parallel ranks)."""
+    return _SyncBatchNormActB8.apply(x, gamma, beta, running_mean, running_var, num_batches_tracked, relu, momentum, eps,
+                                     world, group, C)
+
+
 class _BatchNormDeferB8(torch.autograd.Function):
     """BatchNorm(+ReLU) on a B8 tensor deferred into the next bf16 convolution (see ops._BatchNormDefer): forward produces
     the statistics and the (scale, shift) rows only and returns the input itself; backward is the ordinary one."""

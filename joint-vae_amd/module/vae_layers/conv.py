@@ -272,9 +272,10 @@ class HipConvStack(nn.Sequential):
                 elif b8 and not (m.training and m.sync_world > 1):
                     x = ops_b8.batchnorm_act(x, channels, m.weight, m.bias, m.running_mean, m.running_var,
                                              m.num_batches_tracked, m.training, relu, m.momentum, m.eps, ext)
+                elif b8:                  # train mode, statistics over all data-parallel ranks: bf16 kernels of their own
+                    x = ops_b8.sync_batchnorm_act(x, channels, m.weight, m.bias, m.running_mean, m.running_var,
+                                                  m.num_batches_tracked, relu, m.momentum, m.eps, m.sync_world, m.sync_group)
                 else:
-                    if b8:
-                        x = ops_b8.from_b8(x, channels)
                     x = m(x, relu=relu, ext=ext)
                 ext = None
                 i += step

@@ -134,3 +134,66 @@ def test_graph_captured_data_parallel_step(tmp_path):
     assert a['last'] < a['first'] and b['last'] < b['first']
     assert not torch.equal(a['eps_probe'], b['eps_probe'])
     assert 0 < a['rmse'] < 10
+
+
+def _b8_worker(rank, port, out_dir):
+    _paths()
+    import torch.distributed as dist
+    from jvae_hip import ops_b8
+    from oracle.det_init import det_inputs
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=WORLD)
+    torch.cuda.set_device(0)
+    net, kw = _build()
+    net.set_compute_dtype('bf16')
+    net.optimizer.set_distributed(WORLD)
+    net.set_sync_batchnorm(WORLD)
+    calls = [0]
+    orig = ops_b8.sync_batchnorm_act
+
+    def counted(*a, **k):
+        calls[0] += 1
+        return orig(*a, **k)
+    ops_b8.sync_batchnorm_act = counted
+    x, y, eps = det_inputs(N_RANK * WORLD, kw['input_shape'], 10, 1, 64, seed=31)
+    sl = slice(rank * N_RANK, (rank + 1) * N_RANK)
+    losses, _ = net.train_step(x[sl].cuda(), y[sl].cuda(), epsilon=eps[:, sl].cuda())
+    torch.save({'losses': {k: v.detach().cpu() for k, v in losses.items()},
+                'params': {k: v.detach().cpu() for k, v in net.state_dict().items()},
+                'gnorm': float(net.optimizer.grad_norm()), 'b8_sync_calls': calls[0]}, os.path.join(out_dir, f'b{rank}.pt'))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sync_batchnorm_bf16_layout_matches_single_process(tmp_path):
+    """The bf16 (B8) mode with synchronised BatchNorm runs on its own kernels (jvae_bn_sums_b8 / fwd_sync / bwd_sums /
+    bwd_sync: no fp32 fall-back between two conversions) and reproduces the single-process bf16 step on the whole batch.
+    Tolerances are the bf16 mode's: the two runs round the same activations to bf16 from statistics
+    that agree to fp32 rounding, so single bf16 ulps (2^-8) flip."""
+    _paths()
+    from oracle.det_init import det_inputs
+    port = 29800 + os.getpid() % 1000
+    mp.spawn(_b8_worker, args=(port, str(tmp_path)), nprocs=WORLD, join=True)
+    net, kw = _build()
+    net.set_compute_dtype('bf16')
+    x, y, eps = det_inputs(N_RANK * WORLD, kw['input_shape'], 10, 1, 64, seed=31)
+    full, _ = net.train_step(x.cuda(), y.cuda(), epsilon=eps.cuda())
+    ranks = [torch.load(os.path.join(tmp_path, f'b{r}.pt')) for r in range(WORLD)]
+    assert ranks[0]['b8_sync_calls'] >= 8 and ranks[1]['b8_sync_calls'] == ranks[0]['b8_sync_calls']
+
+    def rel(a, b):
+        return float((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30))
+    for r in range(WORLD):
+        sl = slice(r * N_RANK, (r + 1) * N_RANK)
+        for k, tol in (('total', 5e-3), ('cross_x', 5e-3), ('kl', 2e-2)):
+            assert rel(ranks[r]['losses'][k], full[k].detach().cpu()[sl]) < tol, (r, k)
+    gn = float(net.optimizer.grad_norm())
+    assert abs(ranks[0]['gnorm'] - gn) < 2e-2 * gn and abs(ranks[1]['gnorm'] - gn) < 2e-2 * gn
+    mine = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    for k in mine:
+        if k.endswith('running_var') or k.endswith('running_mean'):      # global-batch statistics on every rank
+            assert torch.equal(ranks[0]['params'][k], ranks[1]['params'][k]), k
+            assert rel(ranks[0]['params'][k], mine[k]) < 2e-2, k
+    for k, v in ranks[0]['params'].items():                              # replicas stay identical
+        if v.dtype.is_floating_point:
+            assert torch.equal(v, ranks[1]['params'][k]), k
