@@ -47,7 +47,51 @@ def both(main_f, side_f, reps=10):
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e3, e0.elapsed_time(s1) / reps * 1e3
 for nm, f in (('wgrad', wgrad), ('dgrad', dgrad)):
-    m, s = both(bn_bwd, f)
+    both(bn_bwd, f)          # first use of the side stream: workspace allocation, kernel attributes (NOT timed: an earlier
+    m, s = both(bn_bwd, f)   # version of this probe timed it and reported a 2.3x collapse that does not exist)
     print('bn_bwd (main) beside %s (side): bn %.0f us per call, %s %.0f us per call' % (nm, m, nm, s))
 m, s = both(dgrad, wgrad)
 print('dgrad (main) beside wgrad (side): dgrad %.0f, wgrad %.0f us per call' % (m, s))
+# which property of the BatchNorm-backward kernels makes them crawl beside the weight gradients?  A plain streaming copy and
+# a streaming reduction of the same tensors, for comparison
+def copy():
+    dz.copy_(z)
+def tsum():
+    return z.sum()
+print('alone: copy %.0f us, sum %.0f us' % (t(copy), t(tsum)))
+for nm, f in (('copy', copy), ('sum', tsum)):
+    m, s = both(f, wgrad)
+    print('%s (main) beside wgrad (side): %s %.0f us per call, wgrad %.0f us per call' % (nm, nm, m, s))
+m, s = both(wgrad, bn_bwd)
+print('wgrad (main) beside bn_bwd (side): wgrad %.0f, bn %.0f us per call' % (m, s))
+# stream roles: which stream carries the chain (BatchNorm backward) and which the weight gradients?
+def pair(sa, sb, fa, fb, reps=10):
+    torch.cuda.synchronize()
+    e0, ea, eb = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    cur = torch.cuda.current_stream()
+    e0.record()
+    for s_ in (sa, sb):
+        if s_ is not None: s_.wait_stream(cur)
+    with torch.cuda.stream(sb if sb is not None else cur):
+        for _ in range(reps): fb()
+        eb.record()
+    with torch.cuda.stream(sa if sa is not None else cur):
+        for _ in range(reps): fa()
+        ea.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(ea) / reps * 1e3, e0.elapsed_time(eb) / reps * 1e3
+lo, hi = -1, 0
+try:
+    from ctypes import CDLL, c_int, byref
+    a_, b_ = c_int(), c_int()
+    CDLL('libamdhip64.so').hipDeviceGetStreamPriorityRange(byref(a_), byref(b_))
+    print('stream priority range: least %d greatest %d' % (a_.value, b_.value))
+except Exception as e:
+    print('priority range query failed', e)
+A, B = torch.cuda.Stream(), torch.cuda.Stream()
+HP = torch.cuda.Stream(priority=-1)
+for nm, sa, sb in (('bn default / wgrad created', None, B), ('bn created / wgrad created', A, B), ('bn created / wgrad default', A, None),
+                   ('bn high-priority created / wgrad created', HP, B), ('bn high-priority created / wgrad default', HP, None)):
+    for _ in range(2):
+        m, s = pair(sa, sb, bn_bwd, wgrad)
+    print('%-46s bn %.0f us, wgrad %.0f us per call' % (nm + ':', m, s))
