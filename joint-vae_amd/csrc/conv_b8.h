@@ -31,3 +31,10 @@ size_t jvae_conv5_wgrad_b8_ws_floats(int N, int Ca, int Cb);
 int jvae_conv5_wgrad_b8(const void* ps, const void* q, float* dw, int accumulate, int swapflip,
                         int N, int Ca, int WS, int Cb, int S, int P, float* ws, hipStream_t st,
                         const InAff* aff_p = nullptr, const InAff* aff_q = nullptr);
+
+// conv_wgrad_x3.hip: the same operator on the LDS image / pipeline of the split-bf16 weight-gradient kernel, one plane
+bool jvae_conv5_wgrad_b8x_ok(int Ca, int HS, int WS, int Cb, int HB, int WB, int S, int P);
+size_t jvae_conv5_wgrad_b8x_ws_floats(int N, int Ca, int Cb, int S);
+int jvae_conv5_wgrad_b8x(const void* ps, const void* q, float* dw, int accumulate, int swapflip,
+                         int N, int Ca, int WS, int Cb, int S, int P, float* ws, hipStream_t st,
+                         const InAff* aff_p = nullptr, const InAff* aff_q = nullptr);

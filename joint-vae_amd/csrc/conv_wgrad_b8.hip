@@ -250,12 +250,20 @@ bool jvae_conv5_wgrad_b8_ok(int Ca, int HS, int WS, int Cb, int HB, int WB, int 
     return true;
 }
 
-size_t jvae_conv5_wgrad_b8_ws_floats(int N, int Ca, int Cb) { return (size_t)slab_count(N, Ca, Cb) * Ca * Cb * 25; }
+size_t jvae_conv5_wgrad_b8_ws_floats(int N, int Ca, int Cb) {
+    const size_t a = (size_t)slab_count(N, Ca, Cb) * Ca * Cb * 25;
+    const size_t b1 = jvae_conv5_wgrad_b8x_ws_floats(N, Ca, Cb, 1), b2 = jvae_conv5_wgrad_b8x_ws_floats(N, Ca, Cb, 2);
+    const size_t b = b1 > b2 ? b1 : b2;
+    return a > b ? a : b;
+}
 
 // dW (+)= ...; ps / q: B8 tensors; swapflip: the caller passed the role-swapped problem (dst = (b*Ca + a)*25 + 24 - tap)
 int jvae_conv5_wgrad_b8(const void* ps, const void* q, float* dw, int accumulate, int swapflip,
                         int N, int Ca, int WS, int Cb, int S, int P, float* ws, hipStream_t st,
                         const InAff* aff_p, const InAff* aff_q) {
+    // the LDS image and read-ahead pipeline of the split-bf16 kernel, one plane (conv_wgrad_x3.hip)
+    if (jvae_conv5_wgrad_b8x_ok(Ca, WS, WS, Cb, WS * S, WS * S, S, P))
+        return jvae_conv5_wgrad_b8x(ps, q, dw, accumulate, swapflip, N, Ca, WS, Cb, S, P, ws, st, aff_p, aff_q);
     const InAff none{nullptr, nullptr, 0};
     WgB8P p{(const u32x4*)ps, (const u32x4*)q, ws, N, Ca, Cb, (Ca + 7) / 8, (Cb + 7) / 8, P, slab_count(N, Ca, Cb),
             aff_p ? *aff_p : none, aff_q ? *aff_q : none};

@@ -39,14 +39,14 @@ typedef x3_f32x2 f32x2;
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 
 struct WgX3P {
-    const float* ps;     // (N, Ca, HS, WS)
-    const float* q;      // (N, Cb, HB, WB)
+    const void* ps;      // (N, Ca, HS, WS) fp32 NCHW, or B8 units (N, ceil(Ca/8), HS, WS) for the one-plane (bf16) form
+    const void* q;       // (N, Cb, HB, WB) / B8 units (N, ceil(Cb/8), HB, WB)
     float* slab;         // (G, Ca, 25, Cb)
     int N, Ca, Cb, P, G;
     InAff aff_p, aff_q;  // deferred BatchNorm(+ReLU) of ps / q (whichever is the layer input; sc == nullptr: none)
 };
 
-template <int S, int WS, int MODE>
+template <int S, int WS, int MODE, int NPL = 3>
 struct WgX3Geom {
     static constexpr int HS = WS;
     static constexpr int TPIX = (S == 1 && WS >= 16) ? 128 : 64;
@@ -69,9 +69,11 @@ struct WgX3Geom {
     static constexpr int PS = 4 * TPIX;                        // units per plane (32 channels a): [pixel][block]
     static constexpr int NTILE = MODE == 0 ? 25 : (MODE == 2 ? 13 : 7);
     static constexpr int NBT = (NTILE + 3) / 4;                // per wave
-    static constexpr int LDS_BYTES = 3 * (QS + PS) * 16;
+    static constexpr int LDS_BYTES = NPL * (QS + PS) * 16;
     static constexpr int QITEMS = NCBQ * ROWS * (WB / 2);      // staging items: 2 pixels x 8 channels
     static constexpr int PITEMS = 4 * (TPIX / 2);
+    static constexpr int QUNITS = NCBQ * ROWS * WB;            // one-plane form: staging items = B8 units
+    static constexpr int PUNITS = 4 * TPIX;
 };
 
 // HI = byte distance of 4 pixels (4 slots x the channel blocks per slot x 16 bytes)
@@ -85,14 +87,18 @@ __device__ __forceinline__ bf16x8 tr_pair(const unsigned char* base, int off) {
 // SH16: the products run on v_mfma_f32_16x16x32_bf16 (K step = 32 pixels, a 32 x 32 tile = 2 x 2 blocks of 16 x 16) instead of
 // v_mfma_f32_32x32x16_bf16: the same LDS image, the same reads and MFMA cycles per FLOP; the chip holds a higher clock under
 // the 16x16x32 shape (MI355X_MICROARCH.md, DVFS give-back item 7).  JVAE_WGRAD_SH16=0 selects the 32x32x16 form (A/B).
-template <int S, int WS, int MODE, bool AFF, bool SH16>
+// NPL = 1: the operands are bf16 "B8" tensors (conv_b8.hip: 16-byte units of 8 channels per pixel - exactly the units of the
+// LDS image): no split, ONE plane, one MFMA per product; everything else (LDS image, transposed reads, read-ahead, slabs) is
+// shared with the split-bf16 form.  This is the weight-gradient kernel of the bf16 mode (BASELINE configs[4]).
+template <int S, int WS, int MODE, bool AFF, bool SH16, int NPL = 3>
 __global__ __launch_bounds__(256, 2) void conv5_wgrad_x3_kernel(WgX3P p) {
-    using G = WgX3Geom<S, WS, MODE>;
+    using G = WgX3Geom<S, WS, MODE, NPL>;
+    static_assert(NPL == 3 || (NPL == 1 && SH16), "one-plane form: 16x16x32 shape only");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    u32x4* Qs = reinterpret_cast<u32x4*>(lds_raw);             // [3 planes][QS]
-    u32x4* Pt = Qs + 3 * G::QS;                                // [3 planes][PS]
+    u32x4* Qs = reinterpret_cast<u32x4*>(lds_raw);             // [NPL planes][QS]
+    u32x4* Pt = Qs + NPL * G::QS;                              // [NPL planes][PS]
     const unsigned char* Qb = lds_raw;
-    const unsigned char* Pb = lds_raw + 3 * G::QS * 16;
+    const unsigned char* Pb = lds_raw + NPL * G::QS * 16;
     constexpr int NT8 = 8 * (G::NCBQ + 4);
     __shared__ float ctab[AFF ? 2 * NT8 : 1];                  // (scale, shift) of this workgroup's q / ps channels
 
@@ -102,7 +108,7 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_x3_kernel(WgX3P p) {
     const int cbq0 = blockIdx.z * G::NCBQ;                     // first 8-channel block of Q of this workgroup
 
     // halo columns are zeroed once and never written again (rows are rewritten per item, with zeros outside the image)
-    for (int i = tid; i < 3 * G::QS; i += 256) Qs[i] = u32x4{0u, 0u, 0u, 0u};
+    for (int i = tid; i < NPL * G::QS; i += 256) Qs[i] = u32x4{0u, 0u, 0u, 0u};
     if (AFF && tid < NT8) {
         constexpr int NQ = 8 * G::NCBQ;
         const bool isq = tid < NQ;
@@ -179,7 +185,15 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_x3_kernel(WgX3P p) {
     constexpr int HB = G::HS * S;
     constexpr int W2 = G::WB / 2;
     const long qcs = (long)HB * G::WB, pcs = (long)G::HS * WS;  // channel strides
-    f32x2 rq[QU][8], rp[PU][8];
+    f32x2 rq[QU][8], rp[PU][8];                 // (dead in the one-plane form)
+    const float* const qf = (const float*)p.q;
+    const float* const psf = (const float*)p.ps;
+    // one-plane form: B8 units straight from HBM
+    constexpr int QU8 = (G::QUNITS + 255) / 256, PU8 = (G::PUNITS + 255) / 256;
+    u32x4 rq8[QU8], rp8[PU8];                   // (dead in the split form)
+    const u32x4* const q8 = (const u32x4*)p.q;
+    const u32x4* const ps8 = (const u32x4*)p.ps;
+    const int CBa = (p.Ca + 7) / 8, CBb = (p.Cb + 7) / 8;
 
     // Loads are unconditional (out-of-range items read a valid stand-in address and are zeroed when they are stored to
     // LDS) so that the compiler can count the loads in flight.
@@ -187,6 +201,26 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_x3_kernel(WgX3P p) {
         const int n = item / G::TILES, tile = item % G::TILES;
         const int row0 = tile * G::TH;
         const int in_row0 = row0 * S - p.P;
+        if constexpr (NPL == 1) {
+#pragma unroll
+            for (int k = 0; k < QU8; ++k) {                    // x fastest: 16 * WB contiguous bytes per row
+                const int u = tid + k * 256;
+                const int x = u % G::WB, t = u / G::WB;
+                const int lr = t % G::ROWS, c = t / G::ROWS;
+                const int ir = in_row0 + lr, cb = cbq0 + c;
+                const bool ok = u < G::QUNITS && ir >= 0 && ir < HB && cb < CBb;
+                rq8[k] = ok ? q8[(((long)n * CBb + cb) * HB + ir) * G::WB + x] : q8[0];     // stand-in address: zeroed in lstore
+            }
+#pragma unroll
+            for (int k = 0; k < PU8; ++k) {
+                const int u = tid + k * 256;
+                const int px = u % G::TPIX, c = u / G::TPIX;
+                const int cb = (a0 >> 3) + c;
+                const bool ok = u < G::PUNITS && cb < CBa;
+                rp8[k] = ok ? ps8[(((long)n * CBa + cb) * G::HS + row0) * WS + px] : ps8[0];
+            }
+            return;
+        }
 #pragma unroll
         for (int k = 0; k < QU; ++k) {
             const int u = tid + k * 256;
@@ -195,10 +229,10 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_x3_kernel(WgX3P p) {
             const int lr = u / (G::NCBQ * W2);
             const int ir = in_row0 + lr, ch0 = (cbq0 + c) * 8;
             const bool ok = u < G::QITEMS && ir >= 0 && ir < HB;
-            const float* src = p.q + (((long)n * p.Cb + ch0) * HB + (ok ? ir : 0)) * G::WB + 2 * xp;
+            const float* src = qf + (((long)n * p.Cb + ch0) * HB + (ok ? ir : 0)) * G::WB + 2 * xp;
 #pragma unroll
             for (int ci = 0; ci < 8; ++ci)
-                rq[k][ci] = *reinterpret_cast<const f32x2*>((ok && ch0 + ci < p.Cb) ? src + ci * qcs : p.q);
+                rq[k][ci] = *reinterpret_cast<const f32x2*>((ok && ch0 + ci < p.Cb) ? src + ci * qcs : qf);
         }
 #pragma unroll
         for (int k = 0; k < PU; ++k) {
@@ -206,10 +240,10 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_x3_kernel(WgX3P p) {
             const int c = u % 4, px2 = u / 4;
             const int ch0 = a0 + c * 8;
             const bool ok = u < G::PITEMS;
-            const float* src = p.ps + (((long)n * p.Ca + ch0) * G::HS + row0) * WS + 2 * px2;
+            const float* src = psf + (((long)n * p.Ca + ch0) * G::HS + row0) * WS + 2 * px2;
 #pragma unroll
             for (int ci = 0; ci < 8; ++ci)
-                rp[k][ci] = *reinterpret_cast<const f32x2*>((ok && ch0 + ci < p.Ca) ? src + ci * pcs : p.ps);
+                rp[k][ci] = *reinterpret_cast<const f32x2*>((ok && ch0 + ci < p.Ca) ? src + ci * pcs : psf);
         }
     };
     // 2 pixels x 8 channels of fp32 -> [deferred BatchNorm] -> three bf16 planes, two 16-byte units each
@@ -239,6 +273,36 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_x3_kernel(WgX3P p) {
     };
     auto lstore = [&](int item) {                  // item: the work item whose data sits in rq / rp
         const int in_row0 = (item % G::TILES) * G::TH * S - p.P;
+        if constexpr (NPL == 1) {
+#pragma unroll
+            for (int k = 0; k < QU8; ++k) {
+                const int u = tid + k * 256;
+                if (u < G::QUNITS) {
+                    const int x = u % G::WB, t = u / G::WB;
+                    const int lr = t % G::ROWS, c = t / G::ROWS;
+                    const int ir = in_row0 + lr;
+                    const bool live = ir >= 0 && ir < HB && cbq0 + c < CBb;      // padding rows / missing blocks: exact zeros
+                    u32x4 v = live ? rq8[k] : u32x4{0u, 0u, 0u, 0u};
+                    if (AFF && p.aff_q.sc && live) v = aff8(v, &ctab[c * 8], &ctab[NT8 + c * 8], p.aff_q.relu);
+                    const int c0 = p.P + x;
+                    const int sl = S == 1 ? c0 : (c0 & 1) * G::WPH + (c0 >> 1);
+                    Qs[(lr * G::WPS + sl) * G::NCBQ + c] = v;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < PU8; ++k) {
+                const int u = tid + k * 256;
+                if (u < G::PUNITS) {
+                    const int px = u % G::TPIX, c = u / G::TPIX;
+                    const bool live = (a0 >> 3) + c < CBa;
+                    u32x4 v = live ? rp8[k] : u32x4{0u, 0u, 0u, 0u};
+                    if (AFF && p.aff_p.sc && live)
+                        v = aff8(v, &ctab[(G::NCBQ + c) * 8], &ctab[NT8 + (G::NCBQ + c) * 8], p.aff_p.relu);
+                    Pt[px * 4 + c] = v;
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int k = 0; k < QU; ++k) {
             const int u = tid + k * 256;
@@ -276,19 +340,19 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_x3_kernel(WgX3P p) {
             // slots = (K step of 32 pixels, tile, 16-column block): the fragments of the next slot are read before the 12
             // MFMAs (2 row blocks x 6 products) of the current one are issued
             constexpr int KS = G::TPIX / 32, NSLOT = G::NBT * 2;
-            bf16x8 a[2][3], b[2][3];
+            bf16x8 a[2][NPL], b[2][NPL];
             auto read_a = [&](int ks) {
 #pragma unroll
                 for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-                    for (int plane = 0; plane < 3; ++plane)
+                    for (int plane = 0; plane < NPL; ++plane)
                         a[rb][plane] = tr_pair<256>(Pb + plane * G::PS * 16, aoff16 + rb * 32 + ks * 32 * 64);
             };
-            auto read_b = [&](int ks, int slot, bf16x8 (&d)[3]) {
+            auto read_b = [&](int ks, int slot, bf16x8 (&d)[NPL]) {
                 const int pix0 = ks * 32;
                 const int qoff = ((pix0 / WS) * S * G::WPS + (pix0 % WS)) * G::NCBQ * 16;
 #pragma unroll
-                for (int plane = 0; plane < 3; ++plane)
+                for (int plane = 0; plane < NPL; ++plane)
                     d[plane] = tr_pair<64 * G::NCBQ>(Qb + plane * G::QS * 16,
                                                      (MODE == 0 ? boff16[slot >> 1][0] + (slot & 1) * 32 : boff16[slot >> 1][slot & 1]) + qoff);
             };
@@ -304,19 +368,20 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_x3_kernel(WgX3P p) {
                     else if (ks + 1 < KS) read_b(ks + 1, 0, b[cur ^ 1]);
                     __builtin_amdgcn_sched_barrier(0);
                     if (wave + 4 * t < G::NTILE) {                                 // wave-uniform
+                        constexpr int NPROD = NPL == 3 ? 6 : 1;        // one-plane form: the product itself
                         constexpr int APL[6] = {0, 2, 1, 0, 1, 0}, BPL[6] = {2, 0, 1, 1, 0, 0};
 #pragma unroll
-                        for (int m = 0; m < 6; ++m)
+                        for (int m = 0; m < NPROD; ++m)
 #pragma unroll
                             for (int rb = 0; rb < 2; ++rb)
-                                acc16[t][rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[rb][APL[m]], b[cur][BPL[m]],
+                                acc16[t][rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[rb][NPL == 3 ? APL[m] : 0], b[cur][NPL == 3 ? BPL[m] : 0],
                                                                                            acc16[t][rb][cb], 0, 0, 0);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     if (slot + 1 == NSLOT && ks + 1 < KS) read_a(ks + 1);           // the Ps fragments are free again
                 }
             }
-        } else {
+        } else if constexpr (NPL == 3) {
         // Software-pipelined over the (K step, tile) sequence: the fragments of the NEXT slot are read before the six
         // MFMAs of the current one are issued (hipcc would otherwise place every read right in front of its consumer and
         // wait for it with the matrix pipe idle).  Slots beyond a wave's tiles read a valid stand-in address.
@@ -399,10 +464,29 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_x3_kernel(WgX3P p) {
     }
 }
 
-template <int S, int WS, int MODE>
+template <int S, int WS, int MODE, int NPL = 3>
 int launch_wgx3(const WgX3P& p, hipStream_t st) {
-    using G = WgX3Geom<S, WS, MODE>;
+    using G = WgX3Geom<S, WS, MODE, NPL>;
     static_assert(G::LDS_BYTES + 2048 <= 80 * 1024, "two workgroups per CU must fit the 160 KB LDS");
+    dim3 grid(p.G, (p.Ca + 31) / 32, (p.Cb + 8 * G::NCBQ - 1) / (8 * G::NCBQ));
+    if (MODE == 1) grid.z = 1;
+    const bool aff = p.aff_p.sc || p.aff_q.sc;
+    if constexpr (NPL == 1) {
+        static bool attr1 = false;
+        if (!attr1) {
+            const void* fns[2] = {reinterpret_cast<const void*>(&conv5_wgrad_x3_kernel<S, WS, MODE, false, true, 1>),
+                                  reinterpret_cast<const void*>(&conv5_wgrad_x3_kernel<S, WS, MODE, true, true, 1>)};
+            for (const void* f : fns) {
+                hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+                if (e != hipSuccess) return (int)e;
+            }
+            attr1 = true;
+        }
+        if (aff) hipLaunchKernelGGL((conv5_wgrad_x3_kernel<S, WS, MODE, true, true, 1>), grid, dim3(256), G::LDS_BYTES, st, p);
+        else hipLaunchKernelGGL((conv5_wgrad_x3_kernel<S, WS, MODE, false, true, 1>), grid, dim3(256), G::LDS_BYTES, st, p);
+        JVAE_LAUNCH_CHECK();
+        return 0;
+    } else {
     static bool attr_set = false;
     if (!attr_set) {
         const void* fns[4] = {reinterpret_cast<const void*>(&conv5_wgrad_x3_kernel<S, WS, MODE, false, false>),
@@ -415,11 +499,8 @@ int launch_wgx3(const WgX3P& p, hipStream_t st) {
         }
         attr_set = true;
     }
-    dim3 grid(p.G, (p.Ca + 31) / 32, (p.Cb + 8 * G::NCBQ - 1) / (8 * G::NCBQ));
-    if (MODE == 1) grid.z = 1;
     static int sh16 = -1;
     if (sh16 < 0) { const char* e = getenv("JVAE_WGRAD_SH16"); sh16 = (e && e[0] == '0') ? 0 : 1; }
-    const bool aff = p.aff_p.sc || p.aff_q.sc;
     if (sh16) {
         if (aff) hipLaunchKernelGGL((conv5_wgrad_x3_kernel<S, WS, MODE, true, true>), grid, dim3(256), G::LDS_BYTES, st, p);
         else hipLaunchKernelGGL((conv5_wgrad_x3_kernel<S, WS, MODE, false, true>), grid, dim3(256), G::LDS_BYTES, st, p);
@@ -429,6 +510,7 @@ int launch_wgx3(const WgX3P& p, hipStream_t st) {
     }
     JVAE_LAUNCH_CHECK();
     return 0;
+    }
 }
 
 inline int x3_mode(int S, int Cb) { return Cb <= 8 ? 1 : (S == 2 ? 2 : 0); }
@@ -480,6 +562,43 @@ int jvae_conv5_wgrad_x3(const float* ps, const float* q, float* dw, int accumula
         switch (WS) { WGX3_CASE(2, 8, 2) WGX3_CASE(2, 16, 2) WGX3_CASE(2, 32, 2) }
     }
 #undef WGX3_CASE
+    if (rc) return rc;
+    return jvae_wgrad_slab_reduce(ws, dw, p.G, Ca, Cb, accumulate, swapflip, st, 1);
+}
+
+// ---- the one-plane form for bf16 "B8" operands (conv_wgrad_b8.hip dispatches here; JVAE_WGRAD_B8X=0: its own older kernel)
+bool jvae_conv5_wgrad_b8x_ok(int Ca, int HS, int WS, int Cb, int HB, int WB, int S, int P) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("JVAE_WGRAD_B8X"); on = (e && e[0] == '0') ? 0 : 1; }
+    if (!on) return false;
+    if (S != 1 && S != 2) return false;
+    if (HS != WS || HB != WB || WB != WS * S) return false;
+    if (WS != 8 && WS != 16 && WS != 32 && !(WS == 64 && S == 1)) return false;
+    if (P < 0 || P > 4 || Ca < 16 || Cb < 1) return false;
+    if (P + WB > (WS - 1) * S + 5) return false;
+    return true;
+}
+
+size_t jvae_conv5_wgrad_b8x_ws_floats(int N, int Ca, int Cb, int S) { return (size_t)slab_count_x3(N, Ca, Cb, S) * Ca * Cb * 25; }
+
+int jvae_conv5_wgrad_b8x(const void* ps, const void* q, float* dw, int accumulate, int swapflip,
+                         int N, int Ca, int WS, int Cb, int S, int P, float* ws, hipStream_t st,
+                         const InAff* aff_p, const InAff* aff_q) {
+    const InAff none{nullptr, nullptr, 0};
+    WgX3P p{ps, q, ws, N, Ca, Cb, P, slab_count_x3(N, Ca, Cb, S), aff_p ? *aff_p : none, aff_q ? *aff_q : none};
+    int rc = JVAE_ENOTSUP;
+    const int mode = x3_mode(S, Cb);
+#define WGB8X_CASE(S_, WS_, M_) case WS_: rc = launch_wgx3<S_, WS_, M_, 1>(p, st); break;
+    if (mode == 1 && S == 1) {
+        switch (WS) { WGB8X_CASE(1, 8, 1) WGB8X_CASE(1, 16, 1) WGB8X_CASE(1, 32, 1) WGB8X_CASE(1, 64, 1) }
+    } else if (mode == 1) {
+        switch (WS) { WGB8X_CASE(2, 8, 1) WGB8X_CASE(2, 16, 1) WGB8X_CASE(2, 32, 1) }
+    } else if (mode == 0) {
+        switch (WS) { WGB8X_CASE(1, 8, 0) WGB8X_CASE(1, 16, 0) WGB8X_CASE(1, 32, 0) WGB8X_CASE(1, 64, 0) }
+    } else {
+        switch (WS) { WGB8X_CASE(2, 8, 2) WGB8X_CASE(2, 16, 2) WGB8X_CASE(2, 32, 2) }
+    }
+#undef WGB8X_CASE
     if (rc) return rc;
     return jvae_wgrad_slab_reduce(ws, dw, p.G, Ca, Cb, accumulate, swapflip, st, 1);
 }

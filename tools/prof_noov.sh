@@ -1,0 +1,11 @@
+# GPU box: rocprofv3 kernel stats of bench.py with the weight gradients on the MAIN stream (no overlap): every kernel's
+# stand-alone duration inside the real step.  usage: prof_noov.sh TAG [bench args]
+set -e
+TAG=$1; shift
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/$TAG
+rm -rf $O; mkdir -p $O
+rocprofv3 --output-format csv --kernel-trace --stats -d $O/trace -- python3 $R/tools/bench_no_overlap.py --steps 30 --warmup 5 "$@" > $O/bench.json 2> $O/bench.err
+find $O -name "*_kernel_trace.csv" -delete; find $O -name "*_agent_info.csv" -delete; find $O -name "*domain_stats.csv" -delete
+python3 $R/tools/step_stats.py $(find $O -name "*kernel_stats.csv") 35
