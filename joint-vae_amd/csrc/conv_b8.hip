@@ -379,7 +379,7 @@ int launch_b8(const B8FwdP& p, hipStream_t st) {
 bool jvae_conv5_b8_fwd_ok(int Cin, int H, int W, int Cout, int OH, int OW, int S, int P) {
     if (S != 1 && S != 2) return false;
     if (OH != OW || H != W || W != OW * S) return false;
-    if (S == 1 && OW != 8 && OW != 16 && OW != 32 && OW != 64) return false;
+    if (S == 1 && OW != 4 && OW != 8 && OW != 16 && OW != 32 && OW != 64) return false;
     if (S == 2 && OW != 8 && OW != 16 && OW != 32) return false;
     if (P < 0 || P > 4) return false;
     if ((OW - 1) * S + 4 - P >= W + 4) return false;
@@ -446,6 +446,7 @@ int jvae_conv5_b8_fwd(const void* in, const float* w, int swap, int flip, const 
     struct Fin { int* n; ~Fin() { if (n) *n = g_b8_splits; } } fin{nsplit};
     if (S == 1) {
         switch (OW) {
+            case 4: return launch_b8<1, 4, 1, 1>(p, st);      // 4x4 maps (deconv32+): 8 images per workgroup
             case 8: return launch_b8<1, 8, 2, 1>(p, st);
             case 16: return launch_b8<1, 16, 4, 1>(p, st);
             case 32: return launch_b8<1, 32, 4, 1>(p, st);

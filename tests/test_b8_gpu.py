@@ -106,6 +106,37 @@ def test_b8_conv_native_directions(cin, cout, k, s, p, op, tr, H, N):
     assert mask & expected == expected, (mask, expected)
 
 
+@pytest.mark.parametrize('N', [5, 16])
+def test_b8_conv_on_4x4_maps(N):
+    """The 128-channel 5x5 layer on the 4x4 maps of deconv32+ (config 5): forward and input gradient on the bf16 kernels
+    (8 images per workgroup); its weight gradient stays on the fp32 unfold + GEMM path."""
+    from jvae_hip import ops, ops_b8
+    cin = cout = 128
+    g = torch.Generator().manual_seed(4 + N)
+    x = rbf(torch.randn(N, cin, 4, 4, generator=g))
+    w = torch.randn(cin, cout, 5, 5, generator=g) / math.sqrt(cin * 25)
+    b = torch.randn(cout, generator=g)
+    wr = rbf(w)
+    spec = ops.ConvSpec(cin, cout, 5, 1, 2, 0, True)
+    mask = ops_b8.native_mask(spec, N, 4, 4)
+    assert mask & (ops_b8.FWD | ops_b8.DGRAD) == ops_b8.FWD | ops_b8.DGRAD
+    xr = x.clone().requires_grad_(True)
+    yr = F.conv_transpose2d(xr, wr, b, stride=1, padding=2)
+    xb = ops_b8.pack(x.to(DEV))
+    y32, st, ns = ops_b8.conv_fwd_raw(xb, w.to(DEV), b.to(DEV), spec, out_f32=True, want_stats=True)
+    assert rel(y32, yr) < 2e-5
+    part = st[:cout * ns * 2].view(cout, ns, 2).double().sum(1).cpu()
+    d = (yr.detach() - b.view(1, -1, 1, 1)).double()
+    assert torch.allclose(part[:, 0], d.sum((0, 2, 3)), rtol=1e-4, atol=1e-3 * float(d.abs().sum((0, 2, 3)).max()))
+    assert torch.allclose(part[:, 1], (d * d).sum((0, 2, 3)), rtol=1e-4)
+    yb, _, _ = ops_b8.conv_fwd_raw(xb, w.to(DEV), b.to(DEV), spec, want_stats=True)
+    assert rel(ops_b8.unpack(yb, cout), yr) < BF_TOL
+    gy = rbf(torch.randn(yr.shape, generator=g))
+    yr.backward(gy)
+    gx = ops_b8.conv_dgrad_raw(ops_b8.pack(gy.to(DEV)), w.to(DEV), spec, N, 4, 4)
+    assert rel(ops_b8.unpack(gx, cin), xr.grad) < BF_TOL
+
+
 @pytest.mark.parametrize('N,C,H,relu', [(4, 32, 16, True), (3, 20, 8, True), (6, 64, 8, False), (2, 3, 32, True)])
 def test_b8_batchnorm(N, C, H, relu):
     """BatchNorm(+ReLU) on B8 vs torch on the bf16-rounded input; outputs are bf16 (2^-8 of scale), statistics fp32."""
