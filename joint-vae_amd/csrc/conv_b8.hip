@@ -380,7 +380,7 @@ bool jvae_conv5_b8_fwd_ok(int Cin, int H, int W, int Cout, int OH, int OW, int S
     if (S != 1 && S != 2) return false;
     if (OH != OW || H != W || W != OW * S) return false;
     if (S == 1 && OW != 4 && OW != 8 && OW != 16 && OW != 32 && OW != 64) return false;
-    if (S == 2 && OW != 8 && OW != 16 && OW != 32) return false;
+    if (S == 2 && OW != 4 && OW != 8 && OW != 16 && OW != 32) return false;
     if (P < 0 || P > 4) return false;
     if ((OW - 1) * S + 4 - P >= W + 4) return false;
     return Cin >= 1 && Cout >= 1;
@@ -454,6 +454,7 @@ int jvae_conv5_b8_fwd(const void* in, const float* w, int swap, int flip, const 
         }
     } else {
         switch (OW) {
+            case 4: return launch_b8<2, 4, 1, 1>(p, st);
             case 8: return launch_b8<2, 8, 1, 1>(p, st);
             case 16: return launch_b8<2, 16, 2, 1>(p, st);
             case 32: return launch_b8<2, 32, 2, 1>(p, st);

@@ -230,7 +230,7 @@ int launch_t2b8(const T2B8P& p, hipStream_t st) {
 bool jvae_convt2_b8_ok(int C, int HS, int WS, int O, int HB, int WB, int KH, int KW, int S, int P) {
     if (KH != 5 || KW != 5 || S != 2 || P != 2) return false;
     if (HS != WS || HB != 2 * HS || WB != 2 * WS) return false;
-    if (WS != 8 && WS != 16 && WS != 32) return false;
+    if (WS != 4 && WS != 8 && WS != 16 && WS != 32) return false;
     return O >= 1 && C >= 1;
 }
 
@@ -243,6 +243,7 @@ int jvae_convt2_b8(const void* in, const float* w, const float* bias, void* out,
             aff ? *aff : InAff{nullptr, nullptr, 0}};
     struct Fin { int* n; ~Fin() { if (n) *n = g_t2b8_splits; } } fin{nsplit};
     switch (WS) {
+        case 4: return launch_t2b8<4, 4>(p, st);         // 4x4 -> 8x8 (deconv32+): 8 images per workgroup
         case 8: return launch_t2b8<8, 4>(p, st);
         case 16: return launch_t2b8<16, 4>(p, st);
         case 32: return launch_t2b8<32, 4>(p, st);

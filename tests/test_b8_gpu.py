@@ -137,6 +137,36 @@ def test_b8_conv_on_4x4_maps(N):
     assert rel(ops_b8.unpack(gx, cin), xr.grad) < BF_TOL
 
 
+@pytest.mark.parametrize('N', [5, 16])
+def test_b8_transposed_stride2_from_4x4_maps(N):
+    """ConvTranspose2d 128 -> 128, 5x5 stride 2, 4x4 -> 8x8 (deconv32+ layer 2): forward on the 4-phase bf16 kernel, input
+    gradient on the stride-2 forward-type bf16 kernel (8 images per workgroup each)."""
+    from jvae_hip import ops, ops_b8
+    cin = cout = 128
+    g = torch.Generator().manual_seed(40 + N)
+    x = rbf(torch.randn(N, cin, 4, 4, generator=g))
+    w = torch.randn(cin, cout, 5, 5, generator=g) / math.sqrt(cin * 25)
+    b = torch.randn(cout, generator=g)
+    wr = rbf(w)
+    spec = ops.ConvSpec(cin, cout, 5, 2, 2, 1, True)
+    mask = ops_b8.native_mask(spec, N, 4, 4)
+    assert mask & (ops_b8.FWD | ops_b8.DGRAD) == ops_b8.FWD | ops_b8.DGRAD
+    xr = x.clone().requires_grad_(True)
+    yr = F.conv_transpose2d(xr, wr, b, stride=2, padding=2, output_padding=1)
+    xb = ops_b8.pack(x.to(DEV))
+    yb, st, ns = ops_b8.conv_fwd_raw(xb, w.to(DEV), b.to(DEV), spec, want_stats=True)
+    assert yb.shape == (N, cout // 8, 8, 8, 8)
+    assert rel(ops_b8.unpack(yb, cout), yr) < BF_TOL
+    part = st[:cout * ns * 2].view(cout, ns, 2).double().sum(1).cpu()
+    d = (yr.detach() - b.view(1, -1, 1, 1)).double()
+    assert torch.allclose(part[:, 0], d.sum((0, 2, 3)), rtol=1e-4, atol=1e-3 * float(d.abs().sum((0, 2, 3)).max()))
+    assert torch.allclose(part[:, 1], (d * d).sum((0, 2, 3)), rtol=1e-4)
+    gy = rbf(torch.randn(yr.shape, generator=g))
+    yr.backward(gy)
+    gx = ops_b8.conv_dgrad_raw(ops_b8.pack(gy.to(DEV)), w.to(DEV), spec, N, 4, 4)
+    assert rel(ops_b8.unpack(gx, cin), xr.grad) < BF_TOL
+
+
 @pytest.mark.parametrize('N,C,H,relu', [(4, 32, 16, True), (3, 20, 8, True), (6, 64, 8, False), (2, 3, 32, True)])
 def test_b8_batchnorm(N, C, H, relu):
     """BatchNorm(+ReLU) on B8 vs torch on the bf16-rounded input; outputs are bf16 (2^-8 of scale), statistics fp32."""
