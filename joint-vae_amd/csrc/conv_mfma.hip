@@ -213,23 +213,36 @@ __global__ __launch_bounds__(256, 2) void conv5_fwd_kernel(FwdP p) {
     }
 
     // ---- epilogue: D[i = channel][j = pixel]; lane holds pixel j = l31, rows i = (r&3) + 8*(r>>2) + 4*half
+    auto store_tile = [&](const float (&bv)[NT][16], bool biased) {
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const int pix = (wave * MT + mt) * 32 + l31;
-        const int im = pix / (G::TH * OW), rem = pix % (G::TH * OW);
-        const int n = img0 + im;
-        if (n >= p.N) continue;
-        const int oy = row0 + rem / OW, ox = rem % OW;
+        for (int mt = 0; mt < MT; ++mt) {
+            const int pix = (wave * MT + mt) * 32 + l31;
+            const int im = pix / (G::TH * OW), rem = pix % (G::TH * OW);
+            const int n = img0 + im;
+            if (n >= p.N) continue;
+            const int oy = row0 + rem / OW, ox = rem % OW;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int o = o0 + nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (o >= p.CoutReal) continue;
+                    p.out[(((long)n * p.CoutReal + o) * G::OH + oy) * OW + ox] = biased ? acc[nt][mt][r] + bv[nt][r] : acc[nt][mt][r];
+                }
+        }
+    };
+    float bv[NT][16];
+    if (p.bias) {           // the lane's bias values in one batch of loads, not one dependent load in front of every store
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int o = o0 + nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (o >= p.CoutReal) continue;
-                float v = acc[nt][mt][r];
-                if (p.bias) v += p.bias[o];
-                p.out[(((long)n * p.CoutReal + o) * G::OH + oy) * OW + ox] = v;
+                bv[nt][r] = o < p.CoutReal ? p.bias[o] : 0.f;
             }
+        store_tile(bv, true);
+    } else {
+        store_tile(bv, false);
     }
 }
 

@@ -288,7 +288,39 @@ __global__ __launch_bounds__(256, 2) void conv5_x3_kernel(X3P p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[b][r] += acs[b][r];
 
-    // ---- optional BatchNorm statistics of this workgroup's tile (the loop ended with a barrier: LDS is free)
+    // ---- epilogue: lane holds pixel l31 of each 32-pixel group, rows (channels) (r&3) + 8*(r>>2) + 4*half
+    auto store_tile = [&](const float (&bv)[16], bool biased) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int pix = (wave * MT + mt) * 32 + l31;
+            const int im = pix / (G::TH * OW), rem = pix % (G::TH * OW);
+            const int n = img0 + im;
+            if (n >= p.N) continue;
+            const int oy = row0 + rem / OW, ox = rem % OW;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = o0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (o >= p.CoutReal) continue;
+                p.out[(((long)n * p.CoutReal + o) * G::OH + oy) * OW + ox] = biased ? acc[mt][r] + bv[r] : acc[mt][r];
+            }
+        }
+    };
+    float bv[16];
+    if (p.bias) {
+        // the lane's 16 bias values in ONE batch of loads (a load in front of every store is a chain of 16 x MT dependent
+        // round trips per lane: 15 us of the 32-wide forward layer); the bias-free directions keep the plain stores
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int o = o0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            bv[r] = o < p.CoutReal ? p.bias[o] : 0.f;
+        }
+        store_tile(bv, true);
+    } else {
+        store_tile(bv, false);
+    }
+
+    // ---- optional BatchNorm statistics of this workgroup's tile (the loop ended with a barrier: LDS is free).  AFTER the
+    // output stores: they drain while the sums are reduced, and no wave waits at the reduction's barrier with its tile unsent
     if (p.stats) {
         float* red = reinterpret_cast<float*>(lds_raw);       // [4 waves][32][2]
         float sv[32];                                         // [sum | sum of squares][register row]
@@ -305,31 +337,13 @@ __global__ __launch_bounds__(256, 2) void conv5_x3_kernel(X3P p) {
             const int r = l31 & 15, ch = (r & 3) + 8 * (r >> 2) + 4 * half;
             red[(wave * 32 + ch) * 2 + (l31 >> 4)] = tot;
         }
-        __syncthreads();
+        lds_barrier();                                        // LDS only: the output stores keep draining
         if (tid < 32 && o0 + tid < p.CoutReal) {
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int w = 0; w < 4; ++w) { s1 += red[(w * 32 + tid) * 2]; s2 += red[(w * 32 + tid) * 2 + 1]; }
             float* dst = p.stats + ((long)(o0 + tid) * gridDim.x + blockIdx.x) * 2;
             dst[0] = s1; dst[1] = s2;
-        }
-    }
-
-    // ---- epilogue: lane holds pixel l31 of each 32-pixel group, rows (channels) (r&3) + 8*(r>>2) + 4*half
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const int pix = (wave * MT + mt) * 32 + l31;
-        const int im = pix / (G::TH * OW), rem = pix % (G::TH * OW);
-        const int n = img0 + im;
-        if (n >= p.N) continue;
-        const int oy = row0 + rem / OW, ox = rem % OW;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int o = o0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (o >= p.CoutReal) continue;
-            float v = acc[mt][r];
-            if (p.bias) v += p.bias[o];
-            p.out[(((long)n * p.CoutReal + o) * G::OH + oy) * OW + ox] = v;
         }
     }
 }
