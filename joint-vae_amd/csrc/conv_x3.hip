@@ -94,6 +94,9 @@ __global__ __launch_bounds__(256, 2) void conv5_x3_kernel(X3P p) {
     u32x4* Xs = reinterpret_cast<u32x4*>(lds_raw);            // [3 planes][XS]
     u32x4* Ws = Xs + 3 * G::XS;                                // [2 buffers][WGS]
     __shared__ float ctab[AFF ? 2 * 256 : 1];                 // (scale, shift) of all input channels (<= 256)
+    __shared__ float bias_s[32];                              // this workgroup's 32 bias values: fetched while the first patch
+                                                              // loads are in flight (a global load in the epilogue is an exposed
+                                                              // round trip per workgroup: 36 us of the 32-wide layer)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
@@ -104,6 +107,7 @@ __global__ __launch_bounds__(256, 2) void conv5_x3_kernel(X3P p) {
     const int KB = (p.Cin + 15) / 16;
     const int NG = KB * 5;                                     // weight groups: (K step, kernel row)
 
+    if (tid < 32) bias_s[tid] = (p.bias && o0 + tid < p.CoutReal) ? p.bias[o0 + tid] : 0.f;
     if (AFF)
         for (int i = tid; i < KB * 16; i += 256) {
             const bool ok = i < p.Cin;
@@ -307,13 +311,9 @@ __global__ __launch_bounds__(256, 2) void conv5_x3_kernel(X3P p) {
     };
     float bv[16];
     if (p.bias) {
-        // the lane's 16 bias values in ONE batch of loads (a load in front of every store is a chain of 16 x MT dependent
-        // round trips per lane: 15 us of the 32-wide forward layer); the bias-free directions keep the plain stores
+        // the lane's 16 bias values from LDS; the bias-free directions keep the plain stores
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int o = o0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            bv[r] = o < p.CoutReal ? p.bias[o] : 0.f;
-        }
+        for (int r = 0; r < 16; ++r) bv[r] = bias_s[(r & 3) + 8 * (r >> 2) + 4 * half];
         store_tile(bv, true);
     } else {
         store_tile(bv, false);

@@ -18,4 +18,5 @@ for (name, N, cin, cout, H) in (('D5', 1024, 32, 32, 32), ('D3', 1024, 64, 32, 1
     b = torch.zeros(cout, device='cuda'); y = ops.conv_fwd_raw(x, w, b, spec); gy = torch.randn_like(y)
     fl = 2.0 * x.numel() * cout * 25
     tf = timeit(lambda: ops.conv_fwd_stats_raw(x, w, b, spec)); td = timeit(lambda: ops.conv_dgrad_raw(gy, w, spec, x.shape))
-    print(f'JVAE_X3={os.environ.get("JVAE_X3", "1")} {name} fwd+stats {tf:6.1f} us {fl/tf/1e6:6.1f} TF | dgrad {td:6.1f} us {fl/td/1e6:6.1f} TF')
+    tp = timeit(lambda: ops.conv_fwd_raw(x, w, b, spec)); tn = timeit(lambda: ops.conv_fwd_raw(x, w, None, spec)); ts = timeit(lambda: ops.conv_fwd_stats_raw(x, w, None, spec))
+    print(f'JVAE_X3={os.environ.get("JVAE_X3", "1")} {name} fwd+stats {tf:6.1f} us {fl/tf/1e6:6.1f} TF | dgrad {td:6.1f} us {fl/td/1e6:6.1f} TF | fwd (bias, no stats) {tp:6.1f} us | fwd (no bias, no stats) {tn:6.1f} us | fwd (no bias, stats) {ts:6.1f} us')
