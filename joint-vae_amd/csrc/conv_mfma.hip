@@ -61,6 +61,7 @@ __global__ __launch_bounds__(256, 2) void conv5_fwd_kernel(FwdP p) {
     __shared__ __attribute__((aligned(16))) float lds[G::XS + G::WS];
     float* Xs = lds;
     float* Ws = lds + G::XS;
+    __shared__ float bias_s[G::WCOLS];                        // this workgroup's bias values, fetched at the start (conv_x3.hip)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
@@ -68,6 +69,7 @@ __global__ __launch_bounds__(256, 2) void conv5_fwd_kernel(FwdP p) {
     const int img0 = (G::OHW >= G::PIX) ? (int)(blockIdx.x / TILES_PER_IMG) : (int)blockIdx.x * G::NIMG;
     const int row0 = (G::OHW >= G::PIX) ? (int)(blockIdx.x % TILES_PER_IMG) * G::TH : 0;
     const int o0 = blockIdx.y * G::WCOLS;
+    if (tid < G::WCOLS) bias_s[tid] = (p.bias && o0 + tid < p.CoutReal) ? p.bias[o0 + tid] : 0.f;
 
     // ---- zero the whole patch once: halo columns / out-of-image rows / missing images stay zero for all chunks
     for (int i = tid; i < G::XS / 4; i += 256) reinterpret_cast<f32x4*>(Xs)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -237,8 +239,7 @@ __global__ __launch_bounds__(256, 2) void conv5_fwd_kernel(FwdP p) {
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int o = o0 + nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                bv[nt][r] = o < p.CoutReal ? p.bias[o] : 0.f;
+                bv[nt][r] = bias_s[nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half];
             }
         store_tile(bv, true);
     } else {

@@ -55,6 +55,7 @@ __global__ __launch_bounds__(256, 2) void convt2_x3_kernel(T2X3P p) {
     u32x4* Xs = reinterpret_cast<u32x4*>(lds_raw);            // [3 planes][XS]
     u32x4* Ws = Xs + 3 * G::XS;                                // [2 buffers][WGS]
     __shared__ float ctab[AFF ? 2 * 256 : 1];
+    __shared__ float bias_s[32];                               // this workgroup's bias values, fetched at the start (conv_x3.hip)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
@@ -64,6 +65,7 @@ __global__ __launch_bounds__(256, 2) void convt2_x3_kernel(T2X3P p) {
     const int o0 = blockIdx.y * 32;
     const int KB = (p.C + 15) / 16;
     const int OP = p.O;                                        // multiple of 32 (jvae_convt2_ok)
+    if (tid < 32) bias_s[tid] = p.bias ? p.bias[o0 + tid] : 0.f;   // visible after the first barrier of the K loop
 
     if (AFF)
         for (int i = tid; i < KB * 16; i += 256) {
@@ -258,7 +260,7 @@ __global__ __launch_bounds__(256, 2) void convt2_x3_kernel(T2X3P p) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int o = o0 + (e & 3) + 8 * (e >> 2) + 4 * half;
-        const float bv = p.bias ? p.bias[o] : 0.f;
+        const float bv = bias_s[o - o0];
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             float2 v = make_float2(acc[r][0][e] + bv, acc[r][1][e] + bv);
