@@ -10,7 +10,7 @@ clip -> Adam — executed by hand-written gfx950 HIP kernels (libjvae_hip.so) be
     .train_model(...)   (hot loop :2424-2479; test / OOD phases are out of scope)                            :2081-2547
     .train() / .to() / .save() / .load() / .latent_sampling / .device / .nparams
 
-What is NOT rebuilt here (raises NotImplementedError when asked for): type 'vib' (cvae / xvae / vae are complete, jvae: training and labelled evaluation only); resnet
+What is NOT rebuilt here (raises NotImplementedError when asked for): (cvae / xvae / vae / vib are complete, jvae: training and labelled evaluation only); resnet
 feature stacks (torchvision); coded, per-dimension or rmse sigma; the categorical output MODE (the loss
 function exists); the accuracy / misclassification phases of train_model.  Pooling / up-sampling layer tokens, SGD,
 the `y=None` all-class evaluation with its OOD scores and the WIM fine-tuning step are built.
@@ -49,8 +49,9 @@ class Measures(dict):
 
     _KEYS = ('sigma', 'xpow', 'mse', 'rmse', 'dB', 'zdist', 'var_kl')
 
-    def __init__(self, dev, has_dictionary, on_nan, from_main=False):
+    def __init__(self, dev, has_dictionary, on_nan, from_main=False, only=None):
         super().__init__()
+        self._only = only                                # type 'vib': ('sigma', 'zdist', 'var_kl') - nothing is reconstructed
         from jvae_hip import lib as _lib
         self._dev = dev
         self._host = torch.empty(16, dtype=torch.float32, pin_memory=True)
@@ -77,6 +78,9 @@ class Measures(dict):
                            'var_kl': h[15]})
         if self._has_dictionary:
             dict.update(self, {'ld-norm': h[6], 'imut-zy': h[7], 'd-mind': h[8]})
+        if self._only is not None:
+            for k in [k for k in dict.keys(self) if k not in self._only]:
+                dict.__delitem__(self, k)
 
     def __getitem__(self, k):
         self._fill()
@@ -174,18 +178,22 @@ class ClassificationVariationalNetwork(nn.Module):
                                          'sigma', 'wmse', 'z_logdet', 'z_tr_inv_cov'),
                                 'vae': ('cross_x', 'kl', 'zdist', 'var_kl', 'total', 'iws'),
                                 'jvae': ('cross_x', 'kl', 'cross_y', 'total'),
-                                'xvae': ('cross_x', 'kl', 'total', 'zdist', 'iws')}
-    predict_methods_per_type = {'cvae': ['iws', 'closest'], 'vae': [], 'jvae': ['loss', 'esty'], 'xvae': ['loss', 'closest']}
+                                'xvae': ('cross_x', 'kl', 'total', 'zdist', 'iws'),
+                                'vib': ('cross_y', 'kl', 'total')}
+    predict_methods_per_type = {'cvae': ['iws', 'closest'], 'vae': [], 'jvae': ['loss', 'esty'], 'xvae': ['loss', 'closest'],
+                                'vib': ['esty']}
     metrics_per_type = {'cvae': ['rmse', 'dB', 'd-mind', 'ld-norm', 'sigma'], 'vae': ['rmse', 'dB', 'sigma'],
-                        'jvae': ['rmse', 'dB', 'sigma'], 'xvae': ['rmse', 'dB', 'zdist', 'd-mind', 'ld-norm', 'sigma']}
+                        'jvae': ['rmse', 'dB', 'sigma'], 'xvae': ['rmse', 'dB', 'zdist', 'd-mind', 'ld-norm', 'sigma'],
+                        'vib': ['sigma']}
     ood_methods_per_type = {'cvae': ['iws-2s', 'iws-a-1-1', 'iws-a-4-1', 'iws', 'mse', 'elbo', 'soft',
                                      'elbo-2s', 'elbo-a-1-1', 'elbo-a-4-1', 'zdist'],
                             'vae': ['iws', 'iws-2s', 'iws-a-1-1', 'iws-a-4-1', 'elbo', 'elbo-2s', 'elbo-a-1-1',
                                     'elbo-a-4-1', 'zdist'],
-                            'jvae': ['max', 'sum', 'std'], 'xvae': ['max', 'mean', 'std']}
+                            'jvae': ['max', 'sum', 'std'], 'xvae': ['max', 'mean', 'std'],
+                            'vib': ['odin*', 'baseline', 'logits']}
     misclass_methods_per_type = {'cvae': ['softkl*', 'iws', 'softiws*', 'kl', 'max', 'zdist', 'softzdist*',
                                           'baseline*', 'hyz'],
-                                 'vae': [], 'jvae': [], 'xvae': []}
+                                 'vae': [], 'jvae': [], 'xvae': [], 'vib': ['odin*', 'baseline', 'logits', 'hyz']}
 
     def __init__(self, input_shape, num_labels, type='cvae', y_is_coded=False, output_distribution='gaussian',
                  job_number=0, features=None, pretrained_features=None, batch_norm=False, dropout=False,
@@ -195,10 +203,8 @@ class ClassificationVariationalNetwork(nn.Module):
                  encoder_forced_variance=False, output_activation=DEFAULT_OUTPUT_ACTIVATION, sigma={'value': 1},
                  optimizer={}, shadow=False, representation='rgb', version=VERSION, *args, **kw):
         super().__init__(*args, **kw)
-        if type not in ('cvae', 'vae', 'jvae', 'xvae'):
-            raise NotImplementedError("types 'cvae' / 'xvae' (class-conditional prior), 'vae' (single prior) and 'jvae' (labels "
-                                      "coded into the encoder, classifier on z) are built on the native kernels (got {!r})".format(type))
-        assert not (y_is_coded and type == 'vae')
+        assert type in ('jvae', 'cvae', 'xvae', 'vib', 'vae')
+        assert not (y_is_coded and type in ('vib', 'vae'))
         if output_distribution != 'gaussian':
             raise NotImplementedError('categorical output is outside the native-kernel contract')
         assert not upsampler or features, 'no upsampler without features'
@@ -206,8 +212,8 @@ class ClassificationVariationalNetwork(nn.Module):
         self.name = name
         self.job_number = job_number
         self.type = type
-        self.is_cvae, self.is_jvae, self.is_vib, self.is_vae, self.is_xvae = (type == 'cvae', type == 'jvae', False, type == 'vae',
-                                                                              type == 'xvae')
+        self.is_cvae, self.is_jvae, self.is_vib, self.is_vae, self.is_xvae = (type == 'cvae', type == 'jvae', type == 'vib',
+                                                                              type == 'vae', type == 'xvae')
         self.loss_components = self.loss_components_per_type[type]
         self.metrics = self.metrics_per_type[type]
         self.predict_methods = list(self.predict_methods_per_type[type])
@@ -215,9 +221,11 @@ class ClassificationVariationalNetwork(nn.Module):
         self.misclass_methods = list(self.misclass_methods_per_type[type])
         self.y_is_coded = y_is_coded
         self.y_is_decoded = gamma if (self.is_cvae or self.is_vae) else True      # cvae.py:196-199
-        self.x_is_generated = True
-        self.output_distribution = output_distribution
-        self.losses_might_be_computed_for_each_class = not self.is_vae      # cvae.py:205
+        self.x_is_generated = not self.is_vib                               # cvae.py:201: 'vib' has no decoder / imager
+        self.output_distribution = output_distribution if self.x_is_generated else None
+        self.losses_might_be_computed_for_each_class = not self.is_vae and not self.is_vib      # cvae.py:205
+        if not self.x_is_generated:
+            decoder, upsampler = [], None                                   # cvae.py:222-224
 
         if self.y_is_decoded:
             self.classifier_type = 'linear'
@@ -278,8 +286,10 @@ class ClassificationVariationalNetwork(nn.Module):
             if dropout:
                 dense.append(HipDropout(p=dropout))
             width = d
-        self.decoder = DenseStack(*dense)
-        if upsampler:
+        if not self.x_is_generated:
+            pass                                  # cvae.py:291: no `decoder` / `imager` modules (nor state_dict keys) at all
+        elif upsampler:
+            self.decoder = DenseStack(*dense)
             hw = find_input_shape(upsampler, input_shape[1:])
             cells = hw[0] * hw[1]
             assert not width % cells, 'Could not go from {} to *, {} {}'.format(width, *hw)
@@ -288,6 +298,7 @@ class ClassificationVariationalNetwork(nn.Module):
                                                output_distribution=self.output_distribution,
                                                pretrained_dict=pretrained_upsampler, where='output')
         else:
+            self.decoder = DenseStack(*dense)
             upsampler = None
             self.imager = DenseStack(HipLinear(width, int(np.prod(input_shape))),
                                      activation_layers[output_activation]())
@@ -324,7 +335,8 @@ class ClassificationVariationalNetwork(nn.Module):
         self.testing = {0: {m: {'n': 0, 'epochs': 0, 'accuracy': 0} for m in self.predict_methods}}
         self.ood_results = {}
         self.optimizer = Optimizer(self.parameters(), **optimizer)
-        self.optimizer.set_early_bucket(list(self.imager.parameters()) + list(self.decoder.parameters()))
+        if self.x_is_generated:
+            self.optimizer.set_early_bucket(list(self.imager.parameters()) + list(self.decoder.parameters()))
         self.training_parameters['optimizer'] = self.optimizer.params
         self.train_history = {'epochs': 0}
 
@@ -451,8 +463,10 @@ class ClassificationVariationalNetwork(nn.Module):
         logging.error('Error %s, net dumped in %s', str(err), where)
 
     def _decode(self, z):
-        u = self.decoder(z)
-        x_ = self.imager(u.reshape(-1, *self.imager.input_shape))
+        x_ = None
+        if self.x_is_generated:
+            u = self.decoder(z)
+            x_ = self.imager(u.reshape(-1, *self.imager.input_shape))
         if self.classifier_type in ('linear', None):
             logits = self.classifier(z)
         else:                                   # 'softmax': logits from the dictionary itself (cvae.py:498-499)
@@ -471,7 +485,7 @@ class ClassificationVariationalNetwork(nn.Module):
             self._dump_after_encoder_error(err, x, y)
             raise
         x_, logits = self._decode(z)
-        out = (x_.view(self.latent_sampling + 1, *lead, *self.input_shape), logits)
+        out = ((x,) if self.is_vib else (x_.view(self.latent_sampling + 1, *lead, *self.input_shape),)) + (logits,)   # cvae.py:504-508
         if z_output:
             out += (mu, log_var, z)
         if sampling_epsilon_norm_out:
@@ -489,7 +503,10 @@ class ClassificationVariationalNetwork(nn.Module):
         [, mu, log_var, z]).  `epsilon` (L+1,N,K) optionally injects the reparameterisation noise.
         All Python floats of `total_measures` come from ONE packed device read-back.
         """
-        if y is None:
+        if y is None or self.is_vib:
+            if self.is_vib:
+                return self._evaluate_vib(x, y, batch, current_measures, with_beta, kl_var_weighting, gamma_weighting,
+                                          z_output, epsilon, kw.get('_raw_measures'))
             return self._evaluate_all_classes(x, batch, current_measures, with_beta, z_output, epsilon)
         if x.dim() != self.input_dim + 1:
             x = x.reshape(-1, *self.input_shape)
@@ -551,6 +568,49 @@ class ClassificationVariationalNetwork(nn.Module):
             if self.training:
                 self.training_parameters['sigma'] = _LazySigmaParams(self.sigma, measures)
         out = (x_reco, logits[1:].mean(0), losses, measures)
+        if z_output:
+            out += (mu, log_var, z)
+        return out
+
+    # ------------------------------------------------------------------------------------ type 'vib'
+    def _evaluate_vib(self, x, y, batch, current_measures, with_beta, kl_var_weighting, gamma_weighting, z_output, epsilon,
+                      raw_measures=False):
+        """evaluate() of a model WITHOUT decoder (type 'vib': cvae.py:189,201,490-505,891-896): the loss is the classifier's
+        cross entropy on z plus beta x the KL to the single prior; the returned `reconstruction` is x itself.  With labels:
+        every loss (N,); without (the evaluation path): cross_y and total are (C, N) - one row per candidate class
+        (module/losses.py:47-86) - and the prediction is the classifier's ('esty')."""
+        if x.dim() != self.input_dim + 1:
+            x = x.reshape(-1, *self.input_shape)
+            y = None if y is None else y.reshape(-1)
+        N = x.shape[0]
+        cross_y_weight = gamma_weighting * self.gamma                                   # cvae.py:557-563: always in the loss
+        with torch.set_grad_enabled(torch.is_grad_enabled() and y is not None):
+            feats = self._features_of(x).reshape(N, -1)
+            dummy = y if y is not None else torch.zeros(N, dtype=torch.int64, device=x.device)
+            try:
+                mu, log_var, z, eps, _, terms = self.encoder.encode(feats, None, dummy, kl_var_weighting, epsilon)
+            except ValueError as err:
+                self._dump_after_encoder_error(err, x, y)
+                raise
+            _, logits = self._decode(z)
+            ce = x_loss(y, logits, batch_mean=False)                                     # (N,) or (C, N); all L+1 rows
+            beta = self.beta if with_beta else 1.
+            losses = {'kl': terms['kl'], 'zdist': terms['distance'], 'var_kl': terms['var_kl']}
+            total = beta * terms['kl']
+            if cross_y_weight:
+                total = total + cross_y_weight * ce                                     # broadcasts to (C, N) without labels
+            elif y is None:
+                total = total.unsqueeze(0).expand_as(ce)
+            losses['total'] = total
+            losses['cross_y'] = ce
+        prev = current_measures._dev if isinstance(current_measures, Measures) else self._upload_measures(
+            current_measures, x.device) if (current_measures and batch) else None
+        with torch.no_grad():
+            packed = self._pack_measures_raw(x, torch.zeros(N, device=x.device), terms, None, prev, batch, self.sigma.detach(),
+                                             int(self.sigma.is_log))
+        keys = ('sigma', 'zdist', 'var_kl')
+        measures = (packed, False) if raw_measures else Measures(packed, False, _grad_nan_exit, only=keys)
+        out = (x, logits[1:].mean(0), losses, measures)
         if z_output:
             out += (mu, log_var, z)
         return out

@@ -123,11 +123,19 @@ DSL_CASES['j2_n8_jvae'] = dict(net=_conv(10, type='jvae', y_is_coded=True, gamma
 DSL_CASES['x2_n8_xvae'] = dict(net=_conv(10, type='xvae', gamma=2.0, classifier=[20]), N=8, kl_var_weighting=1.0,
                                gamma_weighting=0.5)
 
+# type='vib' (no decoder: the classifier on z and the KL to a single prior are the whole loss; cvae.py:189,201,222-224,
+# 490-505,891-896): one training step
+DSL_CASES['b2_n8_vib'] = dict(net=_conv(10, type='vib', gamma=2.0, classifier=[20], upsampler=None,
+                                        prior=dict(distribution='gaussian', init_mean=0., var_dim='scalar')),
+                              N=8, kl_var_weighting=1.0, gamma_weighting=0.5)
+
 DSL_EVAL_CASES = {
     # NOT here: evaluate(x) without labels for models with CODED labels (jvae, y_is_coded).  The reference cannot run it:
     # cvae.py:593-600 builds the (C, N) label grid, cvae.py:451 then does y.view(N) on it -> "RuntimeError: shape '[N]' is
     # invalid for input of size C*N" (probed for conv and MLP models in the build container); the drop-in raises as well.
     'ex2_n8_xvae_L2': dict(net=_conv(10, type='xvae', gamma=2.0, classifier=[20], test_latent_sampling=2), N=8),
+    'eb2_n8_vib_L2': dict(net=_conv(10, type='vib', gamma=2.0, classifier=[20], upsampler=None, test_latent_sampling=2,
+                                    prior=dict(distribution='gaussian', init_mean=0., var_dim='scalar')), N=8),
     'ea2_n8_vae_L3': dict(net=_conv(10, type='vae', test_latent_sampling=3,
                                     prior=dict(distribution='gaussian', init_mean=0., var_dim='scalar')), N=8),
 }

@@ -225,7 +225,8 @@ def run_eval_case(Net, name):
     out['predict_methods'] = np.array(net.predict_methods)
     path = os.path.join(REPO, 'tests', 'golden', name + '.npz')
     np.savez_compressed(path, **out)
-    print(f'{name}: L={L} iws[:3]={out["loss.iws"].reshape(-1)[:3]} -> {path} ({os.path.getsize(path) / 1024:.0f} KiB)')
+    probe = 'loss.iws' if 'loss.iws' in out else 'loss.total'
+    print(f'{name}: L={L} {probe}[:3]={out[probe].reshape(-1)[:3]} -> {path} ({os.path.getsize(path) / 1024:.0f} KiB)')
 
 
 def run_wim_case(Net, name):
