@@ -11,8 +11,8 @@ clip -> Adam — executed by hand-written gfx950 HIP kernels (libjvae_hip.so) be
     .train() / .to() / .save() / .load() / .latent_sampling / .device / .nparams
 
 What is NOT rebuilt here (raises NotImplementedError when asked for): (cvae / xvae / vae / vib are complete, jvae: training and labelled evaluation only); resnet
-feature stacks (torchvision); coded, per-dimension or rmse sigma; the categorical output MODE (the loss
-function exists); the accuracy / misclassification phases of train_model.  Pooling / up-sampling layer tokens, SGD,
+feature stacks (torchvision); a per-dimension sigma (the reference fails on it too); label-free evaluation of a categorical
+(256-level) decoder - its training / labelled evaluation is built; the misclassification phases of train_model.  Pooling / up-sampling layer tokens, SGD,
 the `y=None` all-class evaluation with its OOD scores and the WIM fine-tuning step are built.
 There is no CPU path: calling forward/evaluate with CPU tensors raises.
 """
@@ -205,8 +205,7 @@ class ClassificationVariationalNetwork(nn.Module):
         super().__init__(*args, **kw)
         assert type in ('jvae', 'cvae', 'xvae', 'vib', 'vae')
         assert not (y_is_coded and type in ('vib', 'vae'))
-        if output_distribution != 'gaussian':
-            raise NotImplementedError('categorical output is outside the native-kernel contract')
+        assert output_distribution in ('gaussian', 'categorical')
         assert not upsampler or features, 'no upsampler without features'
 
         self.name = name
@@ -462,6 +461,10 @@ class ClassificationVariationalNetwork(nn.Module):
         torch.save(y, os.path.join(where, 'y.pt'))
         logging.error('Error %s, net dumped in %s', str(err), where)
 
+    def _reco_shape(self):
+        """Per-sample shape of the decoder output: the image, or (256, C, H, W) level logits for a categorical decoder."""
+        return self.input_shape if self.output_distribution != 'categorical' else (256, *self.input_shape)
+
     def _decode(self, z):
         x_ = None
         if self.x_is_generated:
@@ -485,7 +488,7 @@ class ClassificationVariationalNetwork(nn.Module):
             self._dump_after_encoder_error(err, x, y)
             raise
         x_, logits = self._decode(z)
-        out = ((x,) if self.is_vib else (x_.view(self.latent_sampling + 1, *lead, *self.input_shape),)) + (logits,)   # cvae.py:504-508
+        out = ((x,) if self.is_vib else (x_.view(self.latent_sampling + 1, *lead, *self._reco_shape()),)) + (logits,)   # cvae.py:504-508
         if z_output:
             out += (mu, log_var, z)
         if sampling_epsilon_norm_out:
@@ -533,15 +536,30 @@ class ClassificationVariationalNetwork(nn.Module):
             # data-parallel: the decoder's gradients are final once d(loss)/dz exists -> start their all-reduce there
             z.register_hook(self._early_reduce_hook)
         x_, logits = self._decode(z)
-        x_reco = x_.view(L + 1, N, *self.input_shape)
+        x_reco = x_.view(L + 1, N, *self._reco_shape())
 
         s, s_kind, sigma_rms = self._sigma_operand(sigma_coded, N)
-        wmse_s = ops.recon_wmse(x_reco, x, s, s_kind, snapshot=bool(self.training and self.sigma.decay))     # (L, N)
         ce = None
         if self.y_is_decoded:
             ce = x_loss(y, logits, batch_mean=False)                         # all L+1 rows, as cvae.py:738 does
-        wmse, cross_x, total, mse = ops.elbo(wmse_s, terms['kl'], ce if cross_y_weight else None, s, s_kind, D,
-                                             self.beta if with_beta else 1., float(cross_y_weight or 0.), with_mse=True)
+        if self.output_distribution == 'categorical':
+            # cvae.py:654-660,752-753: -log p(x|z) is the 256-level cross entropy of every pixel, summed over the image (the
+            # only term with a gradient); `wmse` is the plain mean-square error of the arg-max image (reported, sigma not
+            # applied: the `catgorical` test at cvae.py:638 never matches), `mse` = wmse * sigma^2 as for a gaussian decoder
+            ndim = len(self.input_shape)
+            ce_x = categorical_loss(x_reco[1:], x, ndim=ndim, batch_mean=False)                       # (L, N)
+            with torch.no_grad():
+                levels = x_reco[1:].argmax(-ndim - 1).float() / 255
+                wmse = mse_loss(levels, x, ndim=ndim, batch_mean=False).mean(0)
+                mse = None
+            cross_x = ce_x.mean(0)
+            total = cross_x + (self.beta if with_beta else 1.) * terms['kl']
+            if cross_y_weight:
+                total = total + cross_y_weight * ce
+        else:
+            wmse_s = ops.recon_wmse(x_reco, x, s, s_kind, snapshot=bool(self.training and self.sigma.decay))     # (L, N)
+            wmse, cross_x, total, mse = ops.elbo(wmse_s, terms['kl'], ce if cross_y_weight else None, s, s_kind, D,
+                                                 self.beta if with_beta else 1., float(cross_y_weight or 0.), with_mse=True)
         losses = {'kl': terms['kl'], 'zdist': terms['distance'], 'var_kl': terms['var_kl']}
         dictionary = self.encoder.prior.mean if self.encoder.prior.conditional else None
         if dictionary is not None:
@@ -638,13 +656,26 @@ class ClassificationVariationalNetwork(nn.Module):
             dummy = torch.zeros(N, dtype=torch.int64, device=x.device)
             mu, log_var, z, eps, sigma_coded, _ = self.encoder.encode(feats, None, dummy, 1., epsilon)
             x_, logits = self._decode(z)
-            x_reco = x_.view(L + 1, N, *self.input_shape)
+            x_reco = x_.view(L + 1, N, *self._reco_shape())
             s, s_kind, sigma_rms = self._sigma_operand(sigma_coded, N)
-            wmse_s = ops.recon_wmse(x_reco, x, s, s_kind)                                 # (L, N)
+            categorical = self.output_distribution == 'categorical'
+            if categorical:
+                # cvae.py:654-660,672-676: log p(x|z_l) = -(256-level pixel cross entropy); the kernels below take it as the
+                # equivalent "weighted mse" of a unit-sigma gaussian: -D/2 (w + log 2 pi) = -ce  <=>  w = 2 ce / D - log 2 pi
+                ndim = len(self.input_shape)
+                ce_x = categorical_loss(x_reco[1:], x, ndim=ndim, batch_mean=False)          # (L, N)
+                levels = x_reco[1:].argmax(-ndim - 1).float() / 255
+                wmse_cat = mse_loss(levels, x, ndim=ndim, batch_mean=False).mean(0)
+                wmse_s = 2. * ce_x / D - LOG2PI
+                s_report, s, s_kind = s, torch.ones(1, device=x.device), ops.SIGMA_VALUE
+            else:
+                wmse_s = ops.recon_wmse(x_reco, x, s, s_kind)                             # (L, N)
             y_all = torch.arange(C, device=x.device).unsqueeze(1).expand(C, N)
             kd = pr.kl(mu, log_var, y=y_all if pr.conditional else None)                  # (C, N) each
             zero_kl = torch.zeros(N, device=x.device)
             wmse, cross_x, _, mse = ops.elbo(wmse_s, zero_kl, None, s, s_kind, D, 1., 0., with_mse=True)
+            if categorical:
+                wmse, mse = wmse_cat, None             # what the reference reports: the arg-max image's mean-square error
             losses = {'kl': kd['kl'], 'zdist': kd['distance'], 'var_kl': kd['var_kl']}
             dictionary = pr.mean if pr.conditional else None
             terms = {'distance': kd['distance'].reshape(-1), 'var_kl': kd['var_kl'].reshape(-1)}
@@ -671,7 +702,8 @@ class ClassificationVariationalNetwork(nn.Module):
             # rows + max / mean-exp fold over the L samples in one kernel pair (jvae_iws_f32)
             losses['iws'] = ops.iws(wmse_s, eps, log_var, log_pz, s, s_kind, D)
             prev = current_measures._dev if isinstance(current_measures, Measures) else None
-            packed = self._pack_measures(x, wmse, terms, dictionary, prev, batch, mse=mse, sigma_rms=sigma_rms, sigma_t=s)
+            packed = self._pack_measures(x, wmse, terms, dictionary, prev, batch, mse=mse, sigma_rms=sigma_rms,
+                                         sigma_t=s_report if categorical else s)
         measures = Measures(packed, dictionary is not None, _grad_nan_exit)
         out = (x_reco, logits[1:].mean(0), losses, measures)
         if z_output:

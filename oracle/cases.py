@@ -129,6 +129,11 @@ DSL_CASES['b2_n8_vib'] = dict(net=_conv(10, type='vib', gamma=2.0, classifier=[2
                                         prior=dict(distribution='gaussian', init_mean=0., var_dim='scalar')),
                               N=8, kl_var_weighting=1.0, gamma_weighting=0.5)
 
+# output_distribution='categorical': the decoder ends in 256 x C channels of level logits (conv.py:180-185,228-230), -log p(x|z)
+# is the per-pixel 256-way cross entropy (cvae.py:654-660,752-753)
+DSL_CASES['g2_n4_categorical'] = dict(net=_conv(10, output_distribution='categorical', sigma={'value': 1.0}), N=4,
+                                      kl_var_weighting=1.0, gamma_weighting=1.0)
+
 DSL_EVAL_CASES = {
     # NOT here: evaluate(x) without labels for models with CODED labels (jvae, y_is_coded).  The reference cannot run it:
     # cvae.py:593-600 builds the (C, N) label grid, cvae.py:451 then does y.view(N) on it -> "RuntimeError: shape '[N]' is
@@ -136,6 +141,8 @@ DSL_EVAL_CASES = {
     'ex2_n8_xvae_L2': dict(net=_conv(10, type='xvae', gamma=2.0, classifier=[20], test_latent_sampling=2), N=8),
     'eb2_n8_vib_L2': dict(net=_conv(10, type='vib', gamma=2.0, classifier=[20], upsampler=None, test_latent_sampling=2,
                                     prior=dict(distribution='gaussian', init_mean=0., var_dim='scalar')), N=8),
+    'eg2_n4_categorical_L2': dict(net=_conv(10, output_distribution='categorical', sigma={'value': 1.0}, test_latent_sampling=2),
+                                  N=4),
     'ea2_n8_vae_L3': dict(net=_conv(10, type='vae', test_latent_sampling=3,
                                     prior=dict(distribution='gaussian', init_mean=0., var_dim='scalar')), N=8),
 }

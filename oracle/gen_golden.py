@@ -104,8 +104,9 @@ def run_case(Net, name, compact=False):
         x_reco, y_est, losses, measures, mu, log_var, z = net.evaluate(
             x, y, batch=0, with_beta=True, kl_var_weighting=case['kl_var_weighting'],
             gamma_weighting=case['gamma_weighting'], current_measures=None, z_output=True)
-    if compact:
-        # per-image mean and L2 norm of the reconstruction instead of the (L+1, N, C, H, W) tensor itself
+    if compact or x_reco.numel() > (1 << 20):
+        # per-image mean and L2 norm of the reconstruction instead of the (L+1, N, C, H, W) tensor itself (also for the
+        # (L+1, N, 256, C, H, W) level logits of a categorical decoder: 25 MB at N = 4)
         xr = x_reco.detach().double().flatten(2)
         out['x_reco_mean'] = xr.mean(-1).numpy()
         out['x_reco_norm'] = xr.norm(dim=-1).numpy()
@@ -204,7 +205,7 @@ def run_eval_case(Net, name):
     with torch.no_grad(), inject_eps(eps):
         x_reco, y_est, losses, measures = net.evaluate(x, batch=0)
     out['L'] = np.int64(L)
-    if L >= 8:                                # compact: per-image mean / norm of the (L+1, N, ...) reconstruction
+    if L >= 8 or x_reco.numel() > (1 << 20):   # compact: per-image mean / norm of the (L+1, N, ...) reconstruction
         xr = x_reco.double().flatten(2)
         out['x_reco_mean'] = xr.mean(-1).numpy()
         out['x_reco_norm'] = xr.norm(dim=-1).numpy()
