@@ -173,7 +173,8 @@ class Optimizer:
         """(group, lo, hi) of the contiguous flat range holding the early-bucket parameters, or None."""
         ids = {id(p) for p in getattr(self, '_early', [])}
         if not ids or len(self._groups) != 1:
-            if ids and self._world > 1 and not getattr(self, '_early_warned', False):
+            # no group yet = the first step of a model (the flat buffer is built from the first gradients): not worth a warning
+            if ids and self._world > 1 and len(self._groups) > 1 and not getattr(self, '_early_warned', False):
                 self._early_warned = True
                 logging.warning('data-parallel: %d flat gradient groups - the early (decoder) bucket is not overlapped',
                                 len(self._groups))
