@@ -8,8 +8,9 @@ libjvae_hip.so instead of ATen/MIOpen.
 
 DSL recap (conv-models.ini): `[defaults]tok-tok-...`; a token is `C x K + P : S` (channels, kernel,
 padding, stride), upsamplers add `++OP` (output padding) and `!C...` (a plain convolution inside a
-transposed stack).  Pooling (`M`/`A`) and nearest up-sampling (`U`) tokens parse, but building them raises:
-they are outside this build's native-kernel contract.
+transposed stack).  Pooling (`M`/`A`) and nearest up-sampling (`U`) tokens build HipPool2d / HipUpsamplingNearest2d
+(pool.hip); an `output_distribution='categorical'` decoder ends in 256 x C channels + Reshape (reference lines 180-185,
+228-230).  torchvision resnet* / densenet* feature extractors (pretrained downloads) raise.
 """
 import configparser
 import logging
