@@ -62,7 +62,13 @@ struct WgX3Geom {
     // layout put all blocks on the same banks: 4-way conflicts, LDS-bound; profiles/r02_wgrad_x3_pmc_v1.json).
     static constexpr int WP = (WS - 1) * S + 5;
     static constexpr int WPH = (WP + 1) / 2;
-    static constexpr int WPS = S == 1 ? WP : 2 * WPH;          // slots per row
+    // One-plane form (bf16 operands): each fragment read feeds 2 MFMAs instead of 12, so the LDS - not the matrix pipe - is the
+    // limit, and the 2-way conflict of the transposed reads counts (profiles/r02_wgrad_b8_pmc_v1.json: conflict ratio 0.58, MFMA
+    // busy 35 %): the two 16-lane groups of a 32-lane access read pixels 8 slots apart = the same banks.  SWZ swaps the two
+    // 32-byte halves of a slot (blocks {0,1} <-> {2,3}) in slots whose index has bit 3 set, for Q and for Ps; with the row
+    // pitch a multiple of 16 slots that bit is a constant of the LANE (its 16-lane group), whatever the tap, tile or K step.
+    static constexpr bool SWZ = NPL == 1 && MODE == 0 && S == 1 && WS >= 16;
+    static constexpr int WPS = SWZ ? (WP + 15) / 16 * 16 : (S == 1 ? WP : 2 * WPH);          // slots per row
     static constexpr int CH = ROWS * WPS;                      // slots per plane
     static constexpr int NCBQ = MODE == 0 ? 4 : (MODE == 2 ? 2 : 1);   // 8-channel blocks of Q staged per item
     static constexpr int QS = NCBQ * CH;                       // units per plane
@@ -81,6 +87,13 @@ template <int HI>
 __device__ __forceinline__ bf16x8 tr_pair(const unsigned char* base, int off) {
     const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(base + off));
     const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(base + off + HI));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// the same with an explicit address for the second group of 4 pixels (swizzled image: its half may differ)
+__device__ __forceinline__ bf16x8 tr_pair2(const unsigned char* base, int off_lo, int off_hi) {
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(base + off_lo));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(base + off_hi));
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
@@ -148,6 +161,7 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_x3_kernel(WgX3P p) {
     const int aoff16 = (pl16 * 4 + (pp >> 1)) * 16 + (pp & 1) * 8;        // + rb * 32 bytes
     const int lane_pix16 = (pl16 / WS) * S * G::WPS + (pl16 % WS);
     int boff16[SH16 ? G::NBT : 1][MODE == 0 ? 1 : 2];      // MODE 0: the second column block is 2 units (32 bytes) further
+    int boffh[G::SWZ ? G::NBT : 1], steph[G::SWZ ? G::NBT : 1];   // swizzled image: the read of the lane's second 4 pixels
     if (SH16) {
 #pragma unroll
         for (int t = 0; t < G::NBT; ++t)
@@ -161,9 +175,21 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_x3_kernel(WgX3P p) {
                 if (tap > 24) tap = 24;
                 const int kw = tap % 5;
                 const int tslot = S == 1 ? kw : (kw & 1) * G::WPH + (kw >> 1);
-                boff16[t][cb] = ((lane_pix16 + (tap / 5) * G::WPS + tslot) * G::NCBQ + blk) * 16 + (pp & 1) * 8;
+                const int slot = lane_pix16 + (tap / 5) * G::WPS + tslot;
+                if (G::SWZ) {
+                    // bit 3 of the slot index: g16 & 1 for the lane's first 4 pixels (q4 + kw <= 7: no carry), possibly flipped
+                    // for the second 4 (slot + 4); everything else in the index is a multiple of 16
+                    const int bl = g16 & 1, bh = ((g16 & 1) * 8 + q4 + kw + 4) >> 3 & 1;
+                    boff16[t][cb] = (slot * G::NCBQ + (blk ^ (bl << 1))) * 16 + (pp & 1) * 8;
+                    boffh[t] = ((slot + 4) * G::NCBQ + (blk ^ (bh << 1))) * 16 + (pp & 1) * 8;
+                    steph[t] = bh ? -32 : 32;
+                } else {
+                    boff16[t][cb] = (slot * G::NCBQ + blk) * 16 + (pp & 1) * 8;
+                }
             }
     }
+    const int cbstep = (G::SWZ && (g16 & 1)) ? -32 : 32;       // MODE 0: byte distance of the second column block
+    const int aswz = (G::SWZ && (g16 & 1)) ? 32 : 0;           // Ps: row block rb sits at (rb ^ bit) * 32 bytes
 
     f32x16 acc[SH16 ? 1 : G::NBT];
     f32x4 acc16[SH16 ? G::NBT : 1][2][2];
@@ -203,10 +229,10 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_x3_kernel(WgX3P p) {
         const int in_row0 = row0 * S - p.P;
         if constexpr (NPL == 1) {
 #pragma unroll
-            for (int k = 0; k < QU8; ++k) {                    // x fastest: 16 * WB contiguous bytes per row
-                const int u = tid + k * 256;
-                const int x = u % G::WB, t = u / G::WB;
-                const int lr = t % G::ROWS, c = t / G::ROWS;
+            for (int k = 0; k < QU8; ++k) {                    // channel block fastest: adjacent lanes -> adjacent LDS units
+                const int u = tid + k * 256;                   // (x fastest makes the 16-byte LDS stores 4-way conflicted)
+                const int c = u % G::NCBQ, x = (u / G::NCBQ) % G::WB;
+                const int lr = u / (G::NCBQ * G::WB);
                 const int ir = in_row0 + lr, cb = cbq0 + c;
                 const bool ok = u < G::QUNITS && ir >= 0 && ir < HB && cb < CBb;
                 rq8[k] = ok ? q8[(((long)n * CBb + cb) * HB + ir) * G::WB + x] : q8[0];     // stand-in address: zeroed in lstore
@@ -214,7 +240,7 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_x3_kernel(WgX3P p) {
 #pragma unroll
             for (int k = 0; k < PU8; ++k) {
                 const int u = tid + k * 256;
-                const int px = u % G::TPIX, c = u / G::TPIX;
+                const int c = u % 4, px = u / 4;
                 const int cb = (a0 >> 3) + c;
                 const bool ok = u < G::PUNITS && cb < CBa;
                 rp8[k] = ok ? ps8[(((long)n * CBa + cb) * G::HS + row0) * WS + px] : ps8[0];
@@ -278,27 +304,28 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_x3_kernel(WgX3P p) {
             for (int k = 0; k < QU8; ++k) {
                 const int u = tid + k * 256;
                 if (u < G::QUNITS) {
-                    const int x = u % G::WB, t = u / G::WB;
-                    const int lr = t % G::ROWS, c = t / G::ROWS;
+                    const int c = u % G::NCBQ, x = (u / G::NCBQ) % G::WB;
+                    const int lr = u / (G::NCBQ * G::WB);
                     const int ir = in_row0 + lr;
                     const bool live = ir >= 0 && ir < HB && cbq0 + c < CBb;      // padding rows / missing blocks: exact zeros
                     u32x4 v = live ? rq8[k] : u32x4{0u, 0u, 0u, 0u};
                     if (AFF && p.aff_q.sc && live) v = aff8(v, &ctab[c * 8], &ctab[NT8 + c * 8], p.aff_q.relu);
                     const int c0 = p.P + x;
                     const int sl = S == 1 ? c0 : (c0 & 1) * G::WPH + (c0 >> 1);
-                    Qs[(lr * G::WPS + sl) * G::NCBQ + c] = v;
+                    const int slot = lr * G::WPS + sl;
+                    Qs[slot * G::NCBQ + (G::SWZ ? c ^ ((slot >> 3 & 1) << 1) : c)] = v;
                 }
             }
 #pragma unroll
             for (int k = 0; k < PU8; ++k) {
                 const int u = tid + k * 256;
                 if (u < G::PUNITS) {
-                    const int px = u % G::TPIX, c = u / G::TPIX;
+                    const int c = u % 4, px = u / 4;
                     const bool live = (a0 >> 3) + c < CBa;
                     u32x4 v = live ? rp8[k] : u32x4{0u, 0u, 0u, 0u};
                     if (AFF && p.aff_p.sc && live)
                         v = aff8(v, &ctab[(G::NCBQ + c) * 8], &ctab[NT8 + (G::NCBQ + c) * 8], p.aff_p.relu);
-                    Pt[px * 4 + c] = v;
+                    Pt[px * 4 + (G::SWZ ? c ^ ((px >> 3 & 1) << 1) : c)] = v;
                 }
             }
             return;
@@ -346,15 +373,20 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_x3_kernel(WgX3P p) {
                 for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
                     for (int plane = 0; plane < NPL; ++plane)
-                        a[rb][plane] = tr_pair<256>(Pb + plane * G::PS * 16, aoff16 + rb * 32 + ks * 32 * 64);
+                        a[rb][plane] = tr_pair<256>(Pb + plane * G::PS * 16, aoff16 + (rb * 32 ^ aswz) + ks * 32 * 64);
             };
             auto read_b = [&](int ks, int slot, bf16x8 (&d)[NPL]) {
                 const int pix0 = ks * 32;
                 const int qoff = ((pix0 / WS) * S * G::WPS + (pix0 % WS)) * G::NCBQ * 16;
 #pragma unroll
-                for (int plane = 0; plane < NPL; ++plane)
-                    d[plane] = tr_pair<64 * G::NCBQ>(Qb + plane * G::QS * 16,
-                                                     (MODE == 0 ? boff16[slot >> 1][0] + (slot & 1) * 32 : boff16[slot >> 1][slot & 1]) + qoff);
+                for (int plane = 0; plane < NPL; ++plane) {
+                    if constexpr (G::SWZ)
+                        d[plane] = tr_pair2(Qb + plane * G::QS * 16, boff16[slot >> 1][0] + (slot & 1) * cbstep + qoff,
+                                            boffh[slot >> 1] + (slot & 1) * steph[slot >> 1] + qoff);
+                    else
+                        d[plane] = tr_pair<64 * G::NCBQ>(Qb + plane * G::QS * 16,
+                                                         (MODE == 0 ? boff16[slot >> 1][0] + (slot & 1) * cbstep : boff16[slot >> 1][slot & 1]) + qoff);
+                }
             };
             read_a(0);
             read_b(0, 0, b[0]);
