@@ -116,6 +116,42 @@ def dominant_kernel_roofline(device, reps=20):
             'bf16_mfma_achieved': X3_PRODUCTS * flops / sec / 1e12, 'vs_f32_mfma_peak': flops / sec / MFMA_F32_PEAK}
 
 
+def wgrad_kernel_roofline(device, reps=20):
+    """The second MFMA-bound family of the step: the weight gradient of the same layer (imager.15, 53.69 GFLOP) on
+    conv5_wgrad_x3_kernel + its slab fold, launched through the C ABI as the step launches it (deferred BatchNorm on the layer
+    input, accumulation into an existing gradient), timed with HIP events on the launch stream.  Same peak definition as
+    `roofline`; HBM traffic from profiles/r02_wgrad_x3_pmc.json (committed rocprofv3 --pmc passes, not this run)."""
+    from jvae_hip import ops
+    N, C, H = 2 * BATCH_PER_GPU, 32, 32
+    spec = ops.ConvSpec(C, C, 5, 1, 2, 0, transposed=True)
+    x = torch.randn(N, C, H, H, device=device)
+    gy = torch.randn(N, C, H, H, device=device)
+    gw = torch.zeros(C, C, 5, 5, device=device)
+    aff = (torch.rand(C, device=device) + 0.5, torch.randn(C, device=device) * 0.1, True)
+    for _ in range(3):
+        ops.conv_wgrad_raw(x, gy, spec, gw.shape, False, gw, None, aff)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        ops.conv_wgrad_raw(x, gy, spec, gw.shape, False, gw, None, aff)
+    e1.record()
+    torch.cuda.synchronize()
+    sec = e0.elapsed_time(e1) * 1e-3 / reps
+    flops = 2.0 * N * H * H * C * C * 25
+    peak = MFMA_BF16_PEAK / X3_PRODUCTS
+    traffic, src = None, None
+    pmc = os.path.join(REPO, 'profiles', 'r02_wgrad_x3_pmc.json')
+    if os.path.exists(pmc):
+        d = json.load(open(pmc))
+        traffic = ((d.get('hbm_read_bytes') or 0) + (d.get('hbm_write_bytes') or 0)) or None
+        src = 'profiles/r02_wgrad_x3_pmc.json (committed file, not this run)'
+    return {'bound': 'mfma', 'kernel': 'conv5_wgrad_x3_kernel<1,32,0,aff,16x16x32> + wgrad_reduce4_kernel: imager.15 weight gradient '
+                                       '(1024x32x32x32 activations), both operands split exactly into 3 bf16 terms',
+            'achieved': flops / sec / 1e12, 'peak': peak / 1e12, 'unit': 'TFLOP/s', 'frac': flops / sec / peak,
+            'traffic': traffic, 'traffic_source': src, 'launch_ms': sec * 1e3}
+
+
 HBM_PEAK = 8.0e12                  # MI355X HBM3E spec (6.3e12 measured achievable), MI355X_MICROARCH.md
 
 
@@ -330,6 +366,7 @@ def main():
             out['step_throughput_vs_f32_mfma_peak'] = value / world * WORKLOADS[a.workload][1] / (MFMA_F32_PEAK if a.dtype == 'f32' else MFMA_BF16_PEAK)
         if a.workload == 2 and a.dtype == 'f32' and not eval_mode:      # the roofline probes and the CPU baseline belong to the headline config
             out['roofline'] = dominant_kernel_roofline(device)
+            out['roofline_wgrad'] = wgrad_kernel_roofline(device)
             out['roofline_hbm'] = bn_backward_hbm(device)
         if world == 1 and not a.no_cpu_baseline and a.workload == 2 and a.dtype == 'f32' and not eval_mode:
             out['cpu_baseline'] = cpu_baseline()
