@@ -787,6 +787,41 @@ def recon_wmse(x_reco, x, sigma, sigma_is_log, snapshot=False):
     return _Recon.apply(x_reco, x, sigma, int(sigma_is_log), snapshot)
 
 
+class _MseRows(torch.autograd.Function):
+    """mean squares of EVERY row of xo (L, N, D) against x (N, D): the public `mse_loss` (losses.py:8-27).  The kernels compare
+    rows 1..L of an (L+1, N, D) tensor and never touch row 0, so they are handed the address ONE ROW IN FRONT of xo instead
+    of a copy with a dummy row (the forward reads rows 1..L only; the backward writes a zero row 0 into a gradient buffer that
+    does have it, and a view of its rows 1..L is returned)."""
+
+    @staticmethod
+    def forward(ctx, xo, x):
+        xo = _c(_f32(xo, 'mse_loss'))
+        x = _c(_f32(x, 'mse_loss'))
+        Ls, N, D = xo.shape
+        one = torch.ones(1, device=x.device, dtype=torch.float32)
+        wmse = torch.empty((Ls, N), device=x.device, dtype=torch.float32)
+        rc = L.load().jvae_recon_fwd_f32(L.ptr(xo) - 4 * N * D, L.ptr(x), L.ptr(one), SIGMA_VALUE, L.ptr(wmse), Ls, N, D, L.stream_ptr())
+        L.check(rc, 'jvae_recon_fwd_f32')
+        ctx.save_for_backward(xo, x, one, wmse)
+        return wmse
+
+    @staticmethod
+    def backward(ctx, g):
+        xo, x, one, wmse = ctx.saved_tensors
+        Ls, N, D = xo.shape
+        g = _c(g)
+        full = torch.empty((Ls + 1, N, D), device=xo.device, dtype=torch.float32)
+        rc = L.load().jvae_recon_bwd_f32(L.ptr(xo) - 4 * N * D, L.ptr(x), L.ptr(one), SIGMA_VALUE, None, L.ptr(g), L.ptr(wmse),
+                                         L.ptr(full), None, 0, Ls, N, D, None, 0, L.stream_ptr())
+        L.check(rc, 'jvae_recon_bwd_f32')
+        return full[1:], None
+
+
+def mse_rows(xo, x):
+    """xo (L, N, D), x (N, D) -> (L, N) mean squares over D of every row (no copy of xo)."""
+    return _MseRows.apply(xo, x)
+
+
 class _Elbo(torch.autograd.Function):
     """wmse_s (L,N), kl (N,), ce (N,)|None, sigma -> (wmse, cross_x, total, mse) (cvae.py:662-670,773-791,887-902)."""
 

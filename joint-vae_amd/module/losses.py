@@ -12,8 +12,7 @@ from jvae_hip import ops
 def mse_loss(x_output, x_target, ndim=3, batch_mean=True):
     """x_target (N1..Ng, D1..Dt); x_output (L, N1..Ng, D1..Dt) -> (L, N1..Ng) mean squares (or their mean).
 
-    Runs the reconstruction kernel with sigma = 1; that kernel compares rows 1..L of a (L+1, N, D) tensor
-    with x, so a leading dummy row is passed.
+    Runs the reconstruction kernel with sigma = 1 on every row of x_output (ops.mse_rows: no padded copy).
     """
     lead = x_output.shape[:x_output.dim() - x_target.dim()]
     L_ = 1
@@ -24,10 +23,7 @@ def mse_loss(x_output, x_target, ndim=3, batch_mean=True):
     for s in batch:
         n *= s
     D = x_target.numel() // max(n, 1)
-    xo = x_output.reshape(L_, n, D)
-    padded = torch.cat([xo[:1], xo], 0)                     # row 0 is ignored by the kernel
-    one = torch.ones(1, device=x_target.device)
-    wmse = ops.recon_wmse(padded, x_target.reshape(n, D), one, False).reshape(*lead, *batch)
+    wmse = ops.mse_rows(x_output.reshape(L_, n, D), x_target.reshape(n, D)).reshape(*lead, *batch)
     return wmse.mean() if batch_mean else wmse
 
 

@@ -386,6 +386,27 @@ def test_recon(is_log):
     assert rel(sd.grad, sr.grad) < 1e-5
 
 
+@pytest.mark.parametrize('shape', [((3,), (5,), (3, 8, 8)), ((2,), (4,), (1, 28, 28)), ((1,), (3,), (7,))])
+def test_public_mse_loss_every_row_without_a_padded_copy(shape):
+    """module.losses.mse_loss (reference losses.py:8-27): mean squares of EVERY row of x_output against x_target, values and
+    gradient, against F.mse_loss; the kernels get the address one row in front of x_output (ops.mse_rows) instead of a copy."""
+    from module.losses import mse_loss
+    lead, batch, img = shape
+    g = torch.Generator().manual_seed(11)
+    xo = torch.randn(*lead, *batch, *img, generator=g)
+    xt = torch.rand(*batch, *img, generator=g)
+    a = xo.clone().requires_grad_(True)
+    ref = F.mse_loss(a, xt.expand_as(a), reduction='none').flatten(len(lead) + len(batch)).mean(-1)
+    gw = torch.randn(ref.shape, generator=g)
+    (ref * gw).sum().backward()
+    ad = xo.to(DEV).requires_grad_(True)
+    out = mse_loss(ad, xt.to(DEV), ndim=len(img), batch_mean=False)
+    assert tuple(out.shape) == tuple(ref.shape) and rel(out, ref) < 1e-5
+    (out * gw.to(DEV)).sum().backward()
+    assert rel(ad.grad, a.grad) < 1e-5
+    assert abs(float(mse_loss(ad.detach(), xt.to(DEV), ndim=len(img))) - float(ref.mean())) < 1e-5 * float(ref.mean())
+
+
 def test_cross_entropy():
     from jvae_hip import ops
     g = torch.Generator().manual_seed(9)
