@@ -41,7 +41,30 @@ VERSION = 2.
 LOG2PI = math.log(2 * math.pi)
 
 
-class Measures(dict):
+class _LazyDict(dict):
+    """A dict whose content is produced by `_fill()` the first time anything reads it."""
+
+    def _fill(self):
+        raise NotImplementedError
+
+    def copy(self):
+        self._fill()
+        return dict(self)
+
+
+def _lazy(name):
+    def method(self, *a, **k):
+        self._fill()
+        return getattr(dict, name)(self, *a, **k)
+    method.__name__ = name
+    return method
+
+
+for _n in ('__getitem__', 'get', '__contains__', '__iter__', '__len__', 'keys', 'values', 'items', '__repr__', '__eq__'):
+    setattr(_LazyDict, _n, _lazy(_n))
+
+
+class Measures(_LazyDict):
     """`total_measures` of evaluate(): a dict of Python floats (rmse, dB, sigma, ...) exactly as in the reference, but
     materialised LAZILY: the 16 scalars sit in one device buffer (running means included, continued on the device from
     batch to batch) that is copied to pinned host memory asynchronously; the first time any entry is read the dict
@@ -82,48 +105,8 @@ class Measures(dict):
             for k in [k for k in dict.keys(self) if k not in self._only]:
                 dict.__delitem__(self, k)
 
-    def __getitem__(self, k):
-        self._fill()
-        return dict.__getitem__(self, k)
 
-    def get(self, k, d=None):
-        self._fill()
-        return dict.get(self, k, d)
-
-    def __contains__(self, k):
-        self._fill()
-        return dict.__contains__(self, k)
-
-    def __iter__(self):
-        self._fill()
-        return dict.__iter__(self)
-
-    def __len__(self):
-        self._fill()
-        return dict.__len__(self)
-
-    def keys(self):
-        self._fill()
-        return dict.keys(self)
-
-    def values(self):
-        self._fill()
-        return dict.values(self)
-
-    def items(self):
-        self._fill()
-        return dict.items(self)
-
-    def copy(self):
-        self._fill()
-        return dict(self)
-
-    def __repr__(self):
-        self._fill()
-        return dict.__repr__(self)
-
-
-class _LazySigmaParams(dict):
+class _LazySigmaParams(_LazyDict):
     """training_parameters['sigma'] (Sigma.params with the current rms value) without a device read-back per batch."""
 
     def __init__(self, sigma, measures):
@@ -134,34 +117,6 @@ class _LazySigmaParams(dict):
         if not self._done:
             self._done = True
             dict.update(self, self._s.host_params(self._m['sigma']))
-
-    def __getitem__(self, k):
-        self._fill()
-        return dict.__getitem__(self, k)
-
-    def items(self):
-        self._fill()
-        return dict.items(self)
-
-    def keys(self):
-        self._fill()
-        return dict.keys(self)
-
-    def __iter__(self):
-        self._fill()
-        return dict.__iter__(self)
-
-    def __len__(self):
-        self._fill()
-        return dict.__len__(self)
-
-    def copy(self):
-        self._fill()
-        return dict(self)
-
-    def __repr__(self):
-        self._fill()
-        return dict.__repr__(self)
 
 
 def _grad_nan_exit():
