@@ -1,4 +1,5 @@
-// GPU box: checks half_wave_reduce32 (common.h) lane by lane against a host sum.  Build: see tests/diagnostics/README
+// GPU box: checks half_wave_reduce32 (common.h) lane by lane against a host sum.
+// Build (here): hipcc -O3 --offload-arch=gfx950 tests/diagnostics/reduce32_probe.hip -o joint-vae_amd/csrc/build/reduce32_probe ; run it through gpurun.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
