@@ -20,6 +20,25 @@ __device__ __forceinline__ void bn_coef(float g, float b, float mean, float invs
     *sh = b - mean * (g * invstd);
 }
 
+// float offset of the i-th float4 of channel c inside the images [nb, ne): 32-bit arithmetic, a shift when the plane size is a
+// power of two.  (The loops used 64-bit i / P4 and i % P4 per 16 bytes: ~100 vector instructions per load, which is what made
+// these HBM-bound kernels crawl beside the matrix-core kernels of the other stream - they compete for the same issue slots.)
+struct Plane4Idx {
+    unsigned p4; int sh; long stride, base;
+    __device__ __forceinline__ long operator()(unsigned i) const {
+        const unsigned n = sh >= 0 ? i >> sh : i / p4;
+        return base + (long)n * stride + (long)(i - n * p4) * 4;
+    }
+};
+__device__ __forceinline__ Plane4Idx plane4_idx(int nb, int C, int c, int P) {
+    Plane4Idx u;
+    u.p4 = (unsigned)(P >> 2);
+    u.sh = (u.p4 & (u.p4 - 1)) == 0 ? __ffs((int)u.p4) - 1 : -1;
+    u.stride = (long)C * P;
+    u.base = ((long)nb * C + c) * P;
+    return u;
+}
+
 // partial[c][s] = (sum(x-p), sum((x-p)^2)) over the images of split s;  p = x[0][c][0]
 __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, float* __restrict__ partial,
                                                        int N, int C, int P, int nsplit, const float* __restrict__ pv) {
@@ -30,11 +49,11 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
     const int nb = s * per, ne = min(N, nb + per);
     float s1 = 0.f, s2 = 0.f;
     if ((P & 3) == 0) {
-        const int P4 = P >> 2;
-        const long cnt = (long)(ne - nb) * P4;
-        for (long i = threadIdx.x; i < cnt; i += blockDim.x) {
-            const long n = nb + i / P4, q = i % P4;
-            const f32x4 v = *reinterpret_cast<const f32x4*>(x + ((n * C + c) * (long)P) + q * 4);
+        const unsigned cnt = (unsigned)(ne - nb) * (unsigned)(P >> 2);
+        const Plane4Idx pi = plane4_idx(nb, C, c, P);
+#pragma unroll 2
+        for (unsigned i = threadIdx.x; i < cnt; i += 256) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(x + pi(i));
 #pragma unroll
             for (int j = 0; j < 4; ++j) { const float d = v[j] - pivot; s1 += d; s2 += d * d; }
         }
@@ -111,11 +130,11 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
     const int per = (N + nchunk - 1) / nchunk;
     const int nb = j * per, ne = min(N, nb + per);
     if ((P & 3) == 0) {
-        const int P4 = P >> 2;
-        const long cnt = (long)(ne - nb) * P4;
-        for (long i = threadIdx.x; i < cnt; i += blockDim.x) {
-            const long n = nb + i / P4, q = i % P4;
-            const long off = (n * C + c) * (long)P + q * 4;
+        const unsigned cnt = (unsigned)(ne - nb) * (unsigned)(P >> 2);
+        const Plane4Idx pi = plane4_idx(nb, C, c, P);
+#pragma unroll 2
+        for (unsigned i = threadIdx.x; i < cnt; i += 256) {
+            const long off = pi(i);
             f32x4 v = *reinterpret_cast<const f32x4*>(x + off);
 #pragma unroll
             for (int e = 0; e < 4; ++e) { const float t = fmaf(v[e], sc, sh); v[e] = relu ? fmaxf(t, 0.f) : t; }
@@ -198,11 +217,11 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     const int nb = s * per, ne = min(N, nb + per);
     float s1 = 0.f, s2 = 0.f;
     if ((P & 3) == 0) {
-        const int P4 = P >> 2;
-        const long cnt = (long)(ne - nb) * P4;
-        for (long i = threadIdx.x; i < cnt; i += blockDim.x) {
-            const long n = nb + i / P4, q = i % P4;
-            const long off = (n * C + c) * (long)P + q * 4;
+        const unsigned cnt = (unsigned)(ne - nb) * (unsigned)(P >> 2);
+        const Plane4Idx pi = plane4_idx(nb, C, c, P);
+#pragma unroll 2
+        for (unsigned i = threadIdx.x; i < cnt; i += 256) {
+            const long off = pi(i);
             const f32x4 xv = *reinterpret_cast<const f32x4*>(x + off);
             const f32x4 gv = *reinterpret_cast<const f32x4*>(dy + off);
 #pragma unroll
@@ -267,11 +286,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     const int per = (N + nchunk - 1) / nchunk;
     const int nb = j * per, ne = min(N, nb + per);
     if ((P & 3) == 0) {
-        const int P4 = P >> 2;
-        const long cnt = (long)(ne - nb) * P4;
-        for (long i = threadIdx.x; i < cnt; i += blockDim.x) {
-            const long n = nb + i / P4, q = i % P4;
-            const long off = (n * C + c) * (long)P + q * 4;
+        const unsigned cnt = (unsigned)(ne - nb) * (unsigned)(P >> 2);
+        const Plane4Idx pi = plane4_idx(nb, C, c, P);
+#pragma unroll 2
+        for (unsigned i = threadIdx.x; i < cnt; i += 256) {
+            const long off = pi(i);
             const f32x4 xv = *reinterpret_cast<const f32x4*>(x + off);
             f32x4 gv = *reinterpret_cast<const f32x4*>(dy + off);
 #pragma unroll
