@@ -74,13 +74,16 @@ __global__ __launch_bounds__(256) void unfold4_kernel(const float* __restrict__ 
 __global__ __launch_bounds__(256) void fold_kernel(const float* __restrict__ col, float* __restrict__ xb,
                                                    const float* __restrict__ bias, ConvGeom g, int n0, int nimg,
                                                    long sn, long sk, long sq) {
-    const long total = (long)nimg * g.Cb * g.Hb * g.Wb;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int wb = (int)(i % g.Wb);
-        long r = i / g.Wb;
-        const int hb = (int)(r % g.Hb); r /= g.Hb;
-        const int cb = (int)(r % g.Cb);
-        const int n = (int)(r / g.Cb);
+    // 32-bit index arithmetic (the host launches this kernel only for fewer than 2^31 elements: a 64-bit div / mod chain per
+    // element is ~300 vector instructions in front of a handful of loads)
+    const unsigned total = (unsigned)nimg * g.Cb * g.Hb * g.Wb;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        unsigned r = i / (unsigned)g.Wb;
+        const int wb = (int)(i - r * g.Wb);
+        unsigned r2 = r / (unsigned)g.Hb;
+        const int hb = (int)(r - r2 * g.Hb);
+        const int n = (int)(r2 / (unsigned)g.Cb);
+        const int cb = (int)(r2 - (unsigned)n * g.Cb);
         float acc = bias ? bias[cb] : 0.f;
         if (g.Hs * g.Ws < g.KH * g.KW) {
             // few folded positions (e.g. 2x2): walk them instead of the taps
@@ -283,6 +286,7 @@ int jvae_fold_bwd(const ConvGeom& g, const float* ys, const float* w, const floa
         int rc = jvae_gemm_launch(g.N, Kd, g.Cs, Ps, ys, (long)g.Cs * Ps, Ps, 1, w, Kd, 1, 0,
                                   ws, Kd, 1, (long)g.N * Kd, nullptr, 0, 0, 1, st);
         if (rc) return rc;
+        if ((long)g.N * g.Cb * g.Hb * g.Wb >= (1L << 31)) return JVAE_ENOTSUP;          // fold_kernel indexes with 32 bits
         hipLaunchKernelGGL(fold_kernel, dim3(grid_for((long)g.N * g.Cb * g.Hb * g.Wb)), dim3(256), 0, st, ws, xb, bias,
                            g, 0, g.N, (long)Kd, 1L, (long)g.N * Kd);
         JVAE_LAUNCH_CHECK();
@@ -296,6 +300,7 @@ int jvae_fold_bwd(const ConvGeom& g, const float* ys, const float* w, const floa
         int rc = jvae_gemm_launch(Kd, Ps, g.Cs, ni, w, 1, Kd, 0, ys + (long)n0 * g.Cs * Ps, Ps, 1, (long)g.Cs * Ps,
                                   ws, Ps, 1, (long)Kd * Ps, nullptr, 0, 0, 1, st);
         if (rc) return rc;
+        if ((long)ni * g.Cb * g.Hb * g.Wb >= (1L << 31)) return JVAE_ENOTSUP;
         hipLaunchKernelGGL(fold_kernel, dim3(grid_for((long)ni * g.Cb * g.Hb * g.Wb)), dim3(256), 0, st, ws, xb, bias,
                            g, n0, ni, (long)Kd * Ps, (long)Ps, 1L);
         JVAE_LAUNCH_CHECK();
