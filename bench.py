@@ -364,7 +364,8 @@ def main():
             # NOT a utilisation figure: algorithmic conv/linear FLOPs per second divided by the fp32-MFMA peak the north-star
             # target (>= 0.5) is phrased in; most of those FLOPs run on the bf16 pipes (6 bf16 products per fp32 product)
             out['step_throughput_vs_f32_mfma_peak'] = value / world * WORKLOADS[a.workload][1] / (MFMA_F32_PEAK if a.dtype == 'f32' else MFMA_BF16_PEAK)
-        if a.workload == 2 and a.dtype == 'f32' and not eval_mode:      # the roofline probes and the CPU baseline belong to the headline config
+        # the roofline probes and the CPU baseline belong to the headline config (JVAE_BENCH_NO_PROBES=1: kernel traces of the step alone)
+        if a.workload == 2 and a.dtype == 'f32' and not eval_mode and os.environ.get('JVAE_BENCH_NO_PROBES') != '1':
             out['roofline'] = dominant_kernel_roofline(device)
             out['roofline_wgrad'] = wgrad_kernel_roofline(device)
             out['roofline_hbm'] = bn_backward_hbm(device)

@@ -3,6 +3,7 @@
 set -e
 TAG=$1; shift
 cd /tmp && export TMPDIR=/tmp
+export JVAE_BENCH_NO_PROBES=1      # the trace holds the training steps only (no roofline probe launches)
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
 rm -rf $O; mkdir -p $O
