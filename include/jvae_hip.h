@@ -85,6 +85,11 @@ int jvae_channel_sum_f32(const float* t, float* out, int N, int C, int P, int ac
  * unbiased into running_var, momentum update, num_batches_tracked += 1), else running statistics.
  * relu != 0 fuses the following nn.ReLU (conv.py:214-220).  Backward recomputes the ReLU mask from x. */
 size_t jvae_bn_workspace_bytes(int C);
+/* Host-only (no GPU work): launch plan of the BatchNorm kernels - nsplit image parts for the reduction kernels, nchunk for the
+ * apply kernels - and the image range [nb, ne) of part j out of `parts` (trailing parts may be EMPTY, nb == ne, never
+ * negative: the reference keeps the ragged last batch, cvae.py:2245-2249, so every N must partition safely). */
+int jvae_bn_plan(int N, int C, int P, int* nsplit, int* nchunk);
+int jvae_image_range(int N, int parts, int j, int* nb, int* ne);
 int jvae_bn_fwd_f32(const float* x, const float* gamma, const float* beta,
                     float* running_mean, float* running_var, long long* num_batches_tracked,
                     float* y, float* save_mean, float* save_invstd,
@@ -176,6 +181,7 @@ int jvae_conv2d_wgrad_b8(const void* x, const void* dy, float* dw, float* dbias,
                          void* ws, size_t ws_bytes, void* stream);
 /* BatchNorm2d (+ReLU) on B8 tensors; arguments as jvae_bn_fwd_ext_f32 / jvae_bn_bwd_f32 with HW = pixels per image. */
 size_t jvae_bn_workspace_bytes_b8(int C);
+int jvae_bn_plan_b8(int N, int C, long HW, int* nsplit, int* nchunk);      /* host-only, see jvae_bn_plan */
 int jvae_bn_fwd_b8(const void* x, const float* gamma, const float* beta,
                    float* running_mean, float* running_var, long long* num_batches_tracked,
                    void* y, float* save_mean, float* save_invstd,

@@ -45,8 +45,8 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
     __shared__ float red[17];
     const int c = blockIdx.x, s = blockIdx.y;
     const float pivot = pv ? pv[c] : x[(long)c * P];
-    const int per = (N + nsplit - 1) / nsplit;
-    const int nb = s * per, ne = min(N, nb + per);
+    const ImageRange ir = image_range(N, nsplit, s);   // trailing parts may be empty, never negative
+    const int nb = ir.nb, ne = ir.ne;
     float s1 = 0.f, s2 = 0.f;
     if ((P & 3) == 0) {
         const unsigned cnt = (unsigned)(ne - nb) * (unsigned)(P >> 2);
@@ -127,8 +127,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
     }
     __syncthreads();
     const float sc = cs[0], sh = cs[1];
-    const int per = (N + nchunk - 1) / nchunk;
-    const int nb = j * per, ne = min(N, nb + per);
+    const ImageRange ir = image_range(N, nchunk, j);   // trailing parts may be empty, never negative
+    const int nb = ir.nb, ne = ir.ne;
     if ((P & 3) == 0) {
         const unsigned cnt = (unsigned)(ne - nb) * (unsigned)(P >> 2);
         const Plane4Idx pi = plane4_idx(nb, C, c, P);
@@ -213,8 +213,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     const float g_ = gamma ? gamma[c] : 1.f, b_ = beta ? beta[c] : 0.f;
     float sc, sh;
     bn_coef(g_, b_, mu, is, &sc, &sh);
-    const int per = (N + nsplit - 1) / nsplit;
-    const int nb = s * per, ne = min(N, nb + per);
+    const ImageRange ir = image_range(N, nsplit, s);   // trailing parts may be empty, never negative
+    const int nb = ir.nb, ne = ir.ne;
     float s1 = 0.f, s2 = 0.f;
     if ((P & 3) == 0) {
         const unsigned cnt = (unsigned)(ne - nb) * (unsigned)(P >> 2);
@@ -283,8 +283,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     float sc, sh;
     bn_coef(g_, b_, mu, is, &sc, &sh);
     const float k = g_ * is;
-    const int per = (N + nchunk - 1) / nchunk;
-    const int nb = j * per, ne = min(N, nb + per);
+    const ImageRange ir = image_range(N, nchunk, j);   // trailing parts may be empty, never negative
+    const int nb = ir.nb, ne = ir.ne;
     if ((P & 3) == 0) {
         const unsigned cnt = (unsigned)(ne - nb) * (unsigned)(P >> 2);
         const Plane4Idx pi = plane4_idx(nb, C, c, P);
@@ -352,6 +352,22 @@ inline int pick_chunk(int N, int C, int P) {
 }  // namespace
 
 extern "C" {
+
+// Host-only (no GPU call): the launch plan of the fp32 BatchNorm kernels for a (N, C, P) tensor - `nsplit` image parts for the
+// two reduction kernels, `nchunk` for the two apply kernels - and the image range [nb, ne) that part j of `parts` receives
+// (image_range(), the one definition every kernel uses).  tests/test_abi_and_host.py sweeps every batch size with these.
+int jvae_bn_plan(int N, int C, int P, int* nsplit, int* nchunk) {
+    if (N <= 0 || C <= 0 || P <= 0 || !nsplit || !nchunk) return JVAE_EINVAL;
+    *nsplit = pick_split(N, C, P);
+    *nchunk = pick_chunk(N, C, P);
+    return 0;
+}
+int jvae_image_range(int N, int parts, int j, int* nb, int* ne) {
+    if (N < 0 || parts <= 0 || j < 0 || j >= parts || !nb || !ne) return JVAE_EINVAL;
+    const ImageRange r = image_range(N, parts, j);
+    *nb = r.nb; *ne = r.ne;
+    return 0;
+}
 
 // workspace: 2*C*MAX_SPLIT partials + 2*C coefficients
 size_t jvae_bn_workspace_bytes(int C) { return sizeof(float) * ((size_t)2 * C * MAX_SPLIT + (size_t)2 * C); }

@@ -57,8 +57,8 @@ __global__ __launch_bounds__(256) void bn8_stats_kernel(const bf16x8* __restrict
     float pf[8];            // pivot (C) given: the same on every data-parallel rank (synchronised statistics)
 #pragma unroll
     for (int ci = 0; ci < 8; ++ci) pf[ci] = pivot ? (cb * 8 + ci < C ? pivot[cb * 8 + ci] : 0.f) : (float)pv[ci];
-    const int per = (N + nsplit - 1) / nsplit;
-    const int nb = s * per, ne = min(N, nb + per);
+    const ImageRange ir = image_range(N, nsplit, s);   // trailing parts may be empty, never negative
+    const int nb = ir.nb, ne = ir.ne;
     float s1[8], s2[8];
 #pragma unroll
     for (int ci = 0; ci < 8; ++ci) s1[ci] = s2[ci] = 0.f;
@@ -133,8 +133,8 @@ __global__ __launch_bounds__(256) void bn8_apply_kernel(const bf16x8* __restrict
     float sc[8], sh[8];
 #pragma unroll
     for (int ci = 0; ci < 8; ++ci) { sc[ci] = coef[cb * 8 + ci]; sh[ci] = coef[C8 + cb * 8 + ci]; }
-    const int per = (N + nchunk - 1) / nchunk;
-    const int nb = j * per, ne = min(N, nb + per);
+    const ImageRange ir = image_range(N, nchunk, j);   // trailing parts may be empty, never negative
+    const int nb = ir.nb, ne = ir.ne;
     const unsigned cnt = (unsigned)((long)(ne - nb) * HW);
     const UnitIdx ui = unit_idx(nb, CB, cb, HW);
 #pragma unroll 2
@@ -167,8 +167,8 @@ __global__ __launch_bounds__(256) void bn8_bwd_reduce_kernel(const bf16x8* __res
         is[ci] = c < C ? invstd[c] : 0.f;
         bn_coef(c < C && gamma ? gamma[c] : (c < C ? 1.f : 0.f), c < C && beta ? beta[c] : 0.f, mu[ci], is[ci], &sc[ci], &sh[ci]);
     }
-    const int per = (N + nsplit - 1) / nsplit;
-    const int nb = s * per, ne = min(N, nb + per);
+    const ImageRange ir = image_range(N, nsplit, s);   // trailing parts may be empty, never negative
+    const int nb = ir.nb, ne = ir.ne;
     float s1[8], s2[8];
 #pragma unroll
     for (int ci = 0; ci < 8; ++ci) s1[ci] = s2[ci] = 0.f;
@@ -239,8 +239,8 @@ __global__ __launch_bounds__(256) void bn8_bwd_apply_kernel(const bf16x8* __rest
         k[ci] = g_ * is[ci];
         m1[ci] = coef[c]; m2[ci] = coef[C8 + c];
     }
-    const int per = (N + nchunk - 1) / nchunk;
-    const int nb = j * per, ne = min(N, nb + per);
+    const ImageRange ir = image_range(N, nchunk, j);   // trailing parts may be empty, never negative
+    const int nb = ir.nb, ne = ir.ne;
     const unsigned cnt = (unsigned)((long)(ne - nb) * HW);
     const UnitIdx ui = unit_idx(nb, CB, cb, HW);
 #pragma unroll 2
@@ -328,6 +328,15 @@ inline int pick_chunk(int N, int CB, long HW) {
 }  // namespace
 
 extern "C" {
+
+// Host-only launch plan of the bf16 (B8 layout) BatchNorm kernels: see jvae_bn_plan.
+int jvae_bn_plan_b8(int N, int C, long HW, int* nsplit, int* nchunk) {
+    if (N <= 0 || C <= 0 || HW <= 0 || !nsplit || !nchunk) return JVAE_EINVAL;
+    const int CB = (C + 7) / 8;
+    *nsplit = pick_split(N, CB, HW);
+    *nchunk = pick_chunk(N, CB, HW);
+    return 0;
+}
 
 // partial sums (2 * C8 * MAX_SPLIT floats) followed by 2 * C8 per-channel coefficients
 size_t jvae_bn_workspace_bytes_b8(int C) { return sizeof(float) * ((size_t)2 * ((C + 7) / 8 * 8) * (MAX_SPLIT + 1)); }

@@ -21,6 +21,21 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Images [nb, ne) of part j when N images are dealt to `parts` workgroups in runs of ceil(N / parts).  The last parts can be
+// EMPTY (nb >= N whenever (parts - 1) * ceil(N / parts) >= N, e.g. N = 49 over 64 parts): ne is clamped to nb so that ne - nb is
+// never negative - every kernel that partitions a batch takes its range from here (and only from here).
+struct ImageRange { int nb, ne; };
+__host__ __device__ __forceinline__ ImageRange image_range(int N, int parts, int j) {
+    const int per = (N + parts - 1) / parts;
+    const long b = (long)j * per;
+    ImageRange r;
+    r.nb = b < N ? (int)b : N;
+    const long e = b + per;
+    r.ne = e < N ? (int)e : N;
+    if (r.ne < r.nb) r.ne = r.nb;
+    return r;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -70,8 +70,8 @@ __global__ __launch_bounds__(256) void b8_channel_sum_kernel(const bf16x8* __res
                                                              int N, int CB, long HW, int nsplit) {
     __shared__ float red[4][8];
     const int cb = blockIdx.x, s = blockIdx.y;
-    const int per = (N + nsplit - 1) / nsplit;
-    const int nb = s * per, ne = min(N, nb + per);
+    const ImageRange ir = image_range(N, nsplit, s);   // trailing parts may be empty, never negative
+    const int nb = ir.nb, ne = ir.ne;
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const long cnt = (long)(ne - nb) * HW;
     for (long i = threadIdx.x; i < cnt; i += blockDim.x) {

@@ -124,8 +124,8 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restric
                                                           int N, int C, int P, int nsplit) {
     __shared__ float red[17];
     const int c = blockIdx.x, sp = blockIdx.y;
-    const int per = (N + nsplit - 1) / nsplit;
-    const int nb = sp * per, ne = min(N, nb + per);
+    const ImageRange ir = image_range(N, nsplit, sp);   // trailing parts may be empty, never negative
+    const int nb = ir.nb, ne = ir.ne;
     float s = 0.f;
     if ((P & 3) == 0) {
         const int P4 = P >> 2;
@@ -153,6 +153,14 @@ __global__ void channel_fold_kernel(const float* __restrict__ partial, float* __
     float s = 0.f;
     for (int k = 0; k < nsplit; ++k) s += partial[(long)c * nsplit + k];
     out[c] = (accumulate ? out[c] : 0.f) + s;
+}
+
+// images per fold_kernel launch: the kernel's element index is 32-bit
+inline int fold_slab_images(const ConvGeom& g) {
+    const long per = (long)g.Cb * g.Hb * g.Wb;
+    long n = ((1L << 31) - 1) / (per > 0 ? per : 1);
+    if (const char* e = getenv("JVAE_FOLD_SLAB")) { const long v = atol(e); if (v > 0 && v < n) n = v; }   // tests: force the slab path
+    return (int)(n < 1 ? 1 : (n > g.N ? (g.N > 0 ? g.N : 1) : n));
 }
 
 inline int grid_for(long total) {
@@ -286,10 +294,14 @@ int jvae_fold_bwd(const ConvGeom& g, const float* ys, const float* w, const floa
         int rc = jvae_gemm_launch(g.N, Kd, g.Cs, Ps, ys, (long)g.Cs * Ps, Ps, 1, w, Kd, 1, 0,
                                   ws, Kd, 1, (long)g.N * Kd, nullptr, 0, 0, 1, st);
         if (rc) return rc;
-        if ((long)g.N * g.Cb * g.Hb * g.Wb >= (1L << 31)) return JVAE_ENOTSUP;          // fold_kernel indexes with 32 bits
-        hipLaunchKernelGGL(fold_kernel, dim3(grid_for((long)g.N * g.Cb * g.Hb * g.Wb)), dim3(256), 0, st, ws, xb, bias,
-                           g, 0, g.N, (long)Kd, 1L, (long)g.N * Kd);
-        JVAE_LAUNCH_CHECK();
+        // fold_kernel indexes with 32 bits: slabs of images below 2^31 output elements (one launch for every real size)
+        const int slab = fold_slab_images(g);
+        for (int n0 = 0; n0 < g.N; n0 += slab) {
+            const int ni = (g.N - n0 < slab) ? g.N - n0 : slab;
+            hipLaunchKernelGGL(fold_kernel, dim3(grid_for((long)ni * g.Cb * g.Hb * g.Wb)), dim3(256), 0, st,
+                               ws + (long)n0 * Kd, xb, bias, g, n0, ni, (long)Kd, 1L, (long)g.N * Kd);
+            JVAE_LAUNCH_CHECK();
+        }
         return 0;
     }
     const int chunk = chunk_images(g, ws_bytes);
@@ -300,10 +312,13 @@ int jvae_fold_bwd(const ConvGeom& g, const float* ys, const float* w, const floa
         int rc = jvae_gemm_launch(Kd, Ps, g.Cs, ni, w, 1, Kd, 0, ys + (long)n0 * g.Cs * Ps, Ps, 1, (long)g.Cs * Ps,
                                   ws, Ps, 1, (long)Kd * Ps, nullptr, 0, 0, 1, st);
         if (rc) return rc;
-        if ((long)ni * g.Cb * g.Hb * g.Wb >= (1L << 31)) return JVAE_ENOTSUP;
-        hipLaunchKernelGGL(fold_kernel, dim3(grid_for((long)ni * g.Cb * g.Hb * g.Wb)), dim3(256), 0, st, ws, xb, bias,
-                           g, n0, ni, (long)Kd * Ps, (long)Ps, 1L);
-        JVAE_LAUNCH_CHECK();
+        const int slab = fold_slab_images(g);
+        for (int m0 = 0; m0 < ni; m0 += slab) {
+            const int mi = (ni - m0 < slab) ? ni - m0 : slab;
+            hipLaunchKernelGGL(fold_kernel, dim3(grid_for((long)mi * g.Cb * g.Hb * g.Wb)), dim3(256), 0, st,
+                               ws + (long)m0 * Kd * Ps, xb, bias, g, n0 + m0, mi, (long)Kd * Ps, (long)Ps, 1L);
+            JVAE_LAUNCH_CHECK();
+        }
     }
     return 0;
 }

@@ -94,8 +94,8 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_kernel(WgP p) {
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
     // images of this workgroup
-    const int per = (p.N + p.G - 1) / p.G;
-    const int n_beg = blockIdx.x * per, n_end = min(p.N, n_beg + per);
+    const ImageRange ir = image_range(p.N, p.G, blockIdx.x);   // trailing workgroups may be empty
+    const int n_beg = ir.nb, n_end = ir.ne;
     constexpr int W4 = G::WB / 4;
     constexpr int QUNITS = CB * G::ROWS * W4;
     constexpr int PUNITS = 32 * G::TPIX / 4;

@@ -205,8 +205,8 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_x3_kernel(WgX3P p) {
             for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     }
 
-    const int per = (p.N + p.G - 1) / p.G;
-    const int n_beg = blockIdx.x * per, n_end = min(p.N, n_beg + per);
+    const ImageRange ir = image_range(p.N, p.G, blockIdx.x);   // trailing workgroups may be empty
+    const int n_beg = ir.nb, n_end = ir.ne;
     constexpr int QU = (G::QITEMS + 255) / 256, PU = (G::PITEMS + 255) / 256;
     constexpr int HB = G::HS * S;
     constexpr int W2 = G::WB / 2;

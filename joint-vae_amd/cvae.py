@@ -927,7 +927,10 @@ class ClassificationVariationalNetwork(nn.Module):
                 with torch.cuda.graph(gb, pool=ga.pool()):
                     update()
             finally:
+                # both flags exist only while the two halves are being captured: a later EAGER train_step() / train_model()
+                # on this model must again join the side stream and exchange its gradients inside reduce_gradients()
                 self._graph_capture = False
+                self.optimizer._external_reduce = False
             for g in self.optimizer._groups:
                 g.step -= 1
 

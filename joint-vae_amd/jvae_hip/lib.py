@@ -36,6 +36,7 @@ _SIGS = {
     'jvae_conv2d_dgrad_b8': (c_int, [P, P, P] + [c_int] * 11 + [P, c_size_t, P]),
     'jvae_conv2d_wgrad_b8': (c_int, [P, P, P, P, c_int] + [c_int] * 11 + [P, c_size_t, P]),
     'jvae_bn_workspace_bytes_b8': (c_size_t, [c_int]),
+    'jvae_bn_plan_b8': (c_int, [c_int, c_int, c_long, POINTER(c_int), POINTER(c_int)]),
     'jvae_bn_fwd_b8': (c_int, [P] * 9 + [c_int, c_int, c_long, c_float, c_float, c_int, c_int, P, c_int, P, P, c_size_t, P]),
     'jvae_bn_bwd_b8': (c_int, [P] * 9 + [c_int, c_int, c_int, c_long, c_int, P, c_size_t, P]),
     'jvae_bn_finalize_b8': (c_int, [P] * 9 + [c_int, c_int, c_long, c_float, c_float, c_int, P, c_int, P, P, c_size_t, P]),
@@ -55,6 +56,8 @@ _SIGS = {
     'jvae_channel_sum_workspace_bytes': (c_size_t, [c_int]),
     'jvae_channel_sum_f32': (c_int, [P, P, c_int, c_int, c_int, c_int, P, c_size_t, P]),
     'jvae_bn_workspace_bytes': (c_size_t, [c_int]),
+    'jvae_bn_plan': (c_int, [c_int, c_int, c_int, POINTER(c_int), POINTER(c_int)]),
+    'jvae_image_range': (c_int, [c_int, c_int, c_int, POINTER(c_int), POINTER(c_int)]),
     'jvae_bn_fwd_f32': (c_int, [P] * 9 + [c_int, c_int, c_int, c_float, c_float, c_int, c_int, P, c_size_t, P]),
     'jvae_bn_fwd_ext_f32': (c_int, [P] * 9 + [c_int, c_int, c_int, c_float, c_float, c_int, c_int, P, c_int, P, P, c_size_t, P]),
     'jvae_bn_sums_f32': (c_int, [P, P, P, c_int, c_int, c_int, P, c_size_t, P]),

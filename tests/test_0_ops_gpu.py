@@ -178,7 +178,11 @@ def test_split_bf16_wgrad_is_fp32_accurate(cin, cout, s, tr, H, N):
     print(f'wgrad {cin}->{cout} s{s} tr={tr} H={H}: error vs fp64 split-bf16 / fp32-MFMA: {res}')
 
 
-@pytest.mark.parametrize('N,C,P,relu', [(8, 32, 1024, True), (5, 3, 1024, False), (16, 200, 4, True), (2, 64, 63, True)])
+# (98,32,1024), (672,32,1024), (42,3,4096), (49,32,1024), (37,64,256): plans whose trailing image parts are EMPTY
+# ((parts-1)*ceil(N/parts) >= N) - the ragged last batches the reference never drops (cvae.py:2245-2249)
+@pytest.mark.parametrize('N,C,P,relu', [(8, 32, 1024, True), (5, 3, 1024, False), (16, 200, 4, True), (2, 64, 63, True),
+                                        (98, 32, 1024, True), (672, 32, 1024, True), (42, 3, 4096, False),
+                                        (49, 32, 1024, True), (37, 64, 256, True), (74, 3, 1023, False)])
 def test_batchnorm_train(N, C, P, relu):
     from jvae_hip import ops
     g = torch.Generator().manual_seed(N + C + P)
@@ -206,6 +210,15 @@ def test_batchnorm_train(N, C, P, relu):
     ye = ops.batchnorm_act(xd.detach(), gd.detach(), bd.detach(), rmd, rvd, nbt, False, relu)
     yer = F.batch_norm(x, rmr, rvr, gamma, beta, False, 0.1, 1e-5)
     assert rel(ye, torch.relu(yer) if relu else yer) < 1e-5
+
+
+@pytest.mark.parametrize('N,C,P', [(49, 32, 1024), (98, 64, 256), (5, 3, 1023)])
+def test_channel_sum_ragged_partitions(N, C, P):
+    from jvae_hip import ops
+    g = torch.Generator().manual_seed(N)
+    t = torch.randn(N, C, P, generator=g)
+    out = ops.channel_sum(t.to(DEV))
+    assert rel(out, t.double().sum((0, 2)).float()) < 1e-5
 
 
 @pytest.mark.parametrize('act', [0, 1, 2])

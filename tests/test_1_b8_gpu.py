@@ -167,7 +167,9 @@ def test_b8_transposed_stride2_from_4x4_maps(N):
     assert rel(ops_b8.unpack(gx, cin), xr.grad) < BF_TOL
 
 
-@pytest.mark.parametrize('N,C,H,relu', [(4, 32, 16, True), (3, 20, 8, True), (6, 64, 8, False), (2, 3, 32, True)])
+# (37,32,32), (49,3,32), (98,32,16), (130,32,32): launch plans with EMPTY trailing image parts (jvae_bn_plan_b8) - ragged batches
+@pytest.mark.parametrize('N,C,H,relu', [(4, 32, 16, True), (3, 20, 8, True), (6, 64, 8, False), (2, 3, 32, True),
+                                        (37, 32, 32, True), (49, 3, 32, False), (98, 32, 16, True), (130, 32, 32, True)])
 def test_b8_batchnorm(N, C, H, relu):
     """BatchNorm(+ReLU) on B8 vs torch on the bf16-rounded input; outputs are bf16 (2^-8 of scale), statistics fp32."""
     from jvae_hip import ops_b8

@@ -10,7 +10,7 @@ import torch.multiprocessing as mp
 
 pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-N_RANK, WORLD = 6, 2
+N_RANK, WORLD = 49, 2         # 49 per rank: BatchNorm-sums launch plans with EMPTY trailing image parts (ragged batches)
 
 
 def _paths():
@@ -110,6 +110,12 @@ def _graph_worker(rank, port, out_dir):
         losses, meas = step(x, y)
     torch.cuda.synchronize()
     last = float(losses['total'].detach().mean())
+    # an EAGER data-parallel step AFTER graph_train_step() must exchange gradients again (the capture-only
+    # `_external_reduce` flag used to stay set: no join, no all-reduce, replicas silently diverging on their own shards)
+    assert not getattr(net.optimizer, '_external_reduce', False)
+    late, _ = net.train_step(x, y)
+    torch.cuda.synchronize()
+    del late
     eps_probe = torch.randn(4, device='cuda')           # the device generator was offset per rank: ranks draw different noise
     torch.save({'params': {k: v.detach().cpu() for k, v in net.state_dict().items()}, 'first': first, 'last': last,
                 'opt_step': net.optimizer._groups[0].step, 'eps_probe': eps_probe.cpu(), 'rmse': meas['rmse']},
@@ -121,7 +127,7 @@ def _graph_worker(rank, port, out_dir):
 def test_graph_captured_data_parallel_step(tmp_path):
     """graph_train_step() under data parallelism - [zero_grad, forward, backward] and [clip, Adam] as two
     HIP graphs with the flat-gradient all-reduce between them.  Replicas that started from different weights are equal
-    after set_distributed() and STAY bit-identical through eager and graph steps (parameters, BatchNorm running statistics
+    after set_distributed() and STAY bit-identical through eager, graph and again eager steps (parameters, BatchNorm running statistics
     excepted: those are per-rank by design), the loss falls, the optimiser's step count follows the replays."""
     port = 29900 + os.getpid() % 1000
     mp.spawn(_graph_worker, args=(port, str(tmp_path)), nprocs=WORLD, join=True)
@@ -130,7 +136,7 @@ def test_graph_captured_data_parallel_step(tmp_path):
         if 'running_' in k or 'num_batches' in k:
             continue
         assert torch.equal(v, b['params'][k]), k
-    assert a['opt_step'] == b['opt_step'] == 1 + 1 + 6        # eager step + warm-up + replays
+    assert a['opt_step'] == b['opt_step'] == 1 + 1 + 6 + 1    # eager step + warm-up + replays + eager step after the graph
     assert a['last'] < a['first'] and b['last'] < b['first']
     assert not torch.equal(a['eps_probe'], b['eps_probe'])
     assert 0 < a['rmse'] < 10

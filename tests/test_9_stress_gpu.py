@@ -1,0 +1,76 @@
+"""Stress sizes LAST (file names order the `-m gpu` run: 0 kernel parity, 1 bf16 kernels, 2 model goldens, 3 data-parallel,
+9 stress): the label-free evaluation at N = 512 x L = 128 (decoder batch 66 048 images) and the launches it
+is made of.  A fault here can no longer hide the parity suite (round 2: it ran as test 121 of 267 and aborted the run)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import jvae_oracle as O
+from oracle.cases import get_case
+from oracle.det_init import det_inputs, load_det_state
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+RTOL = 1e-4
+
+
+def rel(a, b, floor=1e-30):
+    a = np.asarray(a.detach().double().cpu() if torch.is_tensor(a) else a, dtype=np.float64)
+    b = np.asarray(b.detach().double().cpu() if torch.is_tensor(b) else b, dtype=np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), floor))
+
+
+def test_batchnorm_eval_forward_at_the_label_free_decoder_batch():
+    """N = 129*512 = 66 048 images through the imager's last BatchNorm2d(3) (P = 1024): 1366 chunks of 49 images, the last 18
+    EMPTY - the launch that faulted in round 2.  Eval-mode forward only; checked against the closed form on the device."""
+    from jvae_hip import ops
+    N, C, P = 66048, 3, 1024
+    g = torch.Generator(device=DEV).manual_seed(3)
+    x = torch.randn(N, C, P, 1, generator=g, device=DEV)
+    gamma = torch.tensor([0.7, 1.3, 1.0], device=DEV)
+    beta = torch.tensor([0.1, -0.2, 0.3], device=DEV)
+    rm = torch.tensor([0.05, -0.1, 0.2], device=DEV)
+    rv = torch.tensor([0.9, 1.1, 1.4], device=DEV)
+    nbt = torch.zeros((), dtype=torch.int64, device=DEV)
+    guard = torch.full((1 << 20,), 7.0, device=DEV)           # lives right behind y in the caching allocator's pool
+    y = ops.batchnorm_act(x, gamma, beta, rm, rv, nbt, False, True)
+    sc = gamma / torch.sqrt(rv + 1e-5)
+    ref = torch.relu(x * sc.view(1, C, 1, 1) + (beta - rm * sc).view(1, C, 1, 1))
+    assert float((y - ref).abs().max()) < 1e-5
+    assert bool((guard == 7.0).all()) and int(nbt) == 0
+
+
+def test_eval_path_at_full_size_n512_l128():
+    """SURVEY.md §8f-1 at the size it exists for: N = 512 images, L = 128 latent draws (decoder batch 129 * 512 = 66 048
+    images) in ONE evaluate(x).  Eval-mode BatchNorm makes samples independent, so (i) a subset of the batch evaluated
+    alone, with its rows of the same epsilon, must give the same per-sample losses, (ii) that subset is checked against the
+    CPU oracle at L = 128, (iii) predictions are label-valued and the importance-weighted bound is finite everywhere."""
+    case = dict(get_case('e2_n8_L3'))
+    kw = dict(case['net'], test_latent_sampling=128)
+    from cvae import ClassificationVariationalNetwork as Net
+    net = Net(**kw)
+    load_det_state(net, seed=0)
+    net.to(DEV).eval()
+    N, L, K, C = 512, 128, kw['latent_dim'], kw['num_labels']
+    x, y, eps = det_inputs(N, kw['input_shape'], C, L, K, seed=11)
+    xd, ed = x.to(DEV), eps.to(DEV)
+    with torch.no_grad():
+        x_reco, y_est, losses, meas = net.evaluate(xd, epsilon=ed)
+    assert tuple(x_reco.shape) == (L + 1, N, 3, 32, 32) and tuple(losses['iws'].shape) == (C, N)
+    assert all(bool(torch.isfinite(v).all()) for v in losses.values())
+    pick = torch.tensor([0, 7, 100, 255, 256, 300, 444, 511])
+    with torch.no_grad():
+        _, ye_s, ls, _ = net.evaluate(xd[pick.to(DEV)], epsilon=ed[:, pick.to(DEV)])
+    for k, v in losses.items():
+        sub = v[..., pick.to(DEV)]
+        assert rel(ls[k], sub) < 2e-5, k
+    assert rel(ye_s, y_est[pick.to(DEV)]) < 2e-5
+    sp = O.make_spec(**kw)
+    P = O.init_state(sp, seed=0)
+    with torch.no_grad():
+        _, ye_o, lo, _ = O.evaluate_all_classes(sp, P, x[pick], eps[:, pick])
+    for k in ('total', 'iws', 'kl', 'zdist', 'cross_x', 'wmse'):
+        assert rel(ls[k], lo[k]) < RTOL, k
+    assert np.array_equal(net.predict_after_evaluate(ye_s, ls, method='iws').cpu().numpy(), O.predict(lo, ye_o, 'iws').numpy())
+    pred = net.predict_after_evaluate(y_est, losses, method='iws')
+    assert pred.dtype == torch.int64 and int(pred.min()) >= 0 and int(pred.max()) < C

@@ -68,6 +68,59 @@ def test_out_shape_entry_point_is_host_only():
     assert ops.ConvSpec(64, 64, 8, 1, 0, 0, transposed=True).out_hw(1, 1) == (8, 8)
 
 
+def test_batchnorm_launch_plan_partitions_every_batch_size():
+    """The reference keeps the ragged last batch (cvae.py:2245-2249; BatchNorm2d works for any N, conv.py:214-220), so
+    every batch size must partition into image ranges that are never negative, never overlap and cover [0, N) exactly -
+    including the plans whose trailing parts are EMPTY ((parts-1)*ceil(N/parts) >= N, e.g. N=49 over 64 parts: the round-2
+    regression).  Host-only: walks the same jvae_bn_plan / image_range() the kernels use, for every layer shape of
+    configs 2 and 5 (encoder batch n, decoder batch 2n) and the label-free evaluation's 129*512 decoder batch."""
+    import ctypes
+    from jvae_hip import lib
+    L = lib.load()
+    ns, nc, nb, ne = (ctypes.c_int() for _ in range(4))
+    layers2 = [(32, 1024), (32, 256), (64, 256), (64, 64), (200, 4), (64, 64), (64, 256), (32, 256), (32, 1024), (3, 1024)]
+    layers5 = [(32, 4096), (32, 1024), (64, 1024), (64, 256), (128, 256), (128, 64), (200, 36), (3, 4096)]
+    empties = 0
+
+    def check(N, C, P, b8=False):
+        nonlocal empties
+        rc = L.jvae_bn_plan_b8(N, C, P, ns, nc) if b8 else L.jvae_bn_plan(N, C, P, ns, nc)
+        assert rc == 0
+        for parts in (ns.value, nc.value):
+            assert 1 <= parts <= max(N, 1)
+            pos = 0
+            for j in range(parts):
+                assert L.jvae_image_range(N, parts, j, nb, ne) == 0
+                assert 0 <= nb.value <= ne.value <= N, (N, C, P, parts, j, nb.value, ne.value)
+                if nb.value == ne.value:
+                    empties += 1
+                else:
+                    assert nb.value == pos, (N, parts, j)
+                    pos = ne.value
+            assert pos == N, (N, C, P, parts)
+
+    for n in range(1, 513):
+        for C, P in layers2:
+            check(n, C, P)
+            check(2 * n, C, P)
+    for n in list(range(1, 257, 5)) + [255, 256]:
+        for C, P in layers5:
+            check(n, C, P)
+            check(2 * n, C, P)
+            check(2 * n, C, P, b8=True)
+    check(129 * 512, 3, 1024)
+    check(129 * 512, 32, 1024)
+    for N, parts in ((49, 64), (98, 64), (66048, 1366), (1, 1), (5, 5), (0, 3)):
+        pos = 0
+        for j in range(parts):
+            assert L.jvae_image_range(N, parts, j, nb, ne) == 0
+            assert 0 <= nb.value <= ne.value <= N
+            pos += ne.value - nb.value
+        assert pos == N
+    assert empties > 0          # the sweep really contains plans with empty trailing parts
+    assert L.jvae_image_range(4, 0, 0, nb, ne) < 0 and L.jvae_image_range(4, 2, 2, nb, ne) < 0
+
+
 def test_layer_dsl_shapes():
     from module.vae_layers.conv import build_de_conv_layers, find_input_shape, parse_conv_layer_name
     f = build_de_conv_layers((3, 32, 32), 'conv32', batch_norm=True)
