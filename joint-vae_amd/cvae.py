@@ -385,9 +385,22 @@ class ClassificationVariationalNetwork(nn.Module):
 
     @property
     def max_batch_sizes(self):
-        """The reference hard-wires {'train': 32, 'test': 32} (cvae.py:1145-1147); with 288 GB of
-        HBM the honest bound is far beyond any batch this model is trained with."""
-        return {'train': 1 << 16, 'test': 1 << 16}
+        """The reference hard-wires {'train': 32, 'test': 32} (cvae.py:1145-1147) after a halving search
+        (cvae.py:1087-1143).  Here the bounds follow from the tensors themselves (powers of two, as the search returns):
+        train - the decoder batch (L+1)*N times the widest activation stays below 2^31 elements (one launch chain, every
+        activation kept for backward: ~3 MB per image of config 2, 50 GB at the bound); test - the label-free evaluation
+        decodes in slabs (`_decode`), so only the returned reconstruction (L_test+1, N, ...) must stay below 2^31 elements."""
+        def pow2_below(v):
+            v = max(int(v), 1)
+            return 1 << (v.bit_length() - 1)
+        lim = (1 << 31) - 1
+        if not self.x_is_generated:
+            return {'train': 1 << 16, 'test': 1 << 16}
+        wide = self._widest_decoder_activation()
+        reco = int(np.prod(self._reco_shape()))
+        train = pow2_below(lim // ((self._latent_samplings['train'] + 1) * wide))
+        test = pow2_below(lim // ((self._latent_samplings['eval'] + 1) * reco))
+        return {'train': min(train, 1 << 16), 'test': min(test, 1 << 16)}
 
     # ------------------------------------------------------------------------------------ forward
     def _features_of(self, x):
@@ -420,11 +433,46 @@ class ClassificationVariationalNetwork(nn.Module):
         """Per-sample shape of the decoder output: the image, or (256, C, H, W) level logits for a categorical decoder."""
         return self.input_shape if self.output_distribution != 'categorical' else (256, *self.input_shape)
 
+    # largest activation of one launch chain of the label-free evaluation, in elements: keeps every tensor on that path far
+    # below 2^31 elements and the working set of the (L+1)*N decoder batch bounded (the reference bounds the same thing by
+    # halving the evaluation batch until it fits, cvae.py:1087-1153)
+    EVAL_SLAB_ELEMENTS = 1 << 28
+
+    def _widest_decoder_activation(self):
+        """Elements per image of the widest tensor between z and the reconstruction."""
+        widths = [int(np.prod(self._reco_shape()))]
+        for stack in (self.decoder, self.imager):
+            for m in stack.modules():
+                if isinstance(m, nn.Linear):
+                    widths.append(m.out_features)
+            for sh in getattr(stack, 'shapes', None) or []:
+                widths.append(int(np.prod(sh)))
+        return max(widths)
+
+    def _eval_slab_rows(self):
+        env = os.environ.get('JVAE_EVAL_SLAB_ROWS')                 # tests: force many small slabs
+        if env:
+            return max(int(env), 1)
+        return max(self.EVAL_SLAB_ELEMENTS // self._widest_decoder_activation(), 1)
+
+    def _decode_rows(self, z):
+        u = self.decoder(z)
+        return self.imager(u.reshape(-1, *self.imager.input_shape))
+
     def _decode(self, z):
         x_ = None
         if self.x_is_generated:
-            u = self.decoder(z)
-            x_ = self.imager(u.reshape(-1, *self.imager.input_shape))
+            rows = z.numel() // z.shape[-1]
+            slab = self._eval_slab_rows()
+            if rows > slab and not torch.is_grad_enabled() and not self.training:
+                # evaluation (running-statistics BatchNorm: decoder rows are independent): slabs of rows through the
+                # decoder, each written into its place of the one (rows, ...) reconstruction the caller returns
+                zf = z.reshape(rows, z.shape[-1])
+                x_ = torch.empty((rows, *self._reco_shape()), device=z.device, dtype=torch.float32)
+                for r0 in range(0, rows, slab):
+                    x_[r0:r0 + slab].copy_(self._decode_rows(zf[r0:r0 + slab]).view(-1, *self._reco_shape()))
+            else:
+                x_ = self._decode_rows(z)
         if self.classifier_type in ('linear', None):
             logits = self.classifier(z)
         else:                                   # 'softmax': logits from the dictionary itself (cvae.py:498-499)

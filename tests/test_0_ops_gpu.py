@@ -192,7 +192,7 @@ def test_batchnorm_train(N, C, P, relu):
     rm, rv = torch.randn(C, generator=g), torch.rand(C, generator=g) + 0.5
     xr, gr, br = (t.clone().requires_grad_(True) for t in (x, gamma, beta))
     rmr, rvr = rm.clone(), rv.clone()
-    yr = F.batch_norm(xr, rmr, rvr, gr, br, True, 0.1, 1e-5)
+    yr = pre = F.batch_norm(xr, rmr, rvr, gr, br, True, 0.1, 1e-5)
     if relu:
         yr = torch.relu(yr)
     gy = torch.randn(yr.shape, generator=g)
@@ -204,7 +204,13 @@ def test_batchnorm_train(N, C, P, relu):
     assert rel(yd, yr) < 1e-5
     assert rel(rmd, rmr) < 1e-6 and rel(rvd, rvr) < 1e-5 and int(nbt) == 1
     yd.backward(gy.to(DEV))
-    assert rel(xd.grad, xr.grad) < 1e-4
+    # Two fp32 evaluations of the pre-activation differ by ~1e-6: among millions of elements a few sit that close to the ReLU
+    # threshold and take the other branch (an isolated difference of one dy element, not an error of the kernel).  Those
+    # elements - never more than a handful - are left out of the element-wise comparison of dx.
+    near = (pre.detach().abs() < 2e-5) if relu else torch.zeros_like(pre, dtype=torch.bool)
+    assert int(near.sum()) <= max(8, x.numel() // 20000)
+    keep = (~near).float()
+    assert rel(xd.grad.cpu() * keep, xr.grad * keep) < 1e-4
     assert rel(gd.grad, gr.grad) < 1e-4 and rel(bd.grad, br.grad) < 1e-4
     # eval mode uses the running statistics
     ye = ops.batchnorm_act(xd.detach(), gd.detach(), bd.detach(), rmd, rvd, nbt, False, relu)

@@ -705,6 +705,42 @@ def test_label_free_evaluation_with_coded_labels_is_refused_like_the_reference_f
     assert tuple(out[2]['total'].shape) == (8,)
 
 
+def test_label_free_evaluation_decodes_in_slabs(monkeypatch):
+    """The (L+1)*N decoder batch of evaluate(x) goes through the decoder in slabs of rows (bounded memory, no tensor near
+    2^31 elements; the reference bounds the same pass by halving the batch, cvae.py:1087-1153).  Running-statistics
+    BatchNorm makes rows independent, so a run cut into ragged 7-row slabs must equal the one-slab run BIT FOR BIT; in
+    train mode (batch statistics over the whole decoder batch) the slab path must not be taken."""
+    case = dict(get_case('e2_n8_L3'))
+    net = build(case)
+    net.eval()
+    kw = case['net']
+    N, L = 10, net.latent_sampling
+    x, y, eps = det_inputs(N, kw['input_shape'], kw['num_labels'], L, kw['latent_dim'], seed=5)
+    xd, ed = x.to(DEV), eps.to(DEV)
+    with torch.no_grad():
+        whole = net.evaluate(xd, epsilon=ed)
+    calls = []
+    orig = net._decode_rows
+    monkeypatch.setattr(net, '_decode_rows', lambda z: (calls.append(z.shape[0]), orig(z))[1])
+    monkeypatch.setenv('JVAE_EVAL_SLAB_ROWS', '7')
+    with torch.no_grad():
+        slabbed = net.evaluate(xd, epsilon=ed)
+    rows = (L + 1) * N
+    assert calls == [7] * (rows // 7) + ([rows % 7] if rows % 7 else [])
+    assert torch.equal(whole[0], slabbed[0]) and torch.equal(whole[1], slabbed[1])
+    for k in whole[2]:
+        assert torch.equal(whole[2][k], slabbed[2][k]), k
+    del calls[:]
+    net.train()
+    with torch.no_grad():
+        net.evaluate(xd, epsilon=torch.cat([ed[:1], ed[1:2]]))
+    assert calls == [2 * N]                     # train mode: one pass over the whole decoder batch
+    mb = net.max_batch_sizes
+    assert mb['train'] & (mb['train'] - 1) == 0 and mb['test'] & (mb['test'] - 1) == 0
+    assert (net._latent_samplings['eval'] + 1) * mb['test'] * 3072 < 2 ** 31 <= (net._latent_samplings['eval'] + 1) * 2 * mb['test'] * 3072 \
+        or mb['test'] == 1 << 16
+
+
 def test_accuracy_loop_records_and_recovers(tmp_path):
     """accuracy() (cvae.py:1187-1452) over a synthetic test set: per-method accuracies, `testing` bookkeeping, the
     per-sample losses recorded into `record-<set>.pth` in the reference's format (the file layout itself is

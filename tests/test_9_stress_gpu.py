@@ -54,8 +54,16 @@ def test_eval_path_at_full_size_n512_l128():
     N, L, K, C = 512, 128, kw['latent_dim'], kw['num_labels']
     x, y, eps = det_inputs(N, kw['input_shape'], C, L, K, seed=11)
     xd, ed = x.to(DEV), eps.to(DEV)
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
     with torch.no_grad():
         x_reco, y_est, losses, meas = net.evaluate(xd, epsilon=ed)
+    torch.cuda.synchronize()
+    peak = torch.cuda.max_memory_allocated() - base
+    # bounded memory: the 66 048-image decoder batch runs in slabs of 8 192 images (cvae._decode); unslabbed it needs ~27 GB
+    assert peak < 8 * 2 ** 30, peak / 2 ** 30
+    assert net._eval_slab_rows() == 8192 and net.max_batch_sizes['test'] == 4096
     assert tuple(x_reco.shape) == (L + 1, N, 3, 32, 32) and tuple(losses['iws'].shape) == (C, N)
     assert all(bool(torch.isfinite(v).all()) for v in losses.values())
     pick = torch.tensor([0, 7, 100, 255, 256, 300, 444, 511])
