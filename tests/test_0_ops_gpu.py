@@ -224,7 +224,7 @@ def test_channel_sum_ragged_partitions(N, C, P):
     from jvae_hip import ops
     g = torch.Generator().manual_seed(N)
     t = torch.randn(N, C, P, generator=g)
-    out = ops.channel_sum(t.to(DEV))
+    out = ops.channel_sum(t.to(DEV), N, C, P)
     assert rel(out, t.double().sum((0, 2)).float()) < 1e-5
 
 

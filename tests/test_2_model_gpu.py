@@ -721,7 +721,7 @@ def test_label_free_evaluation_decodes_in_slabs(monkeypatch):
         whole = net.evaluate(xd, epsilon=ed)
     calls = []
     orig = net._decode_rows
-    monkeypatch.setattr(net, '_decode_rows', lambda z: (calls.append(z.shape[0]), orig(z))[1])
+    monkeypatch.setattr(net, '_decode_rows', lambda z: (calls.append(z.numel() // z.shape[-1]), orig(z))[1])
     monkeypatch.setenv('JVAE_EVAL_SLAB_ROWS', '7')
     with torch.no_grad():
         slabbed = net.evaluate(xd, epsilon=ed)
