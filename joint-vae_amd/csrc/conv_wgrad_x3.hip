@@ -62,13 +62,7 @@ struct WgX3Geom {
     // layout put all blocks on the same banks: 4-way conflicts, LDS-bound; profiles/r02_wgrad_x3_pmc_v1.json).
     static constexpr int WP = (WS - 1) * S + 5;
     static constexpr int WPH = (WP + 1) / 2;
-    // One-plane form (bf16 operands): each fragment read feeds 2 MFMAs instead of 12, so the LDS - not the matrix pipe - is the
-    // limit, and the 2-way conflict of the transposed reads counts (profiles/r02_wgrad_b8_pmc_v1.json: conflict ratio 0.58, MFMA
-    // busy 35 %): the two 16-lane groups of a 32-lane access read pixels 8 slots apart = the same banks.  SWZ swaps the two
-    // 32-byte halves of a slot (blocks {0,1} <-> {2,3}) in slots whose index has bit 3 set, for Q and for Ps; with the row
-    // pitch a multiple of 16 slots that bit is a constant of the LANE (its 16-lane group), whatever the tap, tile or K step.
-    static constexpr bool SWZ = NPL == 1 && MODE == 0 && S == 1 && WS >= 16;
-    static constexpr int WPS = SWZ ? (WP + 15) / 16 * 16 : (S == 1 ? WP : 2 * WPH);          // slots per row
+    static constexpr int WPS = S == 1 ? WP : 2 * WPH;          // slots per row
     static constexpr int CH = ROWS * WPS;                      // slots per plane
     static constexpr int NCBQ = MODE == 0 ? 4 : (MODE == 2 ? 2 : 1);   // 8-channel blocks of Q staged per item
     static constexpr int QS = NCBQ * CH;                       // units per plane
@@ -90,22 +84,29 @@ __device__ __forceinline__ bf16x8 tr_pair(const unsigned char* base, int off) {
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-// the same with an explicit address for the second group of 4 pixels (swizzled image: its half may differ)
-__device__ __forceinline__ bf16x8 tr_pair2(const unsigned char* base, int off_lo, int off_hi) {
-    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(base + off_lo));
-    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(base + off_hi));
-    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-}
-
 // SH16: the products run on v_mfma_f32_16x16x32_bf16 (K step = 32 pixels, a 32 x 32 tile = 2 x 2 blocks of 16 x 16) instead of
 // v_mfma_f32_32x32x16_bf16: the same LDS image, the same reads and MFMA cycles per FLOP; the chip holds a higher clock under
 // the 16x16x32 shape (MI355X_MICROARCH.md, DVFS give-back item 7).  JVAE_WGRAD_SH16=0 selects the 32x32x16 form (A/B).
 // NPL = 1: the operands are bf16 "B8" tensors (conv_b8.hip: 16-byte units of 8 channels per pixel - exactly the units of the
 // LDS image): no split, ONE plane, one MFMA per product; everything else (LDS image, transposed reads, read-ahead, slabs) is
 // shared with the split-bf16 form.  This is the weight-gradient kernel of the bf16 mode (BASELINE configs[4]).
+//
+// SWZ (16x16x32 form, 32 channels b x 1 tap, stride 1, maps of 16 / 32 / 64; both the split and the one-plane form).  The two
+// 16-lane groups of a 32-lane transposed read fetch 4-pixel blocks 8 slots apart = 512 bytes = the same banks: a 2-way conflict
+// (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.58 in the one-plane form, profiles/r02_wgrad_b8_pmc_v1.json; 0.49 in the split
+// form, profiles/r02_wgrad_x3_pmc.json).  The image therefore swaps the two 32-byte halves of a slot (channel blocks {0,1} <->
+// {2,3}) in slots whose COLUMN (padded column for Q, pixel index for Ps) has bit 3 set, and the K index of the MFMA is dealt to
+// the lanes so that a lane never needs two different halves: the MFMA only requires that A and B agree on which pixel a K
+// index is, so lane group g supplies the 4-pixel blocks {0,2,1,3}[g] and that + 4 (16 pixels = 16 slots or one row further:
+// bit 3 of the column unchanged) of each 32-pixel K step.  The groups of one 32-lane access then sit 8 columns apart (opposite
+// halves, whatever the tap shift), a lane's two reads share ONE address (+ an immediate), and the half is a constant of
+// (lane, tap) folded into the tile's byte offset; the second 16-channel block is that offset ^ 32.  Keyed on the column, not
+// the slot index, the swizzle needs no padded row pitch (round 2's one-plane version padded it to 16 slots, which the three
+// planes of the split form cannot afford within 80 KB).
 template <int S, int WS, int MODE, bool AFF, bool SH16, int NPL = 3>
 __global__ __launch_bounds__(256, 2) void conv5_wgrad_x3_kernel(WgX3P p) {
     using G = WgX3Geom<S, WS, MODE, NPL>;
+    constexpr bool SWZ = SH16 && MODE == 0 && S == 1 && WS >= 16;
     static_assert(NPL == 3 || (NPL == 1 && SH16), "one-plane form: 16x16x32 shape only");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     u32x4* Qs = reinterpret_cast<u32x4*>(lds_raw);             // [NPL planes][QS]
@@ -157,11 +158,11 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_x3_kernel(WgX3P p) {
     // 16x16x32 roles: 16-lane group g16 = K group (8 pixels), the lanes of a group supply (pixel q4, channel quad pp) of a
     // 16-channel block chosen per MFMA (rb for Ps, cb for the columns)
     const int g16 = lane >> 4, c16 = lane & 15;
-    const int pl16 = 8 * g16 + q4;                             // pixel of this lane inside a 32-pixel K step
+    // pixel of this lane inside a 32-pixel K step (its second four pixels: + 4, swizzled image: + 16)
+    const int pl16 = SWZ ? 4 * ((g16 >> 1) | (g16 & 1) << 1) + q4 : 8 * g16 + q4;
     const int aoff16 = (pl16 * 4 + (pp >> 1)) * 16 + (pp & 1) * 8;        // + rb * 32 bytes
     const int lane_pix16 = (pl16 / WS) * S * G::WPS + (pl16 % WS);
     int boff16[SH16 ? G::NBT : 1][MODE == 0 ? 1 : 2];      // MODE 0: the second column block is 2 units (32 bytes) further
-    int boffh[G::SWZ ? G::NBT : 1], steph[G::SWZ ? G::NBT : 1];   // swizzled image: the read of the lane's second 4 pixels
     if (SH16) {
 #pragma unroll
         for (int t = 0; t < G::NBT; ++t)
@@ -176,20 +177,15 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_x3_kernel(WgX3P p) {
                 const int kw = tap % 5;
                 const int tslot = S == 1 ? kw : (kw & 1) * G::WPH + (kw >> 1);
                 const int slot = lane_pix16 + (tap / 5) * G::WPS + tslot;
-                if (G::SWZ) {
-                    // bit 3 of the slot index: g16 & 1 for the lane's first 4 pixels (q4 + kw <= 7: no carry), possibly flipped
-                    // for the second 4 (slot + 4); everything else in the index is a multiple of 16
-                    const int bl = g16 & 1, bh = ((g16 & 1) * 8 + q4 + kw + 4) >> 3 & 1;
-                    boff16[t][cb] = (slot * G::NCBQ + (blk ^ (bl << 1))) * 16 + (pp & 1) * 8;
-                    boffh[t] = ((slot + 4) * G::NCBQ + (blk ^ (bh << 1))) * 16 + (pp & 1) * 8;
-                    steph[t] = bh ? -32 : 32;
+                if (SWZ) {
+                    const int bit = ((pl16 % WS) + kw) >> 3 & 1;       // bit 3 of the padded column (both reads of the lane)
+                    boff16[t][cb] = (slot * G::NCBQ + (blk ^ (bit << 1))) * 16 + (pp & 1) * 8;
                 } else {
                     boff16[t][cb] = (slot * G::NCBQ + blk) * 16 + (pp & 1) * 8;
                 }
             }
     }
-    const int cbstep = (G::SWZ && (g16 & 1)) ? -32 : 32;       // MODE 0: byte distance of the second column block
-    const int aswz = (G::SWZ && (g16 & 1)) ? 32 : 0;           // Ps: row block rb sits at (rb ^ bit) * 32 bytes
+    const int aswz = (SWZ && (pl16 >> 3 & 1)) ? 32 : 0;        // Ps: row block rb sits at (rb ^ bit 3 of the pixel) * 32 bytes
 
     f32x16 acc[SH16 ? 1 : G::NBT];
     f32x4 acc16[SH16 ? G::NBT : 1][2][2];
@@ -224,6 +220,8 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_x3_kernel(WgX3P p) {
     // Loads are unconditional (out-of-range items read a valid stand-in address and are zeroed when they are stored to
     // LDS) so that the compiler can count the loads in flight.
     auto gload = [&](int item) {
+        int tid = threadIdx.x;
+        if constexpr (NPL == 3) asm volatile("" : "+v"(tid));    // as in lstore
         const int n = item / G::TILES, tile = item % G::TILES;
         const int row0 = tile * G::TH;
         const int in_row0 = row0 * S - p.P;
@@ -298,6 +296,10 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_x3_kernel(WgX3P p) {
         }
     };
     auto lstore = [&](int item) {                  // item: the work item whose data sits in rq / rp
+        // (opaque copy of the thread index, split form: the LDS addresses are re-derived per item instead of being hoisted
+        // out of the image loop into registers this kernel does not have)
+        int tid = threadIdx.x;
+        if constexpr (NPL == 3) asm volatile("" : "+v"(tid));
         const int in_row0 = (item % G::TILES) * G::TH * S - p.P;
         if constexpr (NPL == 1) {
 #pragma unroll
@@ -313,7 +315,7 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_x3_kernel(WgX3P p) {
                     const int c0 = p.P + x;
                     const int sl = S == 1 ? c0 : (c0 & 1) * G::WPH + (c0 >> 1);
                     const int slot = lr * G::WPS + sl;
-                    Qs[slot * G::NCBQ + (G::SWZ ? c ^ ((slot >> 3 & 1) << 1) : c)] = v;
+                    Qs[slot * G::NCBQ + (SWZ ? c ^ ((sl >> 3 & 1) << 1) : c)] = v;
                 }
             }
 #pragma unroll
@@ -325,7 +327,7 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_x3_kernel(WgX3P p) {
                     u32x4 v = live ? rp8[k] : u32x4{0u, 0u, 0u, 0u};
                     if (AFF && p.aff_p.sc && live)
                         v = aff8(v, &ctab[(G::NCBQ + c) * 8], &ctab[NT8 + (G::NCBQ + c) * 8], p.aff_p.relu);
-                    Pt[px * 4 + (G::SWZ ? c ^ ((px >> 3 & 1) << 1) : c)] = v;
+                    Pt[px * 4 + (SWZ ? c ^ ((px >> 3 & 1) << 1) : c)] = v;
                 }
             }
             return;
@@ -341,8 +343,9 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_x3_kernel(WgX3P p) {
                 const bool live = ir >= 0 && ir < HB;          // padding rows / missing channels stay exact zeros
                 const int c0 = p.P + 2 * xp, c1 = c0 + 1;      // padded columns of the two pixels
                 const int s0 = S == 1 ? c0 : (c0 & 1) * G::WPH + (c0 >> 1), s1 = S == 1 ? c1 : (c1 & 1) * G::WPH + (c1 >> 1);
+                const int z0 = SWZ ? (s0 >> 3 & 1) << 1 : 0, z1 = SWZ ? (s1 >> 3 & 1) << 1 : 0;    // swizzle: keyed on the column
                 split_store(rq[k], live, p.Cb - (cbq0 + c) * 8, AFF ? &ctab[c * 8] : ctab, AFF ? &ctab[NT8 + c * 8] : ctab, p.aff_q.relu,
-                            p.aff_q.sc != nullptr, &Qs[(lr * G::WPS + s0) * G::NCBQ + c], &Qs[(lr * G::WPS + s1) * G::NCBQ + c], G::QS);
+                            p.aff_q.sc != nullptr, &Qs[(lr * G::WPS + s0) * G::NCBQ + (c ^ z0)], &Qs[(lr * G::WPS + s1) * G::NCBQ + (c ^ z1)], G::QS);
             }
         }
 #pragma unroll
@@ -350,8 +353,9 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_x3_kernel(WgX3P p) {
             const int u = tid + k * 256;
             if (u < G::PITEMS) {
                 const int c = u % 4, px2 = u / 4;
+                const int zp = SWZ ? (px2 >> 2 & 1) << 1 : 0;      // bit 3 of the pixel index (shared by the two pixels)
                 split_store(rp[k], true, p.Ca - (a0 + c * 8), AFF ? &ctab[(G::NCBQ + c) * 8] : ctab, AFF ? &ctab[NT8 + (G::NCBQ + c) * 8] : ctab,
-                            p.aff_p.relu, p.aff_p.sc != nullptr, &Pt[(2 * px2) * 4 + c], &Pt[(2 * px2 + 1) * 4 + c], G::PS);
+                            p.aff_p.relu, p.aff_p.sc != nullptr, &Pt[(2 * px2) * 4 + (c ^ zp)], &Pt[(2 * px2 + 1) * 4 + (c ^ zp)], G::PS);
             }
         }
     };
@@ -373,19 +377,20 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_x3_kernel(WgX3P p) {
                 for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
                     for (int plane = 0; plane < NPL; ++plane)
-                        a[rb][plane] = tr_pair<256>(Pb + plane * G::PS * 16, aoff16 + (rb * 32 ^ aswz) + ks * 32 * 64);
+                        a[rb][plane] = tr_pair<SWZ ? 1024 : 256>(Pb + plane * G::PS * 16, aoff16 + (rb * 32 ^ aswz) + ks * 32 * 64);
             };
             auto read_b = [&](int ks, int slot, bf16x8 (&d)[NPL]) {
                 const int pix0 = ks * 32;
                 const int qoff = ((pix0 / WS) * S * G::WPS + (pix0 % WS)) * G::NCBQ * 16;
+                // second four pixels of the lane: 16 pixels further = 16 slots (maps of 32 / 64) or one row (maps of 16)
+                constexpr int HI16 = (WS >= 32 ? 16 : G::WPS) * G::NCBQ * 16;
 #pragma unroll
                 for (int plane = 0; plane < NPL; ++plane) {
-                    if constexpr (G::SWZ)
-                        d[plane] = tr_pair2(Qb + plane * G::QS * 16, boff16[slot >> 1][0] + (slot & 1) * cbstep + qoff,
-                                            boffh[slot >> 1] + (slot & 1) * steph[slot >> 1] + qoff);
+                    if constexpr (SWZ)
+                        d[plane] = tr_pair<HI16>(Qb + plane * G::QS * 16, ((slot & 1) ? boff16[slot >> 1][0] ^ 32 : boff16[slot >> 1][0]) + qoff);
                     else
                         d[plane] = tr_pair<64 * G::NCBQ>(Qb + plane * G::QS * 16,
-                                                         (MODE == 0 ? boff16[slot >> 1][0] + (slot & 1) * cbstep : boff16[slot >> 1][slot & 1]) + qoff);
+                                                         (MODE == 0 ? boff16[slot >> 1][0] + (slot & 1) * 32 : boff16[slot >> 1][slot & 1]) + qoff);
                 }
             };
             read_a(0);
