@@ -75,6 +75,20 @@ int jvae_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, float* dbi
                           int N, int Cin, int H, int W, int Cout, int KH, int KW, int S, int P, int OP, int transposed,
                           void* ws, size_t ws_bytes, void* stream);
 
+/* ---- per-step cache of the re-packed convolution weights (csrc/pack_cache.hip; no reference counterpart: PyTorch re-lays
+ * weights out inside its conv library).  The 5x5 kernels read their weights in a packed operand layout that depends on the
+ * weights only; the host brackets the span in which the weights are constant (evaluate() ... backward of cvae.py:2429-2461):
+ * begin() re-packs every registered (weight, layout) pair in ONE launch and arms the lookups, the convolution entry points then
+ * skip their own pack launch, end() disarms (the optimiser is about to change the weights).  Outside a bracket every convolution
+ * packs for itself, as without a cache.  configure(): caller-owned persistent device buffer (256-byte aligned; NULL = off);
+ * owner: a value that changes whenever the set of weight ADDRESSES in use changes (entries of another owner are dropped before
+ * the refresh reads them).  stats(): host-side counters for tests. */
+int jvae_pack_cache_configure(void* buf, size_t bytes);
+int jvae_pack_cache_begin(void* stream, long long owner);
+int jvae_pack_cache_end(void);
+int jvae_pack_cache_reset(void);
+int jvae_pack_cache_stats(int* entries, long long* hits, long long* misses, long long* refreshes);
+
 /* out[c] (+)= sum_{n,q} t[n][c][q]: bias gradient of a conv (P = OH*OW) or linear (P = 1) layer. */
 size_t jvae_channel_sum_workspace_bytes(int C);
 int jvae_channel_sum_f32(const float* t, float* out, int N, int C, int P, int accumulate, void* ws, size_t ws_bytes,

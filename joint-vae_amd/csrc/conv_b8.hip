@@ -14,6 +14,7 @@
 #include "common.h"
 #include "jvae_internal.h"
 #include "conv_b8.h"
+#include "pack_elems.h"
 
 namespace {
 
@@ -107,19 +108,8 @@ __global__ void b8_channel_fold_kernel(const float* __restrict__ partial, float*
 __global__ __launch_bounds__(256) void b8_wpack_kernel(const float* __restrict__ w, __bf16* __restrict__ wp,
                                                        int C, int O, int KB, int OP, int swap, int flip) {
     const long total = (long)KB * 25 * 2 * OP * 8;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int ci = (int)(i % 8);
-        long t = i / 8;
-        const int o = (int)(t % OP); t /= OP;
-        const int half = (int)(t % 2); t /= 2;
-        const int tap = (int)(t % 25);
-        const int kb = (int)(t / 25);
-        const int c = kb * 16 + half * 8 + ci;
-        const int st = flip ? 24 - tap : tap;
-        float v = 0.f;
-        if (c < C && o < O) v = swap ? w[((long)c * O + o) * 25 + st] : w[((long)o * C + c) * 25 + st];
-        wp[i] = (__bf16)v;
-    }
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
+        jvae_pack_b8_elem(w, wp, i, C, O, swap, flip);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -439,8 +429,15 @@ int jvae_conv5_b8_wpack(const float* w, void* wp, int C, int O, int swap, int fl
 int jvae_conv5_b8_fwd(const void* in, const float* w, int swap, int flip, const float* bias, void* out, int out_f32,
                       int N, int Cin, int H, int W, int Cout, int OW, int S, int P, void* ws, hipStream_t st,
                       float* stats, int* nsplit, const InAff* aff) {
-    int rc = jvae_conv5_b8_wpack(w, ws, Cin, Cout, swap, flip, st);
-    if (rc) return rc;
+    {
+        bool fresh = true;
+        void* slot = jvae_pack_cache_get(JVAE_PACK_B8, w, Cin, Cout, swap, flip, &fresh);
+        if (slot) ws = slot;
+        if (!slot || !fresh) {
+            int rc = jvae_conv5_b8_wpack(w, ws, Cin, Cout, swap, flip, st);
+            if (rc) return rc;
+        }
+    }
     B8FwdP p{(const u32x4*)in, (const u32x4*)ws, bias, out, N, (Cin + 7) / 8, H, W, (Cout + 31) / 32 * 32, P,
              Cout, (Cout + 7) / 8, stats, out_f32, aff ? *aff : InAff{nullptr, nullptr, 0}};
     struct Fin { int* n; ~Fin() { if (n) *n = g_b8_splits; } } fin{nsplit};

@@ -4,6 +4,7 @@
 // conv32 / deconv32; everything else (7x7, 8x8, 3x3, 4x4 heads, odd sizes) takes the unfold + GEMM path.
 #include "common.h"
 #include "conv_dispatch.h"
+#include "pack_elems.h"
 
 namespace {
 
@@ -22,12 +23,20 @@ inline bool fold_bwd_fast_s1(const ConvGeom& g) {
 inline bool fold_bwd_fast_s2(const ConvGeom& g) {
     return jvae_convt2_ok(g.Cs, g.Hs, g.Ws, g.Cb, g.Hb, g.Wb, g.KH, g.KW, g.S, g.P);
 }
+// fp32 operand of the 4-phase kernel: the step's cache slot (pack_cache.hip) or the call's workspace; nullptr: launch error
+inline const float* packed_f32(const float* w, float* ws, int C, int O, int swap, int flip, hipStream_t st) {
+    bool fresh = true;
+    float* slot = (float*)jvae_pack_cache_get(JVAE_PACK_F32, w, C, O, swap, flip, &fresh);
+    if (slot && fresh) return slot;
+    float* dst = slot ? slot : ws;
+    return jvae_conv5_pack(w, dst, C, O, swap, flip, st) == 0 ? dst : nullptr;
+}
 inline int run_t2(const ConvGeom& g, const float* small, const float* w, const float* bias, float* big, float* ws,
                   hipStream_t st) {
     if (jvae_convt2_x3_ok(g.Cs, g.Ws, g.Cb)) return jvae_convt2_x3(small, w, bias, big, g.N, g.Cs, g.Ws, g.Cb, ws, st);
-    int rc = jvae_conv5_pack(w, ws, g.Cs, g.Cb, 1, 0, st);
-    if (rc) return rc;
-    return jvae_convt2(small, ws, bias, big, g.N, g.Cs, g.Ws, g.Cb, st);
+    const float* wp = packed_f32(w, ws, g.Cs, g.Cb, 1, 0, st);
+    if (!wp) return JVAE_EINVAL;
+    return jvae_convt2(small, wp, bias, big, g.N, g.Cs, g.Ws, g.Cb, st);
 }
 
 // Transposed convolution of a 1x1 input with no padding (imager.0 of deconv32: 64 x 1 x 1 -> 64 x 8 x 8): the
@@ -104,9 +113,9 @@ int jvae_conv_fwd(const ConvGeom& g, int transposed, const float* x, const float
     if (fold_bwd_fast_s2(g) && ws_bytes >= 4 * jvae_conv5_pack_floats(g.Cs, g.Cb)) {
         if (jvae_convt2_x3_ok(g.Cs, g.Ws, g.Cb))
             return jvae_convt2_x3(x, w, bias, y, g.N, g.Cs, g.Ws, g.Cb, ws, st, stats, nsplit, aff);
-        int rc = jvae_conv5_pack(w, ws, g.Cs, g.Cb, 1, 0, st);
-        if (rc) return rc;
-        return jvae_convt2(x, ws, bias, y, g.N, g.Cs, g.Ws, g.Cb, st, stats, nsplit, aff);
+        const float* wp = packed_f32(w, ws, g.Cs, g.Cb, 1, 0, st);
+        if (!wp) return JVAE_EINVAL;
+        return jvae_convt2(x, wp, bias, y, g.N, g.Cs, g.Ws, g.Cb, st, stats, nsplit, aff);
     }
     if (aff) return JVAE_ENOTSUP;
     return jvae_fold_bwd(g, x, w, bias, y, ws, ws_bytes, st);

@@ -23,6 +23,7 @@
 #include "common.h"
 #include "jvae_internal.h"
 #include "conv_dispatch.h"
+#include "pack_elems.h"
 
 namespace {
 
@@ -252,13 +253,8 @@ __global__ __launch_bounds__(256, 2) void conv5_fwd_kernel(FwdP p) {
 __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ w, float* __restrict__ wp,
                                                    int C, int O, int OP, int swap, int flip) {
     const int total = C * 25 * OP;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        const int o = i % OP, tap = (i / OP) % 25, c = i / (OP * 25);
-        const int st = flip ? 24 - tap : tap;
-        float v = 0.f;
-        if (o < O) v = swap ? w[((long)c * O + o) * 25 + st] : w[((long)o * C + c) * 25 + st];
-        wp[i] = v;
-    }
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x)
+        jvae_pack_f32_elem(w, wp, i, C, O, swap, flip);
 }
 
 thread_local int g_last_splits = 0;     // grid.x of the last forward-type launch (host side, per call: read right after launching)
@@ -330,8 +326,15 @@ int jvae_conv5_fwd(const float* in, const float* w, int swap, int flip, const fl
                    float* stats, int* nsplit, const InAff* aff) {
     if (jvae_conv5_x3_ok(Cin, H, W, Cout, OW, OW, S, P))      // stride-1 layers with >= 16 input channels: conv_x3.hip
         return jvae_conv5_x3_fwd(in, w, swap, flip, bias, out, N, Cin, H, W, Cout, OW, S, P, ws, st, stats, nsplit, aff);
-    int rc = jvae_conv5_pack(w, ws, Cin, Cout, swap, flip, st);
-    if (rc) return rc;
+    {   // packed weights: the step's cache slot (refreshed once per step, pack_cache.hip) or this call's workspace
+        bool fresh = true;
+        float* slot = (float*)jvae_pack_cache_get(JVAE_PACK_F32, w, Cin, Cout, swap, flip, &fresh);
+        if (slot) ws = slot;
+        if (!slot || !fresh) {
+            int rc = jvae_conv5_pack(w, ws, Cin, Cout, swap, flip, st);
+            if (rc) return rc;
+        }
+    }
     FwdP p{in, ws, bias, out, N, Cin, H, W, (Cout + 31) / 32 * 32, P, Cout, stats, aff ? *aff : InAff{nullptr, nullptr, 0}};
     struct Fin { int* n; ~Fin() { if (n) *n = g_last_splits; } } fin{nsplit};
     if (S == 1) {

@@ -13,6 +13,7 @@
 #include "common.h"
 #include "jvae_internal.h"
 #include "conv_b8.h"
+#include "pack_elems.h"
 
 namespace {
 
@@ -237,8 +238,15 @@ bool jvae_convt2_b8_ok(int C, int HS, int WS, int O, int HB, int WB, int KH, int
 // small (N, ceil(C/8), WS, WS, 8) --ConvT 5x5 s2 p2 op1--> big (N, ceil(O/8), 2WS, 2WS, 8); ws: packed weights
 int jvae_convt2_b8(const void* in, const float* w, const float* bias, void* out, int N, int C, int WS, int O,
                    void* ws, hipStream_t st, float* stats, int* nsplit, const InAff* aff) {
-    int rc = jvae_conv5_b8_wpack(w, ws, C, O, 1, 0, st);
-    if (rc) return rc;
+    {
+        bool fresh = true;
+        void* slot = jvae_pack_cache_get(JVAE_PACK_B8, w, C, O, 1, 0, &fresh);
+        if (slot) ws = slot;
+        if (!slot || !fresh) {
+            int rc = jvae_conv5_b8_wpack(w, ws, C, O, 1, 0, st);
+            if (rc) return rc;
+        }
+    }
     T2B8P p{(const u32x4*)in, (const u32x4*)ws, bias, (u32x2*)out, N, (C + 7) / 8, (O + 31) / 32 * 32, O, (O + 7) / 8, stats,
             aff ? *aff : InAff{nullptr, nullptr, 0}};
     struct Fin { int* n; ~Fin() { if (n) *n = g_t2b8_splits; } } fin{nsplit};

@@ -16,6 +16,7 @@
 #include "jvae_internal.h"
 #include "conv_dispatch.h"
 #include "conv_x3.h"
+#include "pack_elems.h"
 
 namespace {
 
@@ -305,8 +306,15 @@ bool jvae_convt2_x3_ok(int C, int WS, int O) {
 // w: the layer's weight read as [c][o][tap] (ConvTranspose2d layout / Conv2d dgrad); ws: jvae_conv5_x3_pack_bytes(C, O)
 int jvae_convt2_x3(const float* in, const float* w, const float* bias, float* out, int N, int C, int WS, int O, float* ws,
                    hipStream_t st, float* stats, int* nsplit, const InAff* aff) {
-    int rc = jvae_conv5_x3_wpack(w, ws, C, O, 1, 0, st);
-    if (rc) return rc;
+    {
+        bool fresh = true;
+        float* slot = (float*)jvae_pack_cache_get(JVAE_PACK_X3, w, C, O, 1, 0, &fresh);
+        if (slot) ws = slot;
+        if (!slot || !fresh) {
+            int rc = jvae_conv5_x3_wpack(w, ws, C, O, 1, 0, st);
+            if (rc) return rc;
+        }
+    }
     T2X3P p{in, (const u32x4*)ws, bias, out, N, C, O, stats, aff ? *aff : InAff{nullptr, nullptr, 0}};
     struct Fin { int* n; ~Fin() { if (n) *n = g_t2x3_splits; } } fin{nsplit};
     switch (WS) {

@@ -27,6 +27,7 @@
 #include "jvae_internal.h"
 #include "conv_dispatch.h"
 #include "conv_x3.h"
+#include "pack_elems.h"
 
 namespace {
 
@@ -39,24 +40,8 @@ typedef x3_f32x2 f32x2;
 __global__ __launch_bounds__(256) void x3_wpack_kernel(const float* __restrict__ w, __bf16* __restrict__ wp,
                                                        int C, int O, int KB, int OP, int swap, int flip) {
     const long total = (long)KB * 25 * 2 * OP * 8;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int ci = (int)(i % 8);
-        long t = i / 8;
-        const int o = (int)(t % OP); t /= OP;
-        const int half = (int)(t % 2); t /= 2;
-        const int tap = (int)(t % 25);
-        const int kb = (int)(t / 25);
-        const int kh = tap / 5, kw = tap % 5;
-        const int c = kb * 16 + half * 8 + ci;
-        const int st = flip ? 24 - tap : tap;
-        float v = 0.f;
-        if (c < C && o < O) v = swap ? w[((long)c * O + o) * 25 + st] : w[((long)o * C + c) * 25 + st];
-        __bf16 s[3];
-        x3_split(v, s[0], s[1], s[2]);
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-            wp[((((long)(kb * 5 + kh) * 30 + (pl * 5 + kw) * 2 + half) * OP) + o) * 8 + ci] = s[pl];
-    }
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
+        jvae_pack_x3_elem(w, wp, i, C, O, swap, flip);
 }
 
 struct X3P {
@@ -425,9 +410,14 @@ int jvae_conv5_x3_fwd(const float* in, const float* w, int swap, int flip, const
                       int N, int Cin, int H, int W, int Cout, int OW, int S, int P, float* ws, hipStream_t st,
                       float* stats, int* nsplit, const InAff* aff) {
     const int OP = (Cout + 31) / 32 * 32;
-    {
-        const int rc = jvae_conv5_x3_wpack(w, ws, Cin, Cout, swap, flip, st);
-        if (rc) return rc;
+    {   // split weights: the step's cache slot (refreshed once per step, pack_cache.hip) or this call's workspace
+        bool fresh = true;
+        float* slot = (float*)jvae_pack_cache_get(JVAE_PACK_X3, w, Cin, Cout, swap, flip, &fresh);
+        if (slot) ws = slot;
+        if (!slot || !fresh) {
+            const int rc = jvae_conv5_x3_wpack(w, ws, Cin, Cout, swap, flip, st);
+            if (rc) return rc;
+        }
     }
     X3P p{in, (const u32x4*)ws, bias, out, N, Cin, H, W, OP, P, Cout, stats, aff ? *aff : InAff{nullptr, nullptr, 0}};
     struct Fin { int* n; ~Fin() { if (n) *n = g_x3_splits; } } fin{nsplit};

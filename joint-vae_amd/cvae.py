@@ -28,6 +28,7 @@ import torch
 from torch import nn
 
 from jvae_hip import ops
+from jvae_hip import lib as _lib
 from module.optimizers import Optimizer
 from module.losses import x_loss, mse_loss, categorical_loss  # noqa: F401  (import surface of the reference)
 from module.vae_layers import Encoder, Classifier, Sigma, build_de_conv_layers, find_input_shape
@@ -508,7 +509,30 @@ class ClassificationVariationalNetwork(nn.Module):
         Returns (x_reco (L+1,N,..), y_est (N,C), batch_losses {name: (N,) tensor}, total_measures {name: float}
         [, mu, log_var, z]).  `epsilon` (L+1,N,K) optionally injects the reparameterisation noise.
         All Python floats of `total_measures` come from ONE packed device read-back.
-        """
+
+        The call opens a span in which the weights are constant (this forward and, in training, the backward that
+        follows, until Optimizer.step()): the packed operand forms of all convolution weights are refreshed by ONE launch
+        here instead of one launch in front of every convolution (jvae_hip/lib.py::pack_cache_begin)."""
+        self._pack_cache_begin(x)
+        try:
+            return self._evaluate(x, y, batch, current_measures, with_beta, kl_var_weighting, gamma_weighting, z_output,
+                                  epsilon, **kw)
+        finally:
+            if not (self.training and torch.is_grad_enabled()):
+                _lib.pack_cache_end()            # no backward will follow: stop vouching for the weights now
+
+    def _pack_cache_begin(self, x):
+        if not x.is_cuda:
+            return                               # the ops raise their own "no CPU fallback" error
+        ws = getattr(self, '_conv_weights', None)
+        if ws is None:
+            from module.vae_layers.conv import HipConv2d, HipConvTranspose2d
+            ws = self._conv_weights = [m.weight for m in self.modules() if isinstance(m, (HipConv2d, HipConvTranspose2d))]
+        # owner = the weight addresses themselves: .to(), a re-flattened optimiser buffer or another model all change it
+        _lib.pack_cache_begin(hash(tuple(w.data_ptr() for w in ws)), x.device)
+
+    def _evaluate(self, x, y=None, batch=0, current_measures=None, with_beta=False, kl_var_weighting=1.,
+                  gamma_weighting=1, z_output=False, epsilon=None, **kw):
         if y is None or self.is_vib:
             if self.is_vib:
                 return self._evaluate_vib(x, y, batch, current_measures, with_beta, kl_var_weighting, gamma_weighting,

@@ -5,7 +5,7 @@ op raises.  The library is built in-tree by `__graft_entry__.build()` / `make -C
 """
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_long, c_size_t, c_void_p, POINTER
+from ctypes import c_char_p, c_float, c_int, c_long, c_longlong, c_size_t, c_void_p, POINTER
 
 import torch
 
@@ -53,6 +53,11 @@ _SIGS = {
     'jvae_conv2d_affine_ok': (c_int, [c_int] * 11),
     'jvae_conv2d_fwd_aff_f32': (c_int, [P, P, P, P, P, POINTER(c_int), P, P, c_int] + [c_int] * 11 + [P, c_size_t, P]),
     'jvae_conv2d_wgrad_aff_f32': (c_int, [P, P, P, P, c_int, P, P, c_int] + [c_int] * 11 + [P, c_size_t, P]),
+    'jvae_pack_cache_configure': (c_int, [P, c_size_t]),
+    'jvae_pack_cache_begin': (c_int, [P, c_longlong]),
+    'jvae_pack_cache_end': (c_int, []),
+    'jvae_pack_cache_reset': (c_int, []),
+    'jvae_pack_cache_stats': (c_int, [POINTER(c_int), POINTER(c_longlong), POINTER(c_longlong), POINTER(c_longlong)]),
     'jvae_channel_sum_workspace_bytes': (c_size_t, [c_int]),
     'jvae_channel_sum_f32': (c_int, [P, P, c_int, c_int, c_int, c_int, P, c_size_t, P]),
     'jvae_bn_workspace_bytes': (c_size_t, [c_int]),
@@ -181,3 +186,43 @@ def workspace(nbytes, device):
     if ws is None or ws.numel() < nbytes:
         _workspaces[key] = ws = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
     return ws
+
+
+# ---- per-step cache of the re-packed convolution weights (csrc/pack_cache.hip) ---------------------------------------------
+PACK_CACHE_BYTES = int(os.environ.get('JVAE_PACK_CACHE_MB', '64')) << 20       # JVAE_PACK_CACHE_MB=0: off (A/B switch)
+_pack_cache = {}
+
+
+def pack_cache_begin(owner, device):
+    """Start of a span with constant weights (evaluate() ... backward): ONE launch on the current stream re-packs every
+    registered convolution weight, the convolutions of the span then skip their own pack launches.  `owner` changes
+    whenever the set of weight addresses changes (see jvae_pack_cache_begin)."""
+    if not PACK_CACHE_BYTES:
+        return
+    lib = load()
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx not in _pack_cache:
+        if _pack_cache:                           # one cache per process (one process per GPU): another device switches it off
+            check(lib.jvae_pack_cache_configure(None, 0), 'jvae_pack_cache_configure')
+            _pack_cache[idx] = None
+        else:
+            buf = torch.empty(PACK_CACHE_BYTES + 256, dtype=torch.uint8, device=device)
+            off = (-buf.data_ptr()) % 256
+            _pack_cache[idx] = buf
+            check(lib.jvae_pack_cache_configure(buf.data_ptr() + off, PACK_CACHE_BYTES), 'jvae_pack_cache_configure')
+    if _pack_cache[idx] is None:
+        return
+    check(lib.jvae_pack_cache_begin(stream_ptr(idx), owner), 'jvae_pack_cache_begin')
+
+
+def pack_cache_end():
+    """The weights are about to change (optimiser) or are no longer vouched for: convolutions pack per call again."""
+    if _lib is not None and _pack_cache:
+        _lib.jvae_pack_cache_end()
+
+
+def pack_cache_stats():
+    lib = load()
+    e, h, m, r = c_int(), c_longlong(), c_longlong(), c_longlong()
+    lib.jvae_pack_cache_stats(ctypes.byref(e), ctypes.byref(h), ctypes.byref(m), ctypes.byref(r))
+    return {'entries': e.value, 'hits': h.value, 'misses': m.value, 'refreshes': r.value}

@@ -347,6 +347,8 @@ class Optimizer:
             self._clip_pending = False
 
     def step(self):
+        from jvae_hip import lib as _lib
+        _lib.pack_cache_end()                    # the weights change below: packed operand forms are no longer valid
         self.reduce_gradients()
         self._adopt_new()
         if not self._groups:

@@ -741,6 +741,71 @@ def test_label_free_evaluation_decodes_in_slabs(monkeypatch):
         or mb['test'] == 1 << 16
 
 
+def test_pack_cache_is_transparent():
+    """csrc/pack_cache.hip: evaluate() opens a span of constant weights in which ONE launch refreshes the packed operand
+    forms of all convolution weights instead of one pack launch per convolution.  It must be invisible: (i) three optimiser
+    steps with the cache give bit-identical parameters and losses to the same steps without it, (ii) once the parameters
+    have settled in the optimiser's flat buffer (first step) every convolution is served from the cache, (iii) a weight changed behind PyTorch's back (`.data` arithmetic: no version
+    counter moves) is seen by the next evaluate(), (iv) outside a span nothing is served from the cache."""
+    from jvae_hip import lib as L
+    from jvae_hip import ops
+    case = full_config(2, 16)
+    kw = case['net']
+    x, y, eps = (t.to(DEV) for t in det_inputs(16, kw['input_shape'], 10, 1, 64, seed=9))
+
+    def two_steps(cache_mb):
+        old = L.PACK_CACHE_BYTES
+        L.PACK_CACHE_BYTES = cache_mb << 20
+        if not cache_mb:
+            L.load().jvae_pack_cache_configure(None, 0)
+            L._pack_cache.clear()
+        try:
+            net = build(case)
+            out = []
+            for step in range(3):
+                losses, _ = net.train_step(x, y, epsilon=eps)
+                out.append(losses['total'].detach().clone())
+            torch.cuda.synchronize()
+            return net, out
+        finally:
+            L.PACK_CACHE_BYTES = old
+    net0, l0 = two_steps(0)
+    L._pack_cache.clear()
+    before = L.pack_cache_stats()
+    net1, l1 = two_steps(64)
+    after = L.pack_cache_stats()
+    for a, b in zip(l0, l1):
+        assert torch.equal(a, b)
+    for (k, p), (_, q) in zip(net0.state_dict().items(), net1.state_dict().items()):
+        assert torch.equal(p, q), k
+    assert after['entries'] >= 12 and after['refreshes'] - before['refreshes'] >= 1
+    hits, misses = after['hits'] - before['hits'], after['misses'] - before['misses']
+    # step 1 fills the table; the first Adam moves the parameters into the flat buffer (new addresses = new owner: refilled in
+    # step 2); step 3 is served from the cache entirely
+    assert misses <= 2 * after['entries'] and hits >= after['entries']
+    # (iii) a weight changed through .data
+    net1.eval()
+    with torch.no_grad():
+        ref_a = net1.evaluate(x, y, epsilon=eps)[2]['total'].clone()
+        net1.imager[3].weight.data.mul_(0.5)
+        ref_b = net1.evaluate(x, y, epsilon=eps)[2]['total'].clone()
+    assert not torch.equal(ref_a, ref_b)
+    net0.eval()
+    net0.imager[3].weight.data.mul_(0.5)
+    old = L.PACK_CACHE_BYTES
+    L.PACK_CACHE_BYTES = 0
+    try:
+        with torch.no_grad():
+            assert torch.equal(net0.evaluate(x, y, epsilon=eps)[2]['total'], ref_b)
+    finally:
+        L.PACK_CACHE_BYTES = old
+    # (iv) a convolution called outside evaluate() packs for itself
+    s0 = L.pack_cache_stats()
+    net1.imager(torch.randn(4, *net1.imager.input_shape, device=DEV))
+    s1 = L.pack_cache_stats()
+    assert (s1['hits'], s1['misses']) == (s0['hits'], s0['misses'])
+
+
 def test_accuracy_loop_records_and_recovers(tmp_path):
     """accuracy() (cvae.py:1187-1452) over a synthetic test set: per-method accuracies, `testing` bookkeeping, the
     per-sample losses recorded into `record-<set>.pth` in the reference's format (the file layout itself is
