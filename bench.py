@@ -65,11 +65,15 @@ def build_model(device, workload=2, test_latent_sampling=1):
     return net
 
 
-def dominant_kernel_roofline(device, reps=20):
-    """Largest layer of the step (imager.15: ConvTranspose2d 32->32 5x5 on 1024x32x32x32, 53.69 GFLOP fwd) launched
-    exactly as the step launches it (deferred BatchNorm+ReLU of its input applied while staging, BatchNorm partial sums
-    of its output in the epilogue; the 5 us weight re-pack kernel in front of it is inside the timed region), timed with
-    HIP events on the launch stream.
+def dominant_kernel_roofline(device, reps=20, in_step_ms=None):
+    """Largest layer of the step (imager.15: ConvTranspose2d 32->32 5x5 on 1024x32x32x32, 53.69 GFLOP fwd).
+
+    `achieved` = algorithmic FLOPs of one launch / its average duration INSIDE the timed steps (`in_step_ms`: one HIP-event
+    pair per step around that launch on its launch stream, recorded by jvae_hip.ops.LaunchProbe; the step launches it with
+    the deferred BatchNorm+ReLU of its input applied while staging and the BatchNorm partial sums of its output in the
+    epilogue; its weights come packed from the step's pack cache).  `standalone` repeats the same launch `reps` times back
+    to back outside the step (its own pack kernel in front of every launch, no neighbours): under 20 consecutive launches of
+    the heaviest kernel the chip holds a lower clock than in the step's mix, so that figure is the pessimistic one.
 
     The layer runs on conv5_x3_kernel (conv_x3.hip): fp32 in / fp32 out, every operand split exactly into three bf16
     terms and each fp32 product accumulated from 6 bf16 MFMA products.  `achieved` counts the ALGORITHMIC fp32 FLOPs;
@@ -92,35 +96,45 @@ def dominant_kernel_roofline(device, reps=20):
         ops.conv_fwd_aff_raw(x, w, b, spec, aff, True)
     e1.record()
     torch.cuda.synchronize()
-    sec = e0.elapsed_time(e1) * 1e-3 / reps
+    alone = e0.elapsed_time(e1) * 1e-3 / reps
     flops = 2.0 * N * H * H * C * C * 25
     x3 = os.environ.get('JVAE_X3', '1') != '0'
+    sec, measured = alone, 'standalone: %d back-to-back launches outside the step' % reps
+    if in_step_ms:
+        sec = sum(in_step_ms) / len(in_step_ms) * 1e-3
+        measured = 'in the timed steps: %d HIP-event pairs (one per step) around the launch, on its launch stream' % len(in_step_ms)
     traffic, traffic_source = None, None
-    for name in (('r02_x3_fwd_pmc.json', 'r01_x3_kernel_pmc.json') if x3 else ('r01_dominant_kernel_pmc.json',)):
+    for name in (('r03_x3_fwd_pmc.json', 'r02_x3_fwd_pmc.json') if x3 else ('r01_dominant_kernel_pmc.json',)):
         pmc = os.path.join(REPO, 'profiles', name)
         if os.path.exists(pmc):       # HBM bytes per launch from separate rocprofv3 --pmc passes of THIS kernel (not of this run)
             d = json.load(open(pmc))
             traffic = d.get('hbm_bytes_per_launch') or ((d.get('hbm_read_bytes') or 0) + (d.get('hbm_write_bytes') or 0)) or None
             traffic_source = f'profiles/{name}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same launch (committed file, not this run)'
             break
-    if not x3:
-        return {'bound': 'mfma', 'kernel': 'conv5_fwd_kernel<1,32,4,1,8,aff>: imager.15 forward (ConvT 32->32 5x5 s1, 1024x32x32x32)',
-                'achieved': flops / sec / 1e12, 'peak': MFMA_F32_PEAK / 1e12, 'unit': 'TFLOP/s',
-                'frac': flops / sec / MFMA_F32_PEAK, 'traffic': traffic, 'traffic_source': traffic_source, 'launch_ms': sec * 1e3}
-    peak = MFMA_BF16_PEAK / X3_PRODUCTS
-    return {'bound': 'mfma', 'kernel': 'conv5_x3_kernel<1,32,2,aff>: imager.15 forward (ConvT 32->32 5x5 s1, 1024x32x32x32), fp32 operands '
-                                       'split exactly into 3 bf16 terms, 6 v_mfma_f32_32x32x16_bf16 per fp32 product tile',
-            'achieved': flops / sec / 1e12, 'peak': peak / 1e12, 'unit': 'TFLOP/s', 'frac': flops / sec / peak,
-            'traffic': traffic, 'traffic_source': traffic_source, 'launch_ms': sec * 1e3,
-            'peak_definition': 'dense bf16 MFMA 2500 TFLOP/s / 6 bf16 products per fp32 product',
-            'bf16_mfma_achieved': X3_PRODUCTS * flops / sec / 1e12, 'vs_f32_mfma_peak': flops / sec / MFMA_F32_PEAK}
+    peak = MFMA_BF16_PEAK / X3_PRODUCTS if x3 else MFMA_F32_PEAK
+    out = {'bound': 'mfma',
+           'kernel': ('conv5_x3_kernel<1,32,2,aff>: imager.15 forward (ConvT 32->32 5x5 s1, 1024x32x32x32), fp32 operands split exactly '
+                      'into 3 bf16 terms, 6 v_mfma_f32_32x32x16_bf16 per fp32 product tile' if x3 else
+                      'conv5_fwd_kernel<1,32,4,1,8,aff>: imager.15 forward (ConvT 32->32 5x5 s1, 1024x32x32x32)'),
+           'achieved': flops / sec / 1e12, 'peak': peak / 1e12, 'unit': 'TFLOP/s', 'frac': flops / sec / peak,
+           'traffic': traffic, 'traffic_source': traffic_source, 'launch_ms': sec * 1e3, 'measured': measured,
+           'algorithmic_flops_per_launch': flops,
+           'standalone': {'launch_ms': alone * 1e3, 'achieved': flops / alone / 1e12, 'frac': flops / alone / peak,
+                          'note': 'the same launch repeated back to back outside the step, its pack kernel included'}}
+    if in_step_ms:
+        t = sorted(in_step_ms)
+        out['launch_ms_min'], out['launch_ms_max'] = t[0], t[-1]
+    if x3:
+        out.update({'peak_definition': 'dense bf16 MFMA 2500 TFLOP/s / 6 bf16 products per fp32 product',
+                    'bf16_mfma_achieved': X3_PRODUCTS * flops / sec / 1e12, 'vs_f32_mfma_peak': flops / sec / MFMA_F32_PEAK})
+    return out
 
 
 def wgrad_kernel_roofline(device, reps=20):
     """The second MFMA-bound family of the step: the weight gradient of the same layer (imager.15, 53.69 GFLOP) on
     conv5_wgrad_x3_kernel + its slab fold, launched through the C ABI as the step launches it (deferred BatchNorm on the layer
     input, accumulation into an existing gradient), timed with HIP events on the launch stream.  Same peak definition as
-    `roofline`; HBM traffic from profiles/r02_wgrad_x3_pmc.json (committed rocprofv3 --pmc passes, not this run)."""
+    `roofline`; HBM traffic from profiles/r03_wgrad_x3_pmc.json (committed rocprofv3 --pmc passes, not this run)."""
     from jvae_hip import ops
     N, C, H = 2 * BATCH_PER_GPU, 32, 32
     spec = ops.ConvSpec(C, C, 5, 1, 2, 0, transposed=True)
@@ -141,11 +155,11 @@ def wgrad_kernel_roofline(device, reps=20):
     flops = 2.0 * N * H * H * C * C * 25
     peak = MFMA_BF16_PEAK / X3_PRODUCTS
     traffic, src = None, None
-    pmc = os.path.join(REPO, 'profiles', 'r02_wgrad_x3_pmc.json')
+    pmc = os.path.join(REPO, 'profiles', 'r03_wgrad_x3_pmc.json')
     if os.path.exists(pmc):
         d = json.load(open(pmc))
         traffic = ((d.get('hbm_read_bytes') or 0) + (d.get('hbm_write_bytes') or 0)) or None
-        src = 'profiles/r02_wgrad_x3_pmc.json (committed file, not this run)'
+        src = 'profiles/r03_wgrad_x3_pmc.json (committed file, not this run)'
     return {'bound': 'mfma', 'kernel': 'conv5_wgrad_x3_kernel<1,32,0,aff,16x16x32> + wgrad_reduce4_kernel: imager.15 weight gradient '
                                        '(1024x32x32x32 activations), both operands split exactly into 3 bf16 terms',
             'achieved': flops / sec / 1e12, 'peak': peak / 1e12, 'unit': 'TFLOP/s', 'frac': flops / sec / peak,
@@ -320,7 +334,16 @@ def main():
             return net.train_step(x, y, batch=i, current_measures=meas)
     for i in range(a.warmup):
         _, meas = one_step(i, meas)
+    probe = None
+    if a.workload == 2 and a.dtype == 'f32' and not eval_mode and not a.graph and os.environ.get('JVAE_BENCH_NO_PROBES') != '1':
+        # the dominant kernel (imager.15 forward: ConvT 32->32 5x5 s1 on the 2N x 32 x 32 x 32 decoder activation) timed INSIDE the
+        # timed steps: one HIP-event pair per step around that launch, on the stream it is launched on
+        from jvae_hip import ops as _ops
+        probe = _ops.FWD_AFF_PROBE = _ops.LaunchProbe(lambda sp, N, H: sp.transposed and sp.s == 1 and sp.cin == 32 and sp.cout == 32
+                                                      and H == 32 and N == 2 * a.batch)
     sync()
+    if probe is not None:
+        probe.armed = True
     # per-step HIP events on the launch stream (median / min are reported beside the contract's mean over the K steps)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
     t0 = time.time()
@@ -330,12 +353,25 @@ def main():
         marks[i + 1].record()
     sync()
     dt = time.time() - t0
+    if probe is not None:
+        probe.armed = False
     per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps))
     if dist is not None:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
     value = world * a.batch * a.steps / dt
+    replicas = None
+    if dist is not None and not eval_mode:
+        # data-parallel replicas must hold bit-identical parameters after the timed steps: exact integer checksum of the
+        # parameters' bit patterns, gathered over the ranks (BatchNorm running statistics are per-rank by design)
+        flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()]).contiguous()
+        chk = flat.view(torch.int32).to(torch.int64).sum().reshape(1)
+        if os.environ.get('JVAE_BENCH_BACKEND', 'nccl') != 'nccl':
+            chk = chk.cpu()                       # gloo gathers host tensors
+        got = [torch.zeros_like(chk) for _ in range(world)]
+        dist.all_gather(got, chk)
+        replicas = [int(t) for t in got]
 
     if rank == 0:
         out = {'metric': 'evaluation_images_per_sec (diagnostic)' if eval_mode else 'training_images_per_sec', 'value': value,
@@ -360,13 +396,17 @@ def main():
                                          ('fp32 MFMA in every layer' if a.dtype == 'f32' else
                                           'bf16 activations / MFMA operands, fp32 accumulation, statistics, losses, optimiser'))},
                'final_loss': float(losses['total'].detach().mean())}
+        if replicas is not None:
+            out['replicas_identical'] = len(set(replicas)) == 1
+            out['replica_param_checksums'] = replicas
+            out['config']['backend'] = os.environ.get('JVAE_BENCH_BACKEND', 'nccl')
         if not eval_mode:
             # NOT a utilisation figure: algorithmic conv/linear FLOPs per second divided by the fp32-MFMA peak the north-star
             # target (>= 0.5) is phrased in; most of those FLOPs run on the bf16 pipes (6 bf16 products per fp32 product)
             out['step_throughput_vs_f32_mfma_peak'] = value / world * WORKLOADS[a.workload][1] / (MFMA_F32_PEAK if a.dtype == 'f32' else MFMA_BF16_PEAK)
         # the roofline probes and the CPU baseline belong to the headline config (JVAE_BENCH_NO_PROBES=1: kernel traces of the step alone)
         if a.workload == 2 and a.dtype == 'f32' and not eval_mode and os.environ.get('JVAE_BENCH_NO_PROBES') != '1':
-            out['roofline'] = dominant_kernel_roofline(device)
+            out['roofline'] = dominant_kernel_roofline(device, in_step_ms=probe.times_ms() if probe is not None else None)
             out['roofline_wgrad'] = wgrad_kernel_roofline(device)
             out['roofline_hbm'] = bn_backward_hbm(device)
         if world == 1 and not a.no_cpu_baseline and a.workload == 2 and a.dtype == 'f32' and not eval_mode:

@@ -121,7 +121,8 @@ class _LazySigmaParams(_LazyDict):
 
 
 def _grad_nan_exit():
-    print('GRAD NAN')              # cvae.py:2454-2457; detected by the Adam kernel, reported when measures are read
+    print('GRAD NAN')              # cvae.py:2454-2457; detected by the Adam kernel: train_step() checks the flag of the previous update
+                                   # before every backward (as the reference's scan does), lazily-read measures check it as well
     sys.exit(1)
 
 
@@ -935,6 +936,8 @@ class ClassificationVariationalNetwork(nn.Module):
                                                    current_measures=current_measures, epsilon=epsilon)
         # total.mean().backward() without the two reduction kernels of the mean nobody reads and the expand of its
         # backward: d(mean)/d(total_i) = 1/N, handed to autograd as a cached constant (same fp32 value as torch's own)
+        if self.optimizer.check_nonfinite():     # cvae.py:2454-2457: a NaN / Inf parameter ends the run BEFORE backward
+            _grad_nan_exit()
         tot = losses['total']
         key = (tot.shape, tot.device)
         if getattr(self, '_mean_grad_key', None) != key:

@@ -227,6 +227,21 @@ def conv_affine_ok(spec, N, H, W):
     return bool(_geom_query('jvae_conv2d_affine_ok', spec.geom(N, H, W)))
 
 
+class LaunchProbe:
+    """HIP-event pairs around ONE convolution launch inside the running step (bench.py's `roofline`: the dominant kernel timed
+    where it runs - same clocks, caches and neighbours as in the step - on the stream it is launched on).  `match(spec, N, H)`
+    selects the launch; events are recorded on the current stream, read after the timed region."""
+
+    def __init__(self, match):
+        self.match, self.events, self.armed = match, [], False
+
+    def times_ms(self):
+        return [a.elapsed_time(b) for a, b in self.events]
+
+
+FWD_AFF_PROBE = None          # set by bench.py only
+
+
 def conv_fwd_aff_raw(x, w, b, spec, aff, want_stats):
     """Forward with a = [relu](x*scale[c] + shift[c]) applied to the input while it is staged; aff = (scale, shift, relu).
     -> (y, stats, nsplit) as conv_fwd_stats_raw."""
@@ -241,8 +256,16 @@ def conv_fwd_aff_raw(x, w, b, spec, aff, want_stats):
         if cap > 0:
             stats = torch.empty((spec.cout * cap * 2,), device=x.device, dtype=torch.float32)
     ws, nb = _conv_ws(geom, x.device)
+    probe = FWD_AFF_PROBE
+    timed = probe is not None and probe.armed and probe.match(spec, N, H)
+    if timed:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
     rc = lib.jvae_conv2d_fwd_aff_f32(L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(y), L.ptr(stats), byref(ns),
                                      L.ptr(aff[0]), L.ptr(aff[1]), int(aff[2]), *geom, L.ptr(ws), nb, L.stream_ptr())
+    if timed:
+        ev[1].record()
+        probe.events.append(ev)
     L.check(rc, 'jvae_conv2d_fwd_aff_f32')
     return y, (stats if ns.value > 0 else None), ns.value
 

@@ -376,6 +376,35 @@ class Optimizer:
                 ops.adam_step(g.p, g.g, g.m, g.v, self._lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
                               g.step, max_norm=clip, sqnorm=self._sqnorm if clip else None, flag=self._flag)
         self._clip_pending = False
+        self._post_flag(dev)
+
+    # ---- NaN / Inf parameters: the reference scans every parameter before each backward (cvae.py:2454-2457) ---------
+    def _post_flag(self, dev):
+        """After the update: the kernel's non-finite flag travels to pinned host memory on the side stream (4 bytes, off
+        the critical path); check_nonfinite() reads it before the NEXT backward."""
+        if torch.cuda.is_current_stream_capturing():
+            return                               # a captured step reports through its measures (graph_train_step)
+        from jvae_hip import lib as _lib
+        if getattr(self, '_flag_host', None) is None:
+            self._flag_host = torch.zeros(1, dtype=torch.int32, pin_memory=True)
+        side = _lib.side_stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            self._flag_host.copy_(self._flag, non_blocking=True)
+            self._flag_event = torch.cuda.Event()
+            self._flag_event.record(side)
+
+    def check_nonfinite(self):
+        """True if the previous update left a NaN / Inf parameter.  Called between the forward and the backward of the next
+        step - where the reference's scan sits (cvae.py:2454-2457: `print('GRAD NAN'); sys.exit(1)` before backward).  The
+        wait is for the PREVIOUS step's 4-byte copy, which finished while this step's forward was being enqueued: the host
+        never stalls on it unless it runs more than a step ahead of the GPU."""
+        ev = getattr(self, '_flag_event', None)
+        if ev is None:
+            return False
+        ev.synchronize()
+        self._flag_event = None
+        return bool(self._flag_host[0] != 0)
 
     def enable_device_hyper(self, on=True):
         """Keep Adam's step count, learning rate and betas in device memory (updated by a one-thread kernel in front of

@@ -806,6 +806,25 @@ def test_pack_cache_is_transparent():
     assert (s1['hits'], s1['misses']) == (s0['hits'], s0['misses'])
 
 
+def test_nonfinite_parameters_end_the_run_before_the_next_backward(capsys):
+    """cvae.py:2454-2457: the reference scans every parameter for NaN / Inf between evaluate() and backward() and ends the run
+    with `print('GRAD NAN'); sys.exit(1)`.  Here the Adam kernel raises a device flag when an updated parameter is not finite;
+    train_step() reads the flag of the PREVIOUS update (a 4-byte copy that completed during this step's forward) at the
+    same place - after evaluate(), before backward: the step after the poisoned update exits with nothing back-propagated."""
+    case = full_config(2, 8)
+    net = build(case)
+    x, y, eps = (t.to(DEV) for t in det_inputs(8, (3, 32, 32), 10, 1, 64, seed=3))
+    net.train_step(x, y, epsilon=eps)                       # a healthy step: no exit on the next one
+    net.train_step(x, y, epsilon=eps)
+    net.optimizer._lr = float('inf')                        # the next update writes Inf / NaN parameters
+    net.train_step(x, y, epsilon=eps)
+    with pytest.raises(SystemExit) as ei:
+        net.train_step(x, y, epsilon=eps)
+    assert ei.value.code == 1 and 'GRAD NAN' in capsys.readouterr().out
+    torch.cuda.synchronize()
+    assert float(net.optimizer._groups[0].g.abs().sum()) == 0.       # zero_grad ran, backward did not
+
+
 def test_accuracy_loop_records_and_recovers(tmp_path):
     """accuracy() (cvae.py:1187-1452) over a synthetic test set: per-method accuracies, `testing` bookkeeping, the
     per-sample losses recorded into `record-<set>.pth` in the reference's format (the file layout itself is
