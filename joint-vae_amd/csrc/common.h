@@ -21,6 +21,21 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Tile of workgroup w when the n workgroups of a launch are dealt round-robin to the 8 XCDs of an MI355X (hardware order:
+// workgroup w runs on XCD w % 8): XCD x works through the CONTIGUOUS tile range [x * n / 8 ...), so tiles that share data
+// (halo rows of one image) meet in one XCD's L2.  A bijection of [0, n) for every n.  JVAE_XCD_MAP=0 at build time: identity.
+#ifndef JVAE_XCD_MAP
+#define JVAE_XCD_MAP 1
+#endif
+__device__ __forceinline__ int xcd_tile(unsigned w, unsigned n) {
+#if JVAE_XCD_MAP
+    const unsigned per = n >> 3, rem = n & 7, x = w & 7, k = w >> 3;
+    return (int)(x * per + (x < rem ? x : rem) + k);
+#else
+    return (int)w;
+#endif
+}
+
 // Images [nb, ne) of part j when N images are dealt to `parts` workgroups in runs of ceil(N / parts).  The last parts can be
 // EMPTY (nb >= N whenever (parts - 1) * ceil(N / parts) >= N, e.g. N = 49 over 64 parts): ne is clamped to nb so that ne - nb is
 // never negative - every kernel that partitions a batch takes its range from here (and only from here).
