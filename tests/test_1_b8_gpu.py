@@ -268,6 +268,56 @@ def test_b8_model_config5_against_fp32_oracle():
     assert abs(den_a ** 0.5 / den_b ** 0.5 - 1) < 2e-2
 
 
+def test_b8_model_config5_at_the_per_rank_batch_against_the_reference_golden(golden_dir):
+    """BASELINE configs[4] at its PER-RANK batch (global 2048 = 8 x 256): the bf16 mode against the REFERENCE's own fp32
+    training step at N = 256 (tests/golden/c5_n256.npz, written by oracle/gen_golden.py from the imported reference; the
+    fp32 mode is held to it at 1e-4 by test_2_model_gpu.py).  RESTATED TOLERANCE for bf16 activations / MFMA operands
+    (north_star's 1e-4 is an fp32 figure): mu / log-variance within 2e-2 of their scale, per-sample total and cross_x
+    within 5e-3 relative, KL terms within 2e-2, the reconstruction's per-image norm within 1e-2 and mean within 3e-2
+    (measured 1.9e-2: the means of a random-weight decoder are small numbers), the global
+    gradient norm within 2 % and every stored per-tensor gradient norm within 25 % (each BatchNorm+ReLU boundary flips the
+    mask of the ~0.1-0.3 % of activations within bf16 rounding of the threshold: DESIGN.md section 4)."""
+    import os
+    import numpy as np
+    from oracle.cases import get_case
+    from oracle.det_init import det_inputs, load_det_state
+    from cvae import ClassificationVariationalNetwork as Net
+    g = np.load(os.path.join(golden_dir, 'c5_n256.npz'))
+    case = get_case('c5_n256')
+    kw, N = case['net'], case['N']
+    assert N == 256
+    net = Net(**kw)
+    load_det_state(net, seed=0)
+    net.to(DEV).train()
+    net.set_compute_dtype('bf16')
+    x, y, eps = (t.to(DEV) for t in det_inputs(N, kw['input_shape'], kw['num_labels'], net.latent_sampling, kw['latent_dim']))
+    net.optimizer.zero_grad()
+    x_reco, y_est, losses, meas, mu, log_var, z = net.evaluate(
+        x, y, batch=0, with_beta=True, kl_var_weighting=case['kl_var_weighting'], gamma_weighting=case['gamma_weighting'],
+        z_output=True, epsilon=eps)
+
+    def relmax(a, b):
+        a, b = np.asarray(a.detach().double().cpu()), np.asarray(b, dtype=np.float64)
+        return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+    assert relmax(mu, g['mu']) < 2e-2 and relmax(log_var, g['log_var']) < 2e-2
+    xr = x_reco.detach().double().flatten(2)
+    assert relmax(xr.mean(-1), g['x_reco_mean']) < 3e-2 and relmax(xr.norm(dim=-1), g['x_reco_norm']) < 1e-2
+    for k, tol in (('total', 5e-3), ('cross_x', 5e-3), ('kl', 2e-2), ('zdist', 2e-2), ('var_kl', 2e-2)):
+        a, b = losses[k].detach().double().cpu().numpy(), g['loss.' + k].astype(np.float64)
+        assert float((np.abs(a - b) / np.abs(b)).max()) < tol, k
+    losses['total'].mean().backward()
+    net.optimizer.clip(net.parameters())
+    tot = float(g['total_grad_norm'])
+    assert abs(float(net.optimizer.grad_norm()) / tot - 1) < 2e-2
+    got = {n: p.grad for n, p in net.named_parameters() if p.grad is not None}
+    worst = 0.
+    for f in g.files:
+        if f.startswith('gnorm.') and float(g[f]) > 1e-3 * tot:      # tensors that carry the gradient (dead biases: exact zeros here)
+            worst = max(worst, abs(float(got[f[6:]].double().norm()) / float(g[f]) - 1))
+    assert worst < 0.25, worst
+    print(f'bf16 config 5 at N=256 vs reference fp32: worst per-tensor gradient-norm difference {worst:.3f}')
+
+
 @pytest.mark.parametrize('cin,cout,k,s,p,op,tr,H', [(32, 64, 5, 1, 2, 0, False, 16), (32, 32, 5, 2, 2, 0, False, 32),
                                                     (64, 64, 5, 1, 2, 0, True, 8), (64, 64, 5, 2, 2, 1, True, 8),
                                                     (32, 3, 5, 1, 2, 0, False, 32), (24, 40, 5, 1, 2, 0, False, 16)])
