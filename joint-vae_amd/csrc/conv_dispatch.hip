@@ -66,7 +66,12 @@ size_t jvae_conv_ws(const ConvGeom& g, int transposed) {
     size_t c = wgrad_fast(g) ? 4 * wgrad_ws_floats(g) : 0;
     if (b > a) a = b;
     if (c > a) a = c;
-    if (transposed && point_input(g)) { const size_t d = 4 * (size_t)16 * g.N * g.Cs; if (d > a) a = d; }
+    if (transposed && point_input(g)) {
+        const size_t d = 4 * (size_t)16 * g.N * g.Cs;                              // dgrad: K pieces of dx
+        const size_t e = 4 * (size_t)8 * g.Cs * g.Cb * g.KH * g.KW;                // wgrad: K pieces of dW
+        if (d > a) a = d;
+        if (e > a) a = e;
+    }
     const size_t e = jvae_channel_sum_ws_bytes(g.Cb > g.Cs ? g.Cb : g.Cs);
     return a > e ? a : e;
 }
@@ -158,5 +163,20 @@ int jvae_conv_wgrad(const ConvGeom& g, int transposed, const float* x, const flo
         return jvae_conv5_wgrad(small, big, dw, 1, 0, g.N, g.Cs, g.Ws, g.Cb, g.S, g.P, ws, st, aff_small, aff_big);
     }
     if (aff) return JVAE_ENOTSUP;
+    if (transposed && point_input(g)) {
+        // ConvTranspose2d of a 1x1 input (imager.0): unfolding the kxk output at its single position is the identity, so
+        // dW[ci][j] (+)= sum_n x[n][ci] dy[n][j] is a plain product of the two tensors as they lie in memory (the generic path
+        // copied dy into a col buffer first and ran 64 workgroups over K = N: 60 us of a 4 ms step).  Few tiles, long K:
+        // K pieces stored side by side, folded onto dw in a fixed order (deterministic).
+        const int cols = g.Cb * g.KH * g.KW;
+        const long outf = (long)g.Cs * cols;
+        int want = (int)(1024 / ((long)cdiv(g.Cs, 64) * cdiv(cols, 64)));
+        want = want < 1 ? 1 : (want > 8 ? 8 : want);
+        if (ws_bytes < 4 * (size_t)(want * outf)) return JVAE_EWORKSPACE;
+        int S = 0;
+        int rc = jvae_gemm_launch_part(g.Cs, cols, g.N, 1, small, 1, g.Cs, 0, big, cols, 1, 0, ws, cols, 1, 0, outf, want, &S, st);
+        if (rc) return rc;
+        return jvae_splitk_fold(ws, nullptr, dw, S, outf, cols, 0, 1, st);
+    }
     return jvae_fold_wgrad(g, big, small, dw, ws, ws_bytes, st);
 }

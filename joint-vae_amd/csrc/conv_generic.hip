@@ -290,9 +290,21 @@ int jvae_fold_bwd(const ConvGeom& g, const float* ys, const float* w, const floa
     const int Kd = g.Cb * g.KH * g.KW, Ps = g.Hs * g.Ws;
     if (pixel_batched(g)) {
         if (ws_bytes < (size_t)col_floats_per_image(g) * 4 * g.N) return JVAE_EWORKSPACE;
-        // dcol_q[n][k] = sum_cs Ys[n][cs][q] W[cs][k]
-        int rc = jvae_gemm_launch(g.N, Kd, g.Cs, Ps, ys, (long)g.Cs * Ps, Ps, 1, w, Kd, 1, 0,
+        // dcol_q[n][k] = sum_cs Ys[n][cs][q] W[cs][k].  Ys is strided by the positions (element stride Ps along cs): transposed
+        // to Yt[q][n][cs] first (a 5 us copy) the product loads 16-byte groups instead of gathering scalars (59 -> 35 us for
+        // features.12 of conv32, profiles/r03_step_trace_no_overlap.txt)
+        const long colf = (long)col_floats_per_image(g) * g.N, ytf = (long)g.N * g.Cs * Ps;
+        int rc;
+        if (Ps > 1 && ws_bytes >= 4 * (size_t)(colf + ytf)) {
+            float* yt = ws + colf;
+            hipLaunchKernelGGL(small_transpose_kernel, dim3(grid_for(ytf)), dim3(256), 0, st, ys, yt, g.N, g.Cs, Ps);
+            JVAE_LAUNCH_CHECK();
+            rc = jvae_gemm_launch(g.N, Kd, g.Cs, Ps, yt, g.Cs, 1, (long)g.N * g.Cs, w, Kd, 1, 0,
                                   ws, Kd, 1, (long)g.N * Kd, nullptr, 0, 0, 1, st);
+        } else {
+            rc = jvae_gemm_launch(g.N, Kd, g.Cs, Ps, ys, (long)g.Cs * Ps, Ps, 1, w, Kd, 1, 0,
+                                  ws, Kd, 1, (long)g.N * Kd, nullptr, 0, 0, 1, st);
+        }
         if (rc) return rc;
         // fold_kernel indexes with 32 bits: slabs of images below 2^31 output elements (one launch for every real size)
         const int slab = fold_slab_images(g);

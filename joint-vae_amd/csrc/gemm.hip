@@ -241,7 +241,13 @@ struct GxImg {
     static constexpr int BYTES = PITCH * ROWS;            // one plane
 };
 
-template <bool AK, bool BNC>
+// DEPTH: K steps whose global loads are in flight in registers ahead of the one being multiplied.  The products served here
+// are a few hundred workgroups of 10 - 30 K steps each: with ONE step in flight every step paid a full load latency
+// (~2 us per step: M = 512, N = 200, K = 3136 in 5 slices took 40 us for 6 us of matrix work, profiles/r03_step_trace_no_overlap.txt);
+// with DEPTH = 3 three steps' loads overlap.  The deep variant takes 16-byte loads only (vecA && vecB, K range a multiple of
+// 4) and loads UNCONDITIONALLY - out-of-range groups read a valid stand-in address and are zeroed when they are stored to LDS -
+// so that the compiler can count the loads in flight (a branch around a load forces s_waitcnt vmcnt(0)).
+template <bool AK, bool BNC, int DEPTH = 1>
 __global__ __launch_bounds__(256, 4) void gemm_x3_kernel(GemmP p) {
     using IA = GxImg<AK>;
     using IB = GxImg<!BNC>;
@@ -266,44 +272,74 @@ __global__ __launch_bounds__(256, 4) void gemm_x3_kernel(GemmP p) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    f32x4 ra[G4], rb[G4];
+    f32x4 ra[DEPTH][G4], rb[DEPTH][G4];
 
-    auto gload = [&](int k0) {
+    // (row, k) coordinates of this thread's float4 group g of a K step starting at k0; the contiguous direction runs fastest
+    auto coordA = [&](int g, int k0, int* fast, int* slow) {
+        if (AK) { *fast = k0 + (tid % KQX) * 4; *slow = m0 + tid / KQX + g * (256 / KQX); }       // (k, m)
+        else    { *fast = m0 + (tid % 16) * 4;  *slow = k0 + tid / 16 + g * 16; }                  // (m, k)
+    };
+    auto coordB = [&](int g, int k0, int* fast, int* slow) {
+        if (BNC) { *fast = n0 + (tid % 16) * 4;  *slow = k0 + tid / 16 + g * 16; }                 // (n, k)
+        else     { *fast = k0 + (tid % KQX) * 4; *slow = n0 + tid / KQX + g * (256 / KQX); }       // (k, n)
+    };
+    auto okA = [&](int fast, int slow) { return AK ? (fast < kend && slow < p.M) : (fast + 3 < p.M && slow < kend); };
+    auto okB = [&](int fast, int slow) { return BNC ? (fast + 3 < p.N && slow < kend) : (fast < kend && slow < p.N); };
+
+    auto gload = [&](int st, int k0) {
 #pragma unroll
         for (int g = 0; g < G4; ++g) {
+            if constexpr (DEPTH > 1) {
+                int f, sl;
+                coordA(g, k0, &f, &sl);
+                const float* sa = AK ? A + (long)sl * p.sAm + f : A + (long)sl * p.sAk + f;
+                ra[st][g] = *reinterpret_cast<const f32x4*>(okA(f, sl) ? sa : A);
+                coordB(g, k0, &f, &sl);
+                const float* sb = BNC ? B + (long)sl * p.sBk + f : B + (long)sl * p.sBn + f;
+                rb[st][g] = *reinterpret_cast<const f32x4*>(okB(f, sl) ? sb : B);
+                continue;
+            }
             if (AK) {
                 const int kq = tid % KQX, row = tid / KQX + g * (256 / KQX);
                 const int m = m0 + row, k = k0 + kq * 4;
                 const float* src = A + (long)m * p.sAm + (long)k * p.sAk;
-                ra[g] = p.vecA ? load4<true>(src, p.sAk, k, kend, m < p.M) : load4<false>(src, p.sAk, k, kend, m < p.M);
+                ra[st][g] = p.vecA ? load4<true>(src, p.sAk, k, kend, m < p.M) : load4<false>(src, p.sAk, k, kend, m < p.M);
             } else {
                 const int mq = tid % 16, kr = tid / 16 + g * 16;
                 const int m = m0 + mq * 4, k = k0 + kr;
                 const float* src = A + (long)m * p.sAm + (long)k * p.sAk;
-                ra[g] = p.vecA ? load4<true>(src, p.sAm, m, p.M, k < kend) : load4<false>(src, p.sAm, m, p.M, k < kend);
+                ra[st][g] = p.vecA ? load4<true>(src, p.sAm, m, p.M, k < kend) : load4<false>(src, p.sAm, m, p.M, k < kend);
             }
             if (BNC) {
                 const int nq = tid % 16, kr = tid / 16 + g * 16;
                 const int n = n0 + nq * 4, k = k0 + kr;
                 const float* src = B + (long)k * p.sBk + (long)n * p.sBn;
-                rb[g] = p.vecB ? load4<true>(src, p.sBn, n, p.N, k < kend) : load4<false>(src, p.sBn, n, p.N, k < kend);
+                rb[st][g] = p.vecB ? load4<true>(src, p.sBn, n, p.N, k < kend) : load4<false>(src, p.sBn, n, p.N, k < kend);
             } else {
                 const int kq = tid % KQX, col = tid / KQX + g * (256 / KQX);
                 const int n = n0 + col, k = k0 + kq * 4;
                 const float* src = B + (long)k * p.sBk + (long)n * p.sBn;
-                rb[g] = p.vecB ? load4<true>(src, p.sBk, k, kend, n < p.N) : load4<false>(src, p.sBk, k, kend, n < p.N);
+                rb[st][g] = p.vecB ? load4<true>(src, p.sBk, k, kend, n < p.N) : load4<false>(src, p.sBk, k, kend, n < p.N);
             }
         }
     };
-    auto lstore = [&]() {
+    auto lstore = [&](int st, int k0) {
 #pragma unroll
         for (int g = 0; g < G4; ++g) {
             // the contiguous direction runs fastest over the threads, as in gload
             const int fa = AK ? tid % KQX : tid % 16, sa_ = AK ? tid / KQX + g * (256 / KQX) : tid / 16 + g * 16;
             const int fb = BNC ? tid % 16 : tid % KQX, sb_ = BNC ? tid / 16 + g * 16 : tid / KQX + g * (256 / KQX);
+            f32x4 va = ra[st][g], vb = rb[st][g];
+            if constexpr (DEPTH > 1) {               // stand-in loads of out-of-range groups: exact zeros
+                int f, sl;
+                coordA(g, k0, &f, &sl);
+                if (!okA(f, sl)) va = f32x4{0.f, 0.f, 0.f, 0.f};
+                coordB(g, k0, &f, &sl);
+                if (!okB(f, sl)) vb = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
             gx_u32x2 sa[3], sb[3];
-            gx_split4(ra[g], sa);
-            gx_split4(rb[g], sb);
+            gx_split4(va, sa);
+            gx_split4(vb, sb);
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) {
                 *reinterpret_cast<gx_u32x2*>(As + pl * IA::BYTES + sa_ * IA::PITCH + fa * 8) = sa[pl];
@@ -321,12 +357,7 @@ __global__ __launch_bounds__(256, 4) void gemm_x3_kernel(GemmP p) {
         return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     };
 
-    if (kbeg < kend) gload(kbeg);
-    for (int k0 = kbeg; k0 < kend; k0 += BKX) {
-        __syncthreads();                 // previous tile's fragment reads are done
-        lstore();
-        __syncthreads();
-        if (k0 + BKX < kend) gload(k0 + BKX);   // in flight under the MFMAs below
+    auto multiply = [&]() {
 #pragma unroll
         for (int ks = 0; ks < BKX / 16; ++ks) {
             gx_bf16x8 a[3], b[3];
@@ -338,6 +369,33 @@ __global__ __launch_bounds__(256, 4) void gemm_x3_kernel(GemmP p) {
             constexpr int APL[6] = {0, 2, 1, 0, 1, 0}, BPL[6] = {2, 0, 1, 1, 0, 0};      // small products first
 #pragma unroll
             for (int t = 0; t < 6; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[APL[t]], b[BPL[t]], acc, 0, 0, 0);
+        }
+    };
+    if constexpr (DEPTH > 1) {
+        // prologue: DEPTH steps in flight (steps beyond kend load the stand-in address: harmless, never stored)
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) gload(d, kbeg + d * BKX);
+        for (int k0 = kbeg; k0 < kend; k0 += DEPTH * BKX) {
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d) {
+                const int kk = k0 + d * BKX;
+                if (kk < kend) {                         // block-uniform
+                    __syncthreads();                     // previous tile's fragment reads are done
+                    lstore(d, kk);
+                    __syncthreads();
+                    gload(d, kk + DEPTH * BKX);          // stage d is free again: three steps ahead, under the MFMAs below
+                    multiply();
+                }
+            }
+        }
+    } else {
+        if (kbeg < kend) gload(0, kbeg);
+        for (int k0 = kbeg; k0 < kend; k0 += BKX) {
+            __syncthreads();                 // previous tile's fragment reads are done
+            lstore(0, k0);
+            __syncthreads();
+            if (k0 + BKX < kend) gload(0, k0 + BKX);   // in flight under the MFMAs below
+            multiply();
         }
     }
 
@@ -365,28 +423,40 @@ __global__ __launch_bounds__(256, 4) void gemm_x3_kernel(GemmP p) {
     }
 }
 
-template <bool AK, bool BNC>
+template <bool AK, bool BNC, int DEPTH>
 int launch_x3_variant(const GemmP& p, int batch, hipStream_t st) {
     constexpr int LDS = 3 * (GxImg<AK>::BYTES + GxImg<!BNC>::BYTES);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x3_kernel<AK, BNC>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x3_kernel<AK, BNC, DEPTH>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     dim3 grid(cdiv(p.N, 64), cdiv(p.M, 64), batch * p.splitk), block(256);
-    hipLaunchKernelGGL((gemm_x3_kernel<AK, BNC>), grid, block, LDS, st, p);
+    hipLaunchKernelGGL((gemm_x3_kernel<AK, BNC, DEPTH>), grid, block, LDS, st, p);
     JVAE_LAUNCH_CHECK();
     return 0;
 }
 
+static int g_gemm_depth = -1;    // JVAE_GEMM_DEPTH=1: one K step in flight (the round-2 kernel; A/B switch)
+
+template <bool AK, bool BNC>
+int launch_x3_ab(const GemmP& p, int batch, hipStream_t st) {
+    if (g_gemm_depth < 0) { const char* e = getenv("JVAE_GEMM_DEPTH"); g_gemm_depth = (e && e[0] == '1') ? 1 : 3; }
+    // deep prefetch: 16-byte loads on both operands, K range a multiple of 4 (kchunk is a multiple of 32)
+    const bool deep = g_gemm_depth > 1 && p.vecA && p.vecB && p.K % 4 == 0
+                      && (AK || p.M % 4 == 0) && (!BNC || p.N % 4 == 0);
+    if (deep) return launch_x3_variant<AK, BNC, 3>(p, batch, st);
+    return launch_x3_variant<AK, BNC, 1>(p, batch, st);
+}
+
 int launch_x3(const GemmP& p, int batch, hipStream_t st) {
     const bool ak = (p.sAk == 1), bnc = (p.sBn == 1);
-    if (ak && bnc) return launch_x3_variant<true, true>(p, batch, st);
-    if (ak) return launch_x3_variant<true, false>(p, batch, st);
-    if (bnc) return launch_x3_variant<false, true>(p, batch, st);
-    return launch_x3_variant<false, false>(p, batch, st);
+    if (ak && bnc) return launch_x3_ab<true, true>(p, batch, st);
+    if (ak) return launch_x3_ab<true, false>(p, batch, st);
+    if (bnc) return launch_x3_ab<false, true>(p, batch, st);
+    return launch_x3_ab<false, false>(p, batch, st);
 }
 
 static int g_gemm_x3 = -1;       // JVAE_GEMM_X3=0: dense products stay on the fp32 matrix-core kernel (A/B switch)

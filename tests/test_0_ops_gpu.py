@@ -81,6 +81,30 @@ def test_conv_all_directions(cin, cout, k, s, p, op, tr, H, N):
     assert rel(bd.grad, br.grad) < 2e-5
 
 
+@pytest.mark.parametrize('N', [300, 1024])
+def test_point_input_transposed_conv_weight_gradient(N):
+    """imager.0 of deconv32 (ConvTranspose2d 64->64 8x8 on a 1x1 input) at training batch sizes: the weight gradient is the
+    plain product x^T . dy cut into K pieces (over the batch) that are folded in a fixed order - accumulated onto an existing
+    gradient, bit-reproducible from run to run."""
+    from jvae_hip import ops
+    g = torch.Generator().manual_seed(N)
+    x = torch.randn(N, 64, 1, 1, generator=g)
+    w = torch.randn(64, 64, 8, 8, generator=g) / 8
+    gy = torch.randn(N, 64, 8, 8, generator=g)
+    ref = torch.einsum('nc,nokl->cokl', x[:, :, 0, 0].double(), gy.double()).float()
+    spec = ops.ConvSpec(64, 64, 8, 1, 0, 0, True)
+    outs = []
+    for _ in range(2):
+        xd, wd = x.to(DEV), w.to(DEV).requires_grad_(True)
+        y = ops.conv2d(xd, wd, None, spec)
+        y.backward(gy.to(DEV), retain_graph=True)
+        first = wd.grad.clone()
+        y.backward(gy.to(DEV))                      # second backward: accumulates onto the first
+        outs.append((first, wd.grad.clone()))
+    assert rel(outs[0][0], ref) < 2e-5 and rel(outs[0][1], 2 * ref) < 2e-5
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
 @pytest.mark.parametrize('cin,cout,tr,H,N', [(32, 32, True, 32, 6), (32, 64, False, 16, 9), (64, 32, True, 16, 5),
                                              (64, 64, True, 8, 7), (48, 40, False, 16, 3), (128, 64, False, 64, 1),
                                              (17, 33, False, 8, 1), (16, 3, True, 32, 2), (250, 32, False, 8, 3)])
