@@ -43,15 +43,11 @@ __global__ __launch_bounds__(256) void conv5_smallco_kernel(SmP p) {
 
     for (int i = tid; i < XS / 4; i += 256) reinterpret_cast<f32x4*>(Xs)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // accumulators as PAIRS of output channels: one v_pk_fma_f32 (two fp32 FMAs per lane, same issue rate as a scalar FMA on
-    // CDNA3 / CDNA4) per (pixel, tap, channel pair) - 2 instead of 3 vector instructions for the 3-channel image head
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    constexpr int CP = (CO + 1) / 2;
-    f32x2 acc[CP][4];
+    float acc[CO][4];
 #pragma unroll
-    for (int o = 0; o < CP; ++o)
+    for (int o = 0; o < CO; ++o)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[o][j] = f32x2{0.f, 0.f};
+        for (int j = 0; j < 4; ++j) acc[o][j] = 0.f;
 
     constexpr int W4 = OW / 4;
     constexpr int XUNITS = CC * ROWS * W4;
@@ -111,13 +107,11 @@ __global__ __launch_bounds__(256) void conv5_smallco_kernel(SmP p) {
 #pragma unroll
                 for (int kw = 0; kw < 5; ++kw) {
                     const f32x4 wv = *reinterpret_cast<const f32x4*>(&Wl[((c * 5 + kh) * 5 + kw) * 4]);
-                    const f32x2 wp[2] = {f32x2{wv[0], wv[1]}, f32x2{wv[2], wv[3]}};      // Wl pads co to 4 with zeros
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const float xv = in12[j + kw + 4 - 2];   // lds col = x + kw - P + 4 relative to 4*xq, P == 2
-                        const f32x2 xx = {xv, xv};
 #pragma unroll
-                        for (int o = 0; o < CP; ++o) acc[o][j] = __builtin_elementwise_fma(wp[o], xx, acc[o][j]);
+                        for (int o = 0; o < CO; ++o) acc[o][j] = fmaf(wv[o], xv, acc[o][j]);
                     }
                 }
             }
@@ -126,7 +120,7 @@ __global__ __launch_bounds__(256) void conv5_smallco_kernel(SmP p) {
 #pragma unroll
     for (int o = 0; o < CO; ++o) {
         const float b = p.bias ? p.bias[o] : 0.f;
-        f32x4 v = {acc[o >> 1][0][o & 1] + b, acc[o >> 1][1][o & 1] + b, acc[o >> 1][2][o & 1] + b, acc[o >> 1][3][o & 1] + b};
+        f32x4 v = {acc[o][0] + b, acc[o][1] + b, acc[o][2] + b, acc[o][3] + b};
         *reinterpret_cast<f32x4*>(p.out + (((long)n * CO + o) * OH + row0 + r) * OW + 4 * xq) = v;
     }
 }
