@@ -291,6 +291,12 @@ int jvae_recon_bwd_f32(const float* x_reco, const float* x, const float* sigma, 
                        const float* g_wmse, const float* wmse, float* g_x_reco, float* gsigma, int accumulate_sigma,
                        int L, int N, int D, void* ws, size_t ws_bytes, void* stream);
 
+/* mse_loss(x_output, x_target, batch_mean=False) itself (module/losses.py:8-27) for EVERY row of x_output: rows (L,N,D),
+ * x (N,D) -> wmse (L,N) = mean_D((rows[l][n] - x[n])^2); backward: g_rows = g_wmse * 2 (rows - x) / D.  (The jvae_recon_*
+ * pair above skips row 0 of an (L+1)-row reconstruction; these take the rows as they are.)  16-byte aligned when D % 4 == 0. */
+int jvae_mse_rows_fwd_f32(const float* rows, const float* x, float* wmse, int L, int N, int D, void* stream);
+int jvae_mse_rows_bwd_f32(const float* rows, const float* x, const float* g_wmse, float* g_rows, int L, int N, int D, void* stream);
+
 /* ---- ELBO assembly (cvae.py:773-791,887-902): wmse = mean_l wmse_s; cross_x = D/2 (2 log sigma + wmse + log 2pi);
  * total = cross_x + cw * ce + beta * kl   (ce may be NULL).  Backward takes the upstream gradients of the three
  * outputs (any may be NULL) and returns g_wmse_s (L,N), g_kl, g_ce (N,) and d/d sigma of the 2 log sigma term.

@@ -12,18 +12,19 @@ namespace {
 // encoder: sigma[n]), 3 = sigma follows each sample's own rmse (the division happens in the ELBO kernels: 1 here)
 enum { SIG_VALUE = 0, SIG_LOG = 1, SIG_CODED = 2, SIG_RMSE = 3 };
 __device__ __forceinline__ float sigma_inv2(const float* sigma, int mode, int n) {
-    if (mode == SIG_RMSE) return 1.f;
+    if (mode == SIG_RMSE || !sigma) return 1.f;      // sigma NULL: the plain mean square (jvae_mse_rows_*)
     const float sg = sigma[mode == SIG_CODED ? n : 0];
     return mode == SIG_VALUE ? 1.f / (sg * sg) : __expf(-2.f * sg);
 }
 
 // one block per (l, n); x_reco row l+1 is compared with x[n]
+// row0 = 1: xr is the (L+1, N, D) reconstruction (row 0 = the mean path, not part of the loss); row0 = 0: xr holds the L rows only
 __global__ __launch_bounds__(256) void recon_fwd_kernel(const float* __restrict__ xr, const float* __restrict__ x,
                                                         const float* __restrict__ sigma, int sigma_mode,
-                                                        float* __restrict__ wmse, int L, int N, int D) {
+                                                        float* __restrict__ wmse, int L, int N, int D, int row0) {
     __shared__ float red[17];
     const int n = blockIdx.x, l = blockIdx.y;
-    const float* a = xr + ((long)(l + 1) * N + n) * D;
+    const float* a = xr + ((long)(l + row0) * N + n) * D;
     const float* b = x + (long)n * D;
     float s = 0.f;
     if ((D & 3) == 0) {
@@ -48,14 +49,15 @@ __global__ __launch_bounds__(256) void recon_bwd_kernel(const float* __restrict_
                                                         const float* __restrict__ sigma_fwd,
                                                         const float* __restrict__ g, const float* __restrict__ wmse,
                                                         float* __restrict__ gxr, float* __restrict__ gsig_part,
-                                                        int L, int N, int D) {
-    const int n = blockIdx.x, l = blockIdx.y;       // l in [0, L]: row of x_reco
-    float* o = gxr + ((long)l * N + n) * D;
+                                                        int L, int N, int D, int rows_only) {
+    // l in [0, L]: row of x_reco (row 0 receives zeros); rows_only: xr / gxr hold the L sample rows only (grid.y = L)
+    const int n = blockIdx.x, l = blockIdx.y + rows_only;
+    float* o = gxr + ((long)(l - rows_only) * N + n) * D;
     if (l == 0) {
         for (int i = threadIdx.x; i < D; i += blockDim.x) o[i] = 0.f;
         return;
     }
-    const float* a = xr + ((long)l * N + n) * D;
+    const float* a = xr + ((long)(l - rows_only) * N + n) * D;
     const float* b = x + (long)n * D;
     float inv2 = sigma_inv2(sigma, sigma_mode, n);
     if (sigma_mode == SIG_VALUE && sigma_fwd) inv2 = 1.f / (sigma_fwd[0] * sigma[0]);
@@ -381,7 +383,31 @@ int jvae_recon_fwd_f32(const float* x_reco, const float* x, const float* sigma, 
     if (!x_reco || !x || !sigma || !wmse || L < 0 || N < 0 || D <= 0 || sigma_is_log < 0 || sigma_is_log > 3) return JVAE_EINVAL;
     if (N == 0 || L == 0) return 0;
     hipLaunchKernelGGL(recon_fwd_kernel, dim3(N, L), dim3(256), 0, (hipStream_t)stream, x_reco, x, sigma, sigma_is_log,
-                       wmse, L, N, D);
+                       wmse, L, N, D, 1);
+    JVAE_LAUNCH_CHECK();
+    return 0;
+}
+
+// mse_loss(x_output, x_target, batch_mean=False) of module/losses.py:8-27 on EVERY row: rows (L, N, D), x (N, D) ->
+// wmse (L, N) = mean_D((rows[l][n] - x[n])^2).  The same kernels as jvae_recon_*, told that there is no mean-path row in front
+// (the Python side used to pass `rows - N*D` to the (L+1)-row entry point: an address in front of the allocation).
+int jvae_mse_rows_fwd_f32(const float* rows, const float* x, float* wmse, int L, int N, int D, void* stream) {
+    if (!rows || !x || !wmse || L < 0 || N < 0 || D <= 0) return JVAE_EINVAL;
+    if ((D & 3) == 0 && (((uintptr_t)rows | (uintptr_t)x) & 15)) return JVAE_EINVAL;      // 16-byte loads
+    if (N == 0 || L == 0) return 0;
+    hipLaunchKernelGGL(recon_fwd_kernel, dim3(N, L), dim3(256), 0, (hipStream_t)stream, rows, x, (const float*)nullptr, SIG_VALUE,
+                       wmse, L, N, D, 0);                                                   // sigma NULL: 1
+    JVAE_LAUNCH_CHECK();
+    return 0;
+}
+
+// g_rows (L, N, D) = g_wmse[l][n] * 2 (rows - x) / D
+int jvae_mse_rows_bwd_f32(const float* rows, const float* x, const float* g_wmse, float* g_rows, int L, int N, int D, void* stream) {
+    if (!rows || !x || !g_wmse || !g_rows || L < 0 || N < 0 || D <= 0) return JVAE_EINVAL;
+    if ((D & 3) == 0 && (((uintptr_t)rows | (uintptr_t)x | (uintptr_t)g_rows) & 15)) return JVAE_EINVAL;
+    if (N == 0 || L == 0) return 0;
+    hipLaunchKernelGGL(recon_bwd_kernel, dim3(N, L), dim3(256), 0, (hipStream_t)stream, rows, x, (const float*)nullptr, SIG_VALUE,
+                       (const float*)nullptr, g_wmse, (const float*)nullptr, g_rows, (float*)nullptr, L, N, D, 1);
     JVAE_LAUNCH_CHECK();
     return 0;
 }
@@ -397,7 +423,7 @@ int jvae_recon_bwd_f32(const float* x_reco, const float* x, const float* sigma, 
     if (N == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(recon_bwd_kernel, dim3(N, L + 1), dim3(256), 0, st, x_reco, x, sigma, sigma_is_log, sigma_fwd, g_wmse,
-                       wmse, g_x_reco, gsigma ? (float*)ws : nullptr, L, N, D);
+                       wmse, g_x_reco, gsigma ? (float*)ws : nullptr, L, N, D, 0);
     JVAE_LAUNCH_CHECK();
     if (gsigma && sigma_is_log == SIG_CODED) {
         hipLaunchKernelGGL(rows_fold_kernel, dim3(cdiv(N, 256)), dim3(256), 0, st, (const float*)ws, gsigma, L, N, accumulate_sigma);

@@ -77,6 +77,8 @@ _SIGS = {
     'jvae_latent_bwd_f32': (c_int, [P] * 17 + [c_int] * 6 + [c_float] * 3 + [c_int, c_int, P, c_size_t, P]),
     'jvae_recon_fwd_f32': (c_int, [P, P, P, c_int, P, c_int, c_int, c_int, P]),
     'jvae_recon_bwd_f32': (c_int, [P, P, P, c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, P, c_size_t, P]),
+    'jvae_mse_rows_fwd_f32': (c_int, [P, P, P, c_int, c_int, c_int, P]),
+    'jvae_mse_rows_bwd_f32': (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
     'jvae_elbo_fwd_f32': (c_int, [P, P, P, P, c_int, P, P, P, P, c_int, c_int, c_int, c_float, c_float, P]),
     'jvae_elbo_bwd_f32': (c_int, [P, P, P, P, c_int, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_float, P, c_size_t, P]),
     'jvae_measures_f32': (c_int, [P, c_long, P, P, P, c_int, c_int, P, c_int, P, c_int, c_int, P, P, c_int, P, P]),

@@ -811,33 +811,33 @@ def recon_wmse(x_reco, x, sigma, sigma_is_log, snapshot=False):
 
 
 class _MseRows(torch.autograd.Function):
-    """mean squares of EVERY row of xo (L, N, D) against x (N, D): the public `mse_loss` (losses.py:8-27).  The kernels compare
-    rows 1..L of an (L+1, N, D) tensor and never touch row 0, so they are handed the address ONE ROW IN FRONT of xo instead
-    of a copy with a dummy row (the forward reads rows 1..L only; the backward writes a zero row 0 into a gradient buffer that
-    does have it, and a view of its rows 1..L is returned)."""
+    """The public `mse_loss(x_output, x_target, ndim, batch_mean=False)` of module/losses.py:8-27 on EVERY row of x_output:
+    xo (L, N, D), x (N, D) -> (L, N) mean squares over D (jvae_mse_rows_{fwd,bwd}_f32: the reconstruction kernels told that
+    there is no mean-path row in front of the rows - no copy, no padded row)."""
 
     @staticmethod
     def forward(ctx, xo, x):
         xo = _c(_f32(xo, 'mse_loss'))
         x = _c(_f32(x, 'mse_loss'))
         Ls, N, D = xo.shape
-        one = torch.ones(1, device=x.device, dtype=torch.float32)
+        if D % 4 == 0:                                   # the kernels use 16-byte loads: an odd view offset gets a copy
+            xo = xo if xo.data_ptr() % 16 == 0 else xo.clone()
+            x = x if x.data_ptr() % 16 == 0 else x.clone()
         wmse = torch.empty((Ls, N), device=x.device, dtype=torch.float32)
-        rc = L.load().jvae_recon_fwd_f32(L.ptr(xo) - 4 * N * D, L.ptr(x), L.ptr(one), SIGMA_VALUE, L.ptr(wmse), Ls, N, D, L.stream_ptr())
-        L.check(rc, 'jvae_recon_fwd_f32')
-        ctx.save_for_backward(xo, x, one, wmse)
+        rc = L.load().jvae_mse_rows_fwd_f32(L.ptr(xo), L.ptr(x), L.ptr(wmse), Ls, N, D, L.stream_ptr())
+        L.check(rc, 'jvae_mse_rows_fwd_f32')
+        ctx.save_for_backward(xo, x)
         return wmse
 
     @staticmethod
     def backward(ctx, g):
-        xo, x, one, wmse = ctx.saved_tensors
+        xo, x = ctx.saved_tensors
         Ls, N, D = xo.shape
         g = _c(g)
-        full = torch.empty((Ls + 1, N, D), device=xo.device, dtype=torch.float32)
-        rc = L.load().jvae_recon_bwd_f32(L.ptr(xo) - 4 * N * D, L.ptr(x), L.ptr(one), SIGMA_VALUE, None, L.ptr(g), L.ptr(wmse),
-                                         L.ptr(full), None, 0, Ls, N, D, None, 0, L.stream_ptr())
-        L.check(rc, 'jvae_recon_bwd_f32')
-        return full[1:], None
+        gx = torch.empty_like(xo)
+        rc = L.load().jvae_mse_rows_bwd_f32(L.ptr(xo), L.ptr(x), L.ptr(g), L.ptr(gx), Ls, N, D, L.stream_ptr())
+        L.check(rc, 'jvae_mse_rows_bwd_f32')
+        return gx, None
 
 
 def mse_rows(xo, x):
