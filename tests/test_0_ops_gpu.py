@@ -81,6 +81,42 @@ def test_conv_all_directions(cin, cout, k, s, p, op, tr, H, N):
     assert rel(bd.grad, br.grad) < 2e-5
 
 
+@pytest.mark.parametrize('N', [64, 37, 512])
+@pytest.mark.parametrize('bias', [True, False])
+def test_small_grid_7x7_head_at_training_batch_sizes(N, bias):
+    """features.12 of conv32 (Conv2d 64 -> 200, 7x7 on 8x8 maps -> 2x2) at training batch sizes incl. a ragged one (the
+    all-geometries test above runs N = 3 / 8, where the K-sliced split-bf16 products are not selected): forward, dgrad and
+    weight gradient against torch, accumulation onto an existing gradient, run-to-run bit equality."""
+    from jvae_hip import ops
+    g = torch.Generator().manual_seed(N + int(bias))
+    x = torch.randn(N, 64, 8, 8, generator=g)
+    w = torch.randn(200, 64, 7, 7, generator=g) / math.sqrt(64 * 49)
+    b = torch.randn(200, generator=g) if bias else None
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True) if bias else None
+    yr = F.conv2d(xr, wr, br)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    spec = ops.ConvSpec(64, 200, 7, 1, 0, 0, False)
+    outs = []
+    for _ in range(2):
+        xd, wd = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+        bd = b.to(DEV).requires_grad_(True) if bias else None
+        yd = ops.conv2d(xd, wd, bd, spec)
+        yd.backward(gy.to(DEV), retain_graph=True)
+        first = wd.grad.clone()
+        yd.backward(gy.to(DEV))
+        outs.append((yd.detach().clone(), xd.grad.clone(), first, wd.grad.clone()))
+    y0, gx0, gw1, gw2 = outs[0]
+    assert rel(y0, yr) < 2e-5
+    assert rel(gx0, 2 * xr.grad) < 2e-5
+    assert rel(gw1, wr.grad) < 5e-5 and rel(gw2, 2 * wr.grad) < 5e-5
+    if bias:
+        assert rel(bd.grad, 2 * br.grad) < 2e-5
+    for a, c in zip(outs[0], outs[1]):
+        assert torch.equal(a, c)
+
+
 @pytest.mark.parametrize('N', [300, 1024])
 def test_point_input_transposed_conv_weight_gradient(N):
     """imager.0 of deconv32 (ConvTranspose2d 64->64 8x8 on a 1x1 input) at training batch sizes: the weight gradient is the
