@@ -120,6 +120,12 @@ class _LazySigmaParams(_LazyDict):
             dict.update(self, self._s.host_params(self._m['sigma']))
 
 
+def _mean_over_draws(logits):
+    """y_est = logits[1:].mean(0) (cvae.py:910-917): with ONE latent draw (training: L = 1) that mean is the row itself -
+    returned as a view, bit-identical, without a reduction kernel on the step's main stream."""
+    return logits[1] if logits.shape[0] == 2 else logits[1:].mean(0)
+
+
 def _grad_nan_exit():
     print('GRAD NAN')              # cvae.py:2454-2457; detected by the Adam kernel: train_step() checks the flag of the previous update
                                    # before every backward (as the reference's scan does), lazily-read measures check it as well
@@ -613,7 +619,7 @@ class ClassificationVariationalNetwork(nn.Module):
             measures = Measures(packed, dictionary is not None, _grad_nan_exit)
             if self.training:
                 self.training_parameters['sigma'] = _LazySigmaParams(self.sigma, measures)
-        out = (x_reco, logits[1:].mean(0), losses, measures)
+        out = (x_reco, _mean_over_draws(logits), losses, measures)
         if z_output:
             out += (mu, log_var, z)
         return out
@@ -656,7 +662,7 @@ class ClassificationVariationalNetwork(nn.Module):
                                              int(self.sigma.is_log))
         keys = ('sigma', 'zdist', 'var_kl')
         measures = (packed, False) if raw_measures else Measures(packed, False, _grad_nan_exit, only=keys)
-        out = (x, logits[1:].mean(0), losses, measures)
+        out = (x, _mean_over_draws(logits), losses, measures)
         if z_output:
             out += (mu, log_var, z)
         return out
@@ -733,7 +739,7 @@ class ClassificationVariationalNetwork(nn.Module):
             packed = self._pack_measures(x, wmse, terms, dictionary, prev, batch, mse=mse, sigma_rms=sigma_rms,
                                          sigma_t=s_report if categorical else s)
         measures = Measures(packed, dictionary is not None, _grad_nan_exit)
-        out = (x_reco, logits[1:].mean(0), losses, measures)
+        out = (x_reco, _mean_over_draws(logits), losses, measures)
         if z_output:
             out += (mu, log_var, z)
         return out

@@ -232,7 +232,8 @@ def test_b8_stack_matches_fp32_stack():
             assert cos > 0.95, (name, n_, cos)
 
 
-def test_b8_model_config5_against_fp32_oracle():
+@pytest.mark.parametrize('N', [16, 37])
+def test_b8_model_config5_against_fp32_oracle(N):
     """Config 5 geometry (3x64x64, conv32+/deconv32+, K=200, C=20) in bf16 mode against the CPU oracle (fp32) on the
     same weights / batch / epsilon.  RESTATED TOLERANCE for bf16 (north_star's 1e-4 is an fp32 figure; SURVEY.md §8d
     config 5): per-sample total and cross_x within 5e-3 relative, KL terms within 2e-2, global gradient direction
@@ -242,8 +243,7 @@ def test_b8_model_config5_against_fp32_oracle():
     from oracle.det_init import det_inputs, load_det_state
     from cvae import ClassificationVariationalNetwork as Net
     case = get_case('c5_n4')
-    kw = case['net']
-    N = 16
+    kw = case['net']                       # N = 37: a ragged last batch (bf16 BatchNorm plans with empty trailing parts)
     net = Net(**kw)
     load_det_state(net, seed=0)
     net.to(DEV).train()
