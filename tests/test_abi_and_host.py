@@ -121,6 +121,29 @@ def test_batchnorm_launch_plan_partitions_every_batch_size():
     assert L.jvae_image_range(4, 0, 0, nb, ne) < 0 and L.jvae_image_range(4, 2, 2, nb, ne) < 0
 
 
+def test_batch_size_bounds_and_evaluation_slabs_follow_from_the_tensors():
+    """Host logic only (the model is built on the CPU, nothing is launched): `max_batch_sizes` is derived from the tensors -
+    powers of two, as the reference's halving search returns (cvae.py:1087-1153; it hard-wires 32, cvae.py:1145-1147) - such that
+    the decoder batch times the widest activation (train) and the returned reconstruction (test) stay below 2^31 elements; the
+    label-free evaluation decodes at most 2^28 activation elements per slab."""
+    from cvae import ClassificationVariationalNetwork as Net
+    from oracle.cases import full_config, get_case
+    net = Net(**full_config(2, 8)['net'])
+    assert net._widest_decoder_activation() == 32 * 32 * 32 and net._eval_slab_rows() == 8192
+    mb = net.max_batch_sizes
+    assert mb == {'train': 16384, 'test': 65536}            # L = 1 for both: 2 * 16384 * 32768 = 2^30, 2 * 65536 * 3072 < 2^31
+    kw = dict(get_case('e2_n8_L3')['net'], test_latent_sampling=128)
+    net = Net(**kw)
+    assert net.max_batch_sizes['test'] == 4096               # 129 * 4096 * 3072 = 1.6e9 < 2^31 <= 129 * 8192 * 3072
+    os.environ['JVAE_EVAL_SLAB_ROWS'] = '7'
+    try:
+        assert net._eval_slab_rows() == 7
+    finally:
+        del os.environ['JVAE_EVAL_SLAB_ROWS']
+    mlp = Net(**get_case('c1_n16_mlp')['net'])
+    assert mlp._widest_decoder_activation() >= 784 and mlp.max_batch_sizes['train'] == 1 << 16
+
+
 def test_layer_dsl_shapes():
     from module.vae_layers.conv import build_de_conv_layers, find_input_shape, parse_conv_layer_name
     f = build_de_conv_layers((3, 32, 32), 'conv32', batch_norm=True)
