@@ -201,12 +201,12 @@ def bn_backward_hbm(device, reps=20):
     out = {'bound': 'hbm', 'kernel': 'bn_bwd_reduce_kernel + bn_bwd_apply_kernel: BatchNorm+ReLU backward of imager.16 (1024x32x32x32 fp32), alone',
            'achieved': nbytes / sec / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s', 'frac': nbytes / sec / HBM_PEAK,
            'launch_ms': sec * 1e3, 'algorithmic_bytes': nbytes}
-    prof = os.path.join(REPO, 'profiles', 'r02_bench_kernel_stats.json')
+    prof = os.path.join(REPO, 'profiles', 'r03_bench_kernel_stats.json')
     if os.path.exists(prof):          # the same family inside the step (two streams share the CUs): committed rocprofv3 summary
         d = json.load(open(prof))
         if d.get('bn_bwd_ms_per_step'):
             out['in_step'] = {'ms_per_step': d['bn_bwd_ms_per_step'], 'achieved': 20.0 * 135.7e6 * 4 / 4 / (d['bn_bwd_ms_per_step'] * 1e-3) / 1e9,
-                              'unit': 'GB/s', 'source': 'profiles/r02_bench_kernel_stats.json (rocprofv3 --kernel-trace of bench.py)'}
+                              'unit': 'GB/s', 'source': 'profiles/r03_bench_kernel_stats.json (rocprofv3 --kernel-trace of bench.py)'}
     return out
 
 

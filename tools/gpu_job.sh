@@ -1,5 +1,17 @@
 # scratch GPU job of the current iteration (edited per run)
 set -o pipefail
 R=$GRAFT_REPO_ROOT; cd $R
-bash tools/prof_trace.sh r3m_trace5 --workload 5 --dtype bf16
-cd $R; tail -1 gpurun_out/r3m_trace5/step_trace.txt
+O=gpurun_out/r3n; mkdir -p $O
+timeout -k 10 900 python -m pytest tests -m gpu -x -q > $O/all.log 2>&1; rc=$?; tail -3 $O/all.log
+[ $rc -ne 0 ] && exit $rc
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+python bench.py > $O/bench_n1.json 2> $O/bench_n1.err
+python - <<'PY'
+import json
+d=json.load(open('gpurun_out/r3n/bench_n1.json')); print(round(d['value']), round(d['ms_per_step'],3), round(d['ms_per_step_median'],3), d['steps'], round(d['roofline']['frac'],3), round(d['roofline']['launch_ms']*1e3,1))
+PY
+bash tools/prof_bench.sh r3n_prof > $O/step_breakdown.txt 2>&1; cd $R
+bash tools/prof_noov.sh r3n_noov > $O/step_breakdown_no_overlap.txt 2>&1; cd $R
+cp $(find gpurun_out/r3n_prof -name "*kernel_stats.csv" | head -1) $O/bench_kernel_stats.csv
+cp $(find gpurun_out/r3n_noov -name "*kernel_stats.csv" | head -1) $O/bench_no_overlap_kernel_stats.csv
+head -18 $O/step_breakdown_no_overlap.txt
