@@ -1,17 +1,22 @@
 # scratch GPU job of the current iteration (edited per run)
 set -o pipefail
 R=$GRAFT_REPO_ROOT; cd $R
-O=gpurun_out/r3n; mkdir -p $O
-timeout -k 10 900 python -m pytest tests -m gpu -x -q > $O/all.log 2>&1; rc=$?; tail -3 $O/all.log
-[ $rc -ne 0 ] && exit $rc
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
-python bench.py > $O/bench_n1.json 2> $O/bench_n1.err
+O=gpurun_out/r3o; mkdir -p $O
+JVAE_BENCH_NO_PROBES=1 python bench.py --no-cpu-baseline --steps 3000 --warmup 10 > $O/soak.json 2> $O/soak.err
 python - <<'PY'
 import json
-d=json.load(open('gpurun_out/r3n/bench_n1.json')); print(round(d['value']), round(d['ms_per_step'],3), round(d['ms_per_step_median'],3), d['steps'], round(d['roofline']['frac'],3), round(d['roofline']['launch_ms']*1e3,1))
+d=json.load(open('gpurun_out/r3o/soak.json')); print('soak', round(d['value']), round(d['ms_per_step'],3), round(d['ms_per_step_median'],3), round(d['ms_per_step_min'],3), d['final_loss'])
 PY
-bash tools/prof_bench.sh r3n_prof > $O/step_breakdown.txt 2>&1; cd $R
-bash tools/prof_noov.sh r3n_noov > $O/step_breakdown_no_overlap.txt 2>&1; cd $R
-cp $(find gpurun_out/r3n_prof -name "*kernel_stats.csv" | head -1) $O/bench_kernel_stats.csv
-cp $(find gpurun_out/r3n_noov -name "*kernel_stats.csv" | head -1) $O/bench_no_overlap_kernel_stats.csv
-head -18 $O/step_breakdown_no_overlap.txt
+python - <<'PY'
+import sys, os, torch, time
+sys.path[:0]=[os.getcwd(), os.path.join(os.getcwd(),'joint-vae_amd')]
+import bench
+net = bench.build_model(torch.device('cuda',0), 2)
+x = torch.rand(512,3,32,32,device='cuda'); y = torch.randint(0,10,(512,),device='cuda')
+m=None
+for i in range(50): _, m = net.train_step(x,y,batch=i,current_measures=m)
+torch.cuda.synchronize(); a0=torch.cuda.memory_allocated(); r0=torch.cuda.memory_reserved()
+for i in range(1500): _, m = net.train_step(x,y,batch=i,current_measures=m)
+torch.cuda.synchronize(); a1=torch.cuda.memory_allocated(); r1=torch.cuda.memory_reserved()
+print('memory allocated MB', a0>>20, a1>>20, 'reserved MB', r0>>20, r1>>20, 'rmse', m['rmse'])
+PY
