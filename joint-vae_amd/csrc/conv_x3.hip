@@ -343,7 +343,9 @@ thread_local int g_x3_splits = 0;
 template <int S, int OW, int MT>
 int launch_x3(const X3P& p, hipStream_t st) {
     using G = X3Geom<S, OW, MT>;
-    static_assert(G::LDS_BYTES + 2048 <= 80 * 1024, "two workgroups per CU must fit the 160 KB LDS");
+    // stride 1: two workgroups per CU; stride 2 (the patch is 4x the output pixels): ONE 4-wave workgroup per CU (see
+    // jvae_conv5_x3_ok)
+    static_assert(G::LDS_BYTES + 2048 <= (S == 1 ? 80 : 160) * 1024, "workgroups per CU vs the 160 KB LDS");
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_x3_kernel<S, OW, MT, false>),
@@ -402,7 +404,19 @@ int jvae_conv5_x3_wpack(const float* w, float* ws, int C, int O, int swap, int f
 bool jvae_conv5_x3_ok(int Cin, int H, int W, int Cout, int OH, int OW, int S, int P) {
     x3_init();
     if (!g_x3) return false;
-    if (S != 1 || Cin < 16 || Cin > 256) return false;
+    if (Cin < 16 || Cin > 256) return false;
+    if (S == 2) {
+        // Stride-2 forward-type layers (E1 / E3 forward, D2 / D4 dgrad of conv32 / deconv32): the patch of 128 output pixels is
+        // 19 rows x 39 columns x 16 channels x 3 planes = 71-84 KB, + 30 KB of weights: ONE workgroup (4 waves) per CU instead
+        // of two.  MEASURED SLOWER than the fp32 matrix-core kernel (round 3, one box: E1 forward 96.7 vs 70.7 us, E3 84.0 vs
+        // 71.3, D2 dgrad 118.8 vs 113.6, D4 dgrad 126.4 vs 113.1; the step 4.00 vs 3.84 ms): with one workgroup per CU nothing
+        // runs under its staging phases.  OFF by default; JVAE_X3_S2=1 selects it (A/B switch).
+        static int s2 = -1;
+        if (s2 < 0) { const char* e = getenv("JVAE_X3_S2"); s2 = (e && e[0] == '1') ? 1 : 0; }
+        if (!s2 || (OW != 8 && OW != 16)) return false;
+        return jvae_conv5_fwd_ok(Cin, H, W, Cout, OH, OW, S, P);
+    }
+    if (S != 1) return false;
     if (OW != 8 && OW != 16 && OW != 32 && OW != 64) return false;
     return jvae_conv5_fwd_ok(Cin, H, W, Cout, OH, OW, S, P);
 }
@@ -426,6 +440,13 @@ int jvae_conv5_x3_fwd(const float* in, const float* w, int swap, int flip, const
     }
     X3P p{in, (const u32x4*)ws, bias, out, N, Cin, H, W, OP, P, Cout, stats, aff ? *aff : InAff{nullptr, nullptr, 0}};
     struct Fin { int* n; ~Fin() { if (n) *n = g_x3_splits; } } fin{nsplit};
+    if (S == 2) {
+        switch (OW) {
+            case 8: return launch_x3<2, 8, 1>(p, st);
+            case 16: return launch_x3<2, 16, 1>(p, st);
+        }
+        return JVAE_ENOTSUP;
+    }
     if (S != 1) return JVAE_ENOTSUP;
     switch (OW) {
         case 8: return launch_x3<1, 8, 1>(p, st);
