@@ -241,12 +241,13 @@ struct GxImg {
     static constexpr int BYTES = PITCH * ROWS;            // one plane
 };
 
-// DEPTH: K steps whose global loads are in flight in registers ahead of the one being multiplied.  The products served here
-// are a few hundred workgroups of 10 - 30 K steps each: with ONE step in flight every step paid a full load latency
-// (~2 us per step: M = 512, N = 200, K = 3136 in 5 slices took 40 us for 6 us of matrix work, profiles/r03_step_trace_no_overlap.txt);
-// with DEPTH = 3 three steps' loads overlap.  The deep variant takes 16-byte loads only (vecA && vecB, K range a multiple of
-// 4) and loads UNCONDITIONALLY - out-of-range groups read a valid stand-in address and are zeroed when they are stored to LDS -
-// so that the compiler can count the loads in flight (a branch around a load forces s_waitcnt vmcnt(0)).
+// DEPTH: K steps whose global loads are in flight in registers ahead of the one being multiplied.  The deep variant (3) takes
+// 16-byte loads only (vecA && vecB, K range a multiple of 4) and loads UNCONDITIONALLY - out-of-range groups read a valid stand-in
+// address and are zeroed when they are stored to LDS - so that the compiler can count the loads in flight (a branch around a load
+// forces s_waitcnt vmcnt(0)).  Measured (round 3, profiles/r03_step_trace_no_overlap.txt): -9 ... +7 % per product, -3 us per
+// step - these products are bound neither by load latency nor by the operand split but by the L2 / Infinity-Cache traffic of
+// 64 x 64 tiles ((64 + 64) K operand elements per 64 * 64 * K multiplications: the 7x7 head's forward moves 205 MB for 32 MB of
+// distinct data).  JVAE_GEMM_DEPTH=1 selects the one-stage form.
 template <bool AK, bool BNC, int DEPTH = 1>
 __global__ __launch_bounds__(256, 4) void gemm_x3_kernel(GemmP p) {
     using IA = GxImg<AK>;
