@@ -209,8 +209,10 @@ inline int fwd_slices(const ConvGeom& g) {
     const long Kd = (long)g.Cb * g.KH * g.KW;
     const long tiles = (long)cdiv(g.N, 64) * cdiv(g.Cs, 64) * g.Hs * g.Ws;
     if (tiles >= 512 || Kd < 1024) return 1;
-    int s = (int)(512 / tiles) + 1;
-    return s > 8 ? 8 : s;
+    // at most one residency round (2 workgroups x 256 CUs of gemm_x3_kernel); measured neutral against one slice more
+    // (features.12 of conv32: 36.9 vs 36.4 us) - one partial result less to fold
+    int s = (int)(512 / tiles);
+    return s > 8 ? 8 : (s < 1 ? 1 : s);
 }
 
 // Yt[q][n][cs] = Ys[n][cs][q]

@@ -32,6 +32,7 @@ struct GemmP {
     int flags;           // 1 = accumulate into C, 2 = ReLU, 4 = atomic add (split-K), 8 = split s stores to C + s*sCsplit
     long sCsplit;        // (flag 8) element distance between the partial results of consecutive K splits
     int vecA, vecB;      // 16-byte vector loads are legal for this operand
+    int xcd;             // gemm_x3_kernel: XCD-aware tile order
 };
 
 // 4 consecutive elements along the contiguous direction, zero-filled outside [0,lim).
@@ -262,8 +263,16 @@ __global__ __launch_bounds__(256, 4) void gemm_x3_kernel(GemmP p) {
     const int half = lane >> 5, l31 = lane & 31;
     const int cg = (lane >> 4) & 1, q4 = (lane & 15) >> 2, pp = lane & 3;      // transposed-read roles
     const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int batch = blockIdx.z / p.splitk, split = blockIdx.z % p.splitk;
+    // XCD-aware tile order (JVAE_GEMM_XCD, default on): consecutive workgroup ids go round-robin to the 8 XCDs, so the tiles of
+    // one (batch, K slice) - which share their A rows and B columns - used to be spread over all eight L2s.  Workgroup
+    // w = (xcd, k) takes tile xcd * (tiles / 8) + k of the (z, y, x) order: one XCD works through whole (batch, K slice) planes.
+    unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (p.xcd) {
+        const unsigned lin = (unsigned)xcd_tile(bx + gridDim.x * (by + gridDim.y * bz), gridDim.x * gridDim.y * gridDim.z);
+        bx = lin % gridDim.x; by = (lin / gridDim.x) % gridDim.y; bz = lin / (gridDim.x * gridDim.y);
+    }
+    const int m0 = by * BM, n0 = bx * BN;
+    const int batch = bz / p.splitk, split = bz % p.splitk;
     const int kbeg = split * p.kchunk;
     const int kend = min(p.K, kbeg + p.kchunk);
     const float* A = p.A + (long)batch * p.sAb;
@@ -452,7 +461,12 @@ int launch_x3_ab(const GemmP& p, int batch, hipStream_t st) {
     return launch_x3_variant<AK, BNC, 1>(p, batch, st);
 }
 
-int launch_x3(const GemmP& p, int batch, hipStream_t st) {
+static int g_gemm_xcd = -1;      // JVAE_GEMM_XCD=0: hardware tile order (A/B switch)
+
+int launch_x3(const GemmP& p0, int batch, hipStream_t st) {
+    if (g_gemm_xcd < 0) { const char* e = getenv("JVAE_GEMM_XCD"); g_gemm_xcd = (e && e[0] == '0') ? 0 : 1; }
+    GemmP p = p0;
+    p.xcd = g_gemm_xcd;
     const bool ak = (p.sAk == 1), bnc = (p.sBn == 1);
     if (ak && bnc) return launch_x3_ab<true, true>(p, batch, st);
     if (ak) return launch_x3_ab<true, false>(p, batch, st);

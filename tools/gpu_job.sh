@@ -1,4 +1,8 @@
 # scratch GPU job of the current iteration (edited per run)
+set -o pipefail
 R=$GRAFT_REPO_ROOT; cd $R
-mkdir -p gpurun_out/r3q
-python tools/aten_ops.py > gpurun_out/r3q/aten.txt 2>&1; tail -40 gpurun_out/r3q/aten.txt
+O=gpurun_out/r3s; mkdir -p $O
+timeout -k 10 600 python -m pytest tests/test_0_ops_gpu.py -x -q -k "conv or head" > $O/t.log 2>&1; rc=$?; tail -2 $O/t.log
+[ $rc -ne 0 ] && exit $rc
+bash tools/prof_trace.sh r3s_t; cd $R
+grep "gemm\|unfold\|fold" gpurun_out/r3s_t/step_trace.txt | cut -c1-12,40-90 | head -30; tail -1 gpurun_out/r3s_t/step_trace.txt
