@@ -1,12 +1,9 @@
 # scratch GPU job of the current iteration (edited per run)
 set -o pipefail
 R=$GRAFT_REPO_ROOT; cd $R
-O=gpurun_out/r3t; mkdir -p $O
-timeout -k 10 900 python -m pytest tests -m gpu -x -q > $O/all.log 2>&1; rc=$?; tail -3 $O/all.log
+O=gpurun_out/r3x; mkdir -p $O
+timeout -k 10 600 python -m pytest tests/test_0_ops_gpu.py -x -q -k "gemm or linear or conv or head or point" > $O/t.log 2>&1; rc=$?; tail -2 $O/t.log
 [ $rc -ne 0 ] && exit $rc
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
-python bench.py > $O/bench_n1.json 2> $O/bench_n1.err
-python - <<'PY'
-import json
-d=json.load(open('gpurun_out/r3t/bench_n1.json')); print(round(d['value']), round(d['ms_per_step'],3), round(d['ms_per_step_median'],3), d['steps'], round(d['roofline']['frac'],3), round(d['roofline']['launch_ms']*1e3,1), round(d['cpu_baseline']['value'],1))
-PY
+bash tools/prof_trace.sh r3x_t; cd $R
+grep "gemm" gpurun_out/r3x_t/step_trace.txt | cut -c1-12,40-90 | head -30; tail -1 gpurun_out/r3x_t/step_trace.txt
+bash tools/ab_step.sh "depth3 JVAE_GEMM_DEPTH=3" "db JVAE_GEMM_DEPTH=2" 2>&1 | tee $O/ab.log
