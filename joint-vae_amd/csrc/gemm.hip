@@ -249,31 +249,8 @@ struct GxImg {
 // step - these products are bound neither by load latency nor by the operand split but by the L2 / Infinity-Cache traffic of
 // 64 x 64 tiles ((64 + 64) K operand elements per 64 * 64 * K multiplications: the 7x7 head's forward moves 205 MB for 32 MB of
 // distinct data).  JVAE_GEMM_DEPTH=1 selects the one-stage form.
-#ifdef JVAE_GEMM_STAMPS
-// Diagnostic build only (tools/gemm_stamps.sh): shader-clock cycles of wave 0 of every workgroup, summed over the launch, spent
-// in the phases of a K step: [0] barrier 1, [1] register -> LDS (incl. the wait for the stage's global loads), [2] barrier 2,
-// [3] issue of the next loads, [4] fragment reads + MFMA issue, [5] K steps counted, [6] prologue, [7] epilogue.
-__device__ unsigned long long g_gemm_stamps[8];
-#define GX_STAMP(i, t0) do { const unsigned long long t1__ = __builtin_amdgcn_s_memtime(); st_acc[i] += t1__ - (t0); (t0) = t1__; } while (0)
-#else
-#define GX_STAMP(i, t0) do { } while (0)
-#endif
-
-// DB (with DEPTH = 2): TWO LDS images.  The phase stamps of the single-image form (tools/gemm_stamps.py, round 3) read, per K
-// step and wave: registers -> LDS (the operand split: ~200 vector instructions) 1270 cycles, fragment reads + 12 dependent MFMAs
-// 1370, two barriers 570, load issue 270 - STRICTLY ONE AFTER THE OTHER inside a workgroup (the barriers separate them), ~3500
-// cycles for 384 cycles of matrix-pipe issue; that - not load latency, not the split alone, not cache locality - is why nothing
-// moved these products.  With two images the split + LDS stores of step i+1 are issued BETWEEN the MFMAs of step i (same basic
-// block: the vector ALU works while the matrix pipe drains the dependent chain), one barrier per step remains.  MEASURED (round 3,
-// one box): the 25-step forward product of the 7x7 head 36 -> 34 us, but its 7-step dgrad and 16-step weight-gradient products
-// 36 -> 47 / 45 us (two images = two workgroups per CU instead of four), the step unchanged: NOT the default (JVAE_GEMM_DEPTH=2).
-template <bool AK, bool BNC, int DEPTH = 1, bool DB = false>
+template <bool AK, bool BNC, int DEPTH = 1>
 __global__ __launch_bounds__(256, 4) void gemm_x3_kernel(GemmP p) {
-    static_assert(!DB || DEPTH == 2, "double-buffered LDS images rotate two register stages");
-#ifdef JVAE_GEMM_STAMPS
-    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long st_t = __builtin_amdgcn_s_memtime();
-#endif
     using IA = GxImg<AK>;
     using IB = GxImg<!BNC>;
     constexpr int BM = 64, BN = 64, G4 = BM * BKX / 4 / 256;   // float4 groups per thread and operand
@@ -281,7 +258,6 @@ __global__ __launch_bounds__(256, 4) void gemm_x3_kernel(GemmP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char gx_lds[];
     unsigned char* As = gx_lds;                                 // [3 planes][IA::BYTES]
     unsigned char* Bs = gx_lds + 3 * IA::BYTES;                 // [3 planes][IB::BYTES]
-    constexpr int IMG = 3 * (IA::BYTES + IB::BYTES);            // DB: the second image sits IMG bytes further
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
@@ -357,9 +333,9 @@ __global__ __launch_bounds__(256, 4) void gemm_x3_kernel(GemmP p) {
             }
         }
     };
-    auto lstore = [&](int st, int k0, int buf = 0, int g_lo = 0, int g_hi = G4) {
+    auto lstore = [&](int st, int k0) {
 #pragma unroll
-        for (int g = g_lo; g < g_hi; ++g) {
+        for (int g = 0; g < G4; ++g) {
             // the contiguous direction runs fastest over the threads, as in gload
             const int fa = AK ? tid % KQX : tid % 16, sa_ = AK ? tid / KQX + g * (256 / KQX) : tid / 16 + g * 16;
             const int fb = BNC ? tid % 16 : tid % KQX, sb_ = BNC ? tid / 16 + g * 16 : tid / KQX + g * (256 / KQX);
@@ -376,8 +352,8 @@ __global__ __launch_bounds__(256, 4) void gemm_x3_kernel(GemmP p) {
             gx_split4(vb, sb);
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) {
-                *reinterpret_cast<gx_u32x2*>(As + buf * IMG + pl * IA::BYTES + sa_ * IA::PITCH + fa * 8) = sa[pl];
-                *reinterpret_cast<gx_u32x2*>(Bs + buf * IMG + pl * IB::BYTES + sb_ * IB::PITCH + fb * 8) = sb[pl];
+                *reinterpret_cast<gx_u32x2*>(As + pl * IA::BYTES + sa_ * IA::PITCH + fa * 8) = sa[pl];
+                *reinterpret_cast<gx_u32x2*>(Bs + pl * IB::BYTES + sb_ * IB::PITCH + fb * 8) = sb[pl];
             }
         }
     };
@@ -391,87 +367,37 @@ __global__ __launch_bounds__(256, 4) void gemm_x3_kernel(GemmP p) {
         return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     };
 
-    auto multiply_ks = [&](int buf, int ks) {
-        gx_bf16x8 a[3], b[3];
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
-            a[pl] = frag(As + buf * IMG + pl * IA::BYTES, AK, IA::PITCH, wm0, ks);
-            b[pl] = frag(Bs + buf * IMG + pl * IB::BYTES, !BNC, IB::PITCH, wn0, ks);
-        }
-        constexpr int APL[6] = {0, 2, 1, 0, 1, 0}, BPL[6] = {2, 0, 1, 1, 0, 0};      // small products first
-#pragma unroll
-        for (int t = 0; t < 6; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[APL[t]], b[BPL[t]], acc, 0, 0, 0);
-    };
     auto multiply = [&]() {
 #pragma unroll
-        for (int ks = 0; ks < BKX / 16; ++ks) multiply_ks(0, ks);
-    };
-    // LDS-only barrier: __syncthreads() also waits for vmcnt(0) - for EVERY global load in flight, i.e. for the prefetched
-    // stages - which exposed a full load latency per K step whatever the prefetch depth (the reason why neither deeper
-    // prefetch, nor pre-split operands, nor cache locality moved these products: DESIGN.md section 9)
-    auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-    if constexpr (DB) {
-        static_assert(BKX / 16 == 2 && G4 == 2, "one float4 group of each operand per MFMA half step");
-        // step i: ONE barrier, then the MFMAs of step i (image i & 1) with the split + LDS stores of step i+1 (register stage
-        // (i+1) & 1 -> image (i+1) & 1) issued between its two halves, then the loads of step i+3 into the freed stage
-        auto step = [&](int i, int kk) {               // i: parity only (compile-time after unrolling)
-            const int cur = i & 1, nxt = cur ^ 1;
-            lds_barrier();                             // image cur is complete; every wave is past its reads of image nxt
-            GX_STAMP(0, st_t);
-            multiply_ks(cur, 0);
-            lstore(nxt, kk + BKX, nxt, 0, 1);
-            multiply_ks(cur, 1);
-            lstore(nxt, kk + BKX, nxt, 1, 2);
-            GX_STAMP(4, st_t);
-            gload(nxt, kk + 3 * BKX);
-            GX_STAMP(3, st_t);
-#ifdef JVAE_GEMM_STAMPS
-            st_acc[5] += 1;
-#endif
-        };
-        gload(0, kbeg);
-        gload(1, kbeg + BKX);
-        lstore(0, kbeg, 0);
-        gload(0, kbeg + 2 * BKX);
-        GX_STAMP(6, st_t);
-        const int nsteps = (kend - kbeg + BKX - 1) / BKX;
-        int k0 = kbeg;
-        for (int i = 0; i + 2 <= nsteps; i += 2, k0 += 2 * BKX) {       // no branch inside: the loads in flight stay countable
-            step(0, k0);
-            step(1, k0 + BKX);
+        for (int ks = 0; ks < BKX / 16; ++ks) {
+            gx_bf16x8 a[3], b[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                a[pl] = frag(As + pl * IA::BYTES, AK, IA::PITCH, wm0, ks);
+                b[pl] = frag(Bs + pl * IB::BYTES, !BNC, IB::PITCH, wn0, ks);
+            }
+            constexpr int APL[6] = {0, 2, 1, 0, 1, 0}, BPL[6] = {2, 0, 1, 1, 0, 0};      // small products first
+#pragma unroll
+            for (int t = 0; t < 6; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[APL[t]], b[BPL[t]], acc, 0, 0, 0);
         }
-        if (nsteps & 1) step(0, k0);
-    } else if constexpr (DEPTH > 1) {
+    };
+    if constexpr (DEPTH > 1) {
         // prologue: DEPTH steps in flight (steps beyond kend load the stand-in address: harmless, never stored)
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) gload(d, kbeg + d * BKX);
-        GX_STAMP(6, st_t);
-        auto stage = [&](int d, int kk) {
-            lds_barrier();                       // previous tile's fragment reads are done
-            GX_STAMP(0, st_t);
-            lstore(d, kk);                       // waits (vmcnt) for stage d only: the later stages stay in flight
-            GX_STAMP(1, st_t);
-            lds_barrier();
-            GX_STAMP(2, st_t);
-            gload(d, kk + DEPTH * BKX);          // stage d is free again: DEPTH steps ahead, under the MFMAs below
-            GX_STAMP(3, st_t);
-            multiply();
-            GX_STAMP(4, st_t);
-#ifdef JVAE_GEMM_STAMPS
-            st_acc[5] += 1;
-#endif
-        };
-        // whole groups of DEPTH steps WITHOUT a branch inside the loop (a branch around a load makes the compiler give up
-        // counting the loads in flight: it then drains them all, vmcnt(0), once per trip); the last 1 .. DEPTH-1 steps follow
-        const int nsteps = (kend - kbeg + BKX - 1) / BKX;
-        int k0 = kbeg;
-        for (int i = 0; i + DEPTH <= nsteps; i += DEPTH, k0 += DEPTH * BKX) {
+        for (int k0 = kbeg; k0 < kend; k0 += DEPTH * BKX) {
 #pragma unroll
-            for (int d = 0; d < DEPTH; ++d) stage(d, k0 + d * BKX);
+            for (int d = 0; d < DEPTH; ++d) {
+                const int kk = k0 + d * BKX;
+                if (kk < kend) {                         // block-uniform
+                    __syncthreads();                     // previous tile's fragment reads are done
+                    lstore(d, kk);
+                    __syncthreads();
+                    gload(d, kk + DEPTH * BKX);          // stage d is free again: three steps ahead, under the MFMAs below
+                    multiply();
+                }
+            }
         }
-#pragma unroll
-        for (int d = 0; d < DEPTH - 1; ++d)
-            if (k0 + d * BKX < kend) stage(d, k0 + d * BKX);       // block-uniform
     } else {
         if (kbeg < kend) gload(0, kbeg);
         for (int k0 = kbeg; k0 < kend; k0 += BKX) {
@@ -486,12 +412,12 @@ __global__ __launch_bounds__(256, 4) void gemm_x3_kernel(GemmP p) {
     // epilogue (as gemm_kernel): D[i][j]: j = lane&31, i = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const bool lead = (split == 0) && !(p.flags & 8);
     const int n = n0 + wn0 + l31;
-    const bool live_col = n < p.N;
-    const float bn = (p.bias_mode == 1 && lead && live_col) ? p.bias[n / p.bias_div] : 0.f;
+    if (n >= p.N) return;
+    const float bn = (p.bias_mode == 1 && lead) ? p.bias[n / p.bias_div] : 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int m = m0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (m >= p.M || !live_col) continue;
+        if (m >= p.M) continue;
         float v = acc[r] + bn;
         if (p.bias_mode == 2 && lead) v += p.bias[m];
         float* dst = C + (long)m * p.sCm + (long)n * p.sCn;
@@ -505,41 +431,32 @@ __global__ __launch_bounds__(256, 4) void gemm_x3_kernel(GemmP p) {
             *dst = v;
         }
     }
-#ifdef JVAE_GEMM_STAMPS
-    GX_STAMP(4, st_t);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    GX_STAMP(7, st_t);
-    if (threadIdx.x == 0)
-        for (int i = 0; i < 8; ++i) atomicAdd(&g_gemm_stamps[i], st_acc[i]);
-#endif
 }
 
-template <bool AK, bool BNC, int DEPTH, bool DB = false>
+template <bool AK, bool BNC, int DEPTH>
 int launch_x3_variant(const GemmP& p, int batch, hipStream_t st) {
-    constexpr int LDS = (DB ? 2 : 1) * 3 * (GxImg<AK>::BYTES + GxImg<!BNC>::BYTES);
+    constexpr int LDS = 3 * (GxImg<AK>::BYTES + GxImg<!BNC>::BYTES);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x3_kernel<AK, BNC, DEPTH, DB>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x3_kernel<AK, BNC, DEPTH>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     dim3 grid(cdiv(p.N, 64), cdiv(p.M, 64), batch * p.splitk), block(256);
-    hipLaunchKernelGGL((gemm_x3_kernel<AK, BNC, DEPTH, DB>), grid, block, LDS, st, p);
+    hipLaunchKernelGGL((gemm_x3_kernel<AK, BNC, DEPTH>), grid, block, LDS, st, p);
     JVAE_LAUNCH_CHECK();
     return 0;
 }
 
-static int g_gemm_depth = -1;    // JVAE_GEMM_DEPTH: 1 = one K step in flight (the round-2 kernel), 3 (default) = three register stages, one
-                                 // LDS image, 2 = two register stages + two LDS images (A/B switches)
+static int g_gemm_depth = -1;    // JVAE_GEMM_DEPTH=1: one K step in flight (the round-2 kernel; A/B switch)
 
 template <bool AK, bool BNC>
 int launch_x3_ab(const GemmP& p, int batch, hipStream_t st) {
-    if (g_gemm_depth < 0) { const char* e = getenv("JVAE_GEMM_DEPTH"); g_gemm_depth = (e && e[0] == '1') ? 1 : ((e && e[0] == '2') ? 2 : 3); }
+    if (g_gemm_depth < 0) { const char* e = getenv("JVAE_GEMM_DEPTH"); g_gemm_depth = (e && e[0] == '1') ? 1 : 3; }
     // deep prefetch: 16-byte loads on both operands, K range a multiple of 4 (kchunk is a multiple of 32)
     const bool deep = g_gemm_depth > 1 && p.vecA && p.vecB && p.K % 4 == 0
                       && (AK || p.M % 4 == 0) && (!BNC || p.N % 4 == 0);
-    if (deep && g_gemm_depth == 2) return launch_x3_variant<AK, BNC, 2, true>(p, batch, st);      // two LDS images (measured: see DB)
     if (deep) return launch_x3_variant<AK, BNC, 3>(p, batch, st);
     return launch_x3_variant<AK, BNC, 1>(p, batch, st);
 }
@@ -680,15 +597,3 @@ extern "C" int jvae_gemm_f32(int M, int N, int K, int batch,
     return jvae_gemm_launch(M, N, K, batch, A, sAm, sAk, sAb, B, sBk, sBn, sBb, C, sCm, sCn, sCb,
                             bias, bias_mode, flags, splitk, (hipStream_t)stream);
 }
-
-#ifdef JVAE_GEMM_STAMPS
-extern "C" int jvae_debug_gemm_stamps(unsigned long long* host8, int reset) {
-    hipError_t e = hipDeviceSynchronize();
-    if (e == hipSuccess && host8) e = hipMemcpyFromSymbol(host8, HIP_SYMBOL(g_gemm_stamps), 8 * sizeof(unsigned long long));
-    if (e == hipSuccess && reset) {
-        const unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        e = hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_stamps), z, sizeof(z));
-    }
-    return (int)e;
-}
-#endif
