@@ -1,8 +1,12 @@
-# scratch GPU job of the current iteration (edited per run)
+# GPU box: the checks of a finished change, in the order the driver runs them (usage: gpurun -- 'bash tools/gpu_job.sh').
 set -o pipefail
 R=$GRAFT_REPO_ROOT; cd $R
-O=gpurun_out/r3y; mkdir -p $O
-bash tools/prof_trace.sh r3y_t; cd $R
-grep "gemm" gpurun_out/r3y_t/step_trace.txt | cut -c1-12,40-90 | head -30; tail -1 gpurun_out/r3y_t/step_trace.txt
-JVAE_GEMM_DEPTH=1 bash tools/prof_trace.sh r3y_t1; cd $R
-grep "gemm" gpurun_out/r3y_t1/step_trace.txt | cut -c1-12,40-90 | head -30; tail -1 gpurun_out/r3y_t1/step_trace.txt
+O=gpurun_out/check; mkdir -p $O
+timeout -k 10 900 python -m pytest tests -m gpu -x -q > $O/all.log 2>&1; rc=$?; tail -3 $O/all.log
+[ $rc -ne 0 ] && exit $rc
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+python bench.py > $O/bench_n1.json 2> $O/bench_n1.err
+python - <<'PY'
+import json
+d=json.load(open('gpurun_out/check/bench_n1.json')); print(round(d['value']), round(d['ms_per_step'],3), round(d['ms_per_step_median'],3), d['steps'], round(d['roofline']['frac'],3), round(d['roofline']['launch_ms']*1e3,1), round(d['cpu_baseline']['value'],1))
+PY
