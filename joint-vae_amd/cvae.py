@@ -397,7 +397,8 @@ class ClassificationVariationalNetwork(nn.Module):
         (cvae.py:1087-1143).  Here the bounds follow from the tensors themselves (powers of two, as the search returns):
         train - the decoder batch (L+1)*N times the widest activation stays below 2^31 elements (one launch chain, every
         activation kept for backward: ~3 MB per image of config 2, 50 GB at the bound); test - the label-free evaluation
-        decodes in slabs (`_decode`), so only the returned reconstruction (L_test+1, N, ...) must stay below 2^31 elements."""
+        decodes in slabs (`_decode`), so only the returned reconstruction (L_test+1, N, ...) and, for a class-conditional prior, the
+        (L_test, C, N, K) latents scored under every class must stay below 2^31 elements."""
         def pow2_below(v):
             v = max(int(v), 1)
             return 1 << (v.bit_length() - 1)
@@ -408,6 +409,10 @@ class ClassificationVariationalNetwork(nn.Module):
         reco = int(np.prod(self._reco_shape()))
         train = pow2_below(lim // ((self._latent_samplings['train'] + 1) * wide))
         test = pow2_below(lim // ((self._latent_samplings['eval'] + 1) * reco))
+        if self.encoder.prior.conditional:
+            # the importance weights of the label-free evaluation score every draw under every class: (L, C, N, K) latents
+            # go through the prior's Mahalanobis kernel as ONE tensor (cvae.py:793-873)
+            test = min(test, pow2_below(lim // (max(self._latent_samplings['eval'], 1) * self.num_labels * self.latent_dim)))
         return {'train': min(train, 1 << 16), 'test': min(test, 1 << 16)}
 
     # ------------------------------------------------------------------------------------ forward

@@ -135,6 +135,8 @@ def test_batch_size_bounds_and_evaluation_slabs_follow_from_the_tensors():
     kw = dict(get_case('e2_n8_L3')['net'], test_latent_sampling=128)
     net = Net(**kw)
     assert net.max_batch_sizes['test'] == 4096               # 129 * 4096 * 3072 = 1.6e9 < 2^31 <= 129 * 8192 * 3072
+    c100 = Net(**dict(full_config(3, 8)['net'], test_latent_sampling=128))
+    assert c100.max_batch_sizes['test'] == 2048              # (L, C, N, K) = 128 * 100 * 2048 * 64 = 1.7e9 < 2^31
     os.environ['JVAE_EVAL_SLAB_ROWS'] = '7'
     try:
         assert net._eval_slab_rows() == 7
