@@ -210,10 +210,13 @@ def bn_backward_hbm(device, reps=20):
     return out
 
 
-def cpu_baseline(max_seconds=30.0):
+def cpu_baseline(max_seconds=60.0):
     """The CPU oracle (PyTorch-CPU restatement of the reference step, pinned to the reference's goldens) on the host
-    cores, bounded samples of the same workload: bs=512 (the metric's batch) and bs=32 (what the reference's unmodified
-    train.py would run: its max_batch_sizes is hard-wired to 32); median step time after warm-up steps."""
+    cores, bounded samples of the same workload.  bs=512 (the metric's batch) is timed at several intra-op thread counts -
+    1 warm-up + 2 steps each, about a minute in all - and the BEST is reported with its thread count as `cores` (VERDICT r3:
+    PyTorch's default of one thread per logical CPU, 128-256 on the GPU boxes, oversubscribes MKL-DNN and ran the same code
+    2.6x slower than 8 threads do); the whole sweep stays in the JSON.  bs=32 (what the reference's unmodified train.py would
+    run: its max_batch_sizes is hard-wired to 32) is timed at the best count of the sweep and at 8 threads."""
     import platform
     import statistics
     from oracle import jvae_oracle as O
@@ -227,28 +230,51 @@ def cpu_baseline(max_seconds=30.0):
                 break
     except OSError:
         pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        usable = os.cpu_count() or 1
+    default_threads = torch.get_num_threads()
 
-    def run(bs, steps, budget):
+    def run(bs, steps, budget, warm):
         kw = full_config(2, bs)['net']
         sp = O.make_spec(**kw)
         P = O.init_state(sp, seed=0)
         opt = O.AdamState(sp)
         x, y, eps = det_inputs(bs, kw['input_shape'], 10, 1, 64, seed=1234)
-        for _ in range(1 if bs >= 256 else 3):
+        for _ in range(warm):
             O.train_step(sp, P, opt, x, y, eps)               # warm-up
         times, t_start = [], time.time()
-        while len(times) < steps and time.time() - t_start < budget:
+        while len(times) < steps and (not times or time.time() - t_start < budget):
             t0 = time.time()
             O.train_step(sp, P, opt, x, y, eps)
             times.append(time.time() - t0)
         med = statistics.median(times)
-        return {'batch': bs, 'steps': len(times), 'median_s_per_step': med, 'min_s_per_step': min(times), 'images_per_s': bs / med}
-    big = run(BATCH_PER_GPU, 5, max_seconds)             # ~25 s of CPU work: a bounded sample, not the metric
-    small = run(32, 12, 8.0)
-    return {'value': big['images_per_s'], 'unit': 'images/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': f'{big["steps"]} train steps of bs={BATCH_PER_GPU} (config 2) after 1 warm-up step, median step time, with the '
-                      f'PyTorch-CPU oracle; {os.cpu_count()} logical CPUs visible, CPU: {model}',
-            'cpu_model': model, 'bs512': big, 'bs32': small}
+        return {'batch': bs, 'threads': torch.get_num_threads(), 'steps': len(times), 'median_s_per_step': med,
+                'min_s_per_step': min(times), 'images_per_s': bs / med}
+    t_sweep = time.time()
+    sweep = []
+    try:
+        for nt in (8, 16, 32, 64, 128):
+            if nt > max(usable, 8) or (sweep and time.time() - t_sweep > max_seconds):
+                break
+            torch.set_num_threads(nt)
+            sweep.append(run(BATCH_PER_GPU, 2, max_seconds / 4, 1))
+        best = max(sweep, key=lambda r: r['images_per_s'])
+        torch.set_num_threads(best['threads'])
+        small = [run(32, 10, 4.0, 3)]
+        if best['threads'] != 8:
+            torch.set_num_threads(8)
+            small.append(run(32, 10, 4.0, 3))
+    finally:
+        torch.set_num_threads(default_threads)
+    small_best = max(small, key=lambda r: r['images_per_s'])
+    return {'value': best['images_per_s'], 'unit': 'images/s', 'cores': best['threads'], 'kind': 'port',
+            'sample': f'bs={BATCH_PER_GPU} train steps of config 2 with the PyTorch-CPU oracle, 2 timed steps after 1 warm-up at each of '
+                      f'{[r["threads"] for r in sweep]} intra-op threads, best median reported (cores = its thread count); '
+                      f'{os.cpu_count()} logical CPUs visible, {usable} usable by this process, CPU: {model}',
+            'cpu_model': model, 'logical_cpus': os.cpu_count(), 'usable_cpus': usable, 'torch_default_threads': default_threads,
+            'thread_sweep_bs512': sweep, 'bs512': best, 'bs32': small_best, 'bs32_runs': small}
 
 
 def _watchdog(seconds):

@@ -77,15 +77,19 @@ int jvae_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, float* dbi
 
 /* ---- per-step cache of the re-packed convolution weights (csrc/pack_cache.hip; no reference counterpart: PyTorch re-lays
  * weights out inside its conv library).  The 5x5 kernels read their weights in a packed operand layout that depends on the
- * weights only; the host brackets the span in which the weights are constant (evaluate() ... backward of cvae.py:2429-2461):
- * begin() re-packs every registered (weight, layout) pair in ONE launch and arms the lookups, the convolution entry points then
- * skip their own pack launch, end() disarms (the optimiser is about to change the weights).  Outside a bracket every convolution
- * packs for itself, as without a cache.  configure(): caller-owned persistent device buffer (256-byte aligned; NULL = off);
- * owner: a value that changes whenever the set of weight ADDRESSES in use changes (entries of another owner are dropped before
- * the refresh reads them).  stats(): host-side counters for tests. */
+ * weights only; the host brackets the span in which the weights are constant (evaluate() ... end of backward of
+ * cvae.py:2429-2461): begin() re-packs every registered (weight, layout) pair of `owner` in ONE launch and arms the lookups,
+ * the convolution entry points then skip their own pack launch, end() disarms (backward is over / the optimiser is about to
+ * change the weights).  Outside a bracket every convolution packs for itself, as without a cache.
+ * configure(): caller-owned persistent device buffer (256-byte aligned; NULL = off), shared out in equal regions to at most
+ * four owners.  owner: a value that changes whenever the set of weight ADDRESSES in use changes; weights[0..n): those addresses
+ * - entries are only ever created for them (any other tensor, e.g. a temporary whose address is re-used later, packs per call).
+ * pin(): the armed owner's region is never recycled for another owner (a HIP graph captured in the bracket has its slot
+ * addresses baked in).  stats(): host-side counters for tests. */
 int jvae_pack_cache_configure(void* buf, size_t bytes);
-int jvae_pack_cache_begin(void* stream, long long owner);
+int jvae_pack_cache_begin(void* stream, long long owner, const void* const* weights, int n);
 int jvae_pack_cache_end(void);
+int jvae_pack_cache_pin(void);
 int jvae_pack_cache_reset(void);
 int jvae_pack_cache_stats(int* entries, long long* hits, long long* misses, long long* refreshes);
 

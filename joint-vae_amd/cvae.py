@@ -16,6 +16,7 @@ feature stacks (torchvision); a per-dimension sigma (the reference fails on it t
 the `y=None` all-class evaluation with its OOD scores and the WIM fine-tuning step are built.
 There is no CPU path: calling forward/evaluate with CPU tensors raises.
 """
+import contextlib
 import json
 import logging
 import math
@@ -428,9 +429,10 @@ class ClassificationVariationalNetwork(nn.Module):
         if y is None and self.y_is_coded:
             raise ValueError('y is supposed to be an input of the net')
         lead = (1,) if x.dim() == self.input_dim else x.shape[:-self.input_dim]
-        if x_features is None:
-            x_features = self._features_of(x)
-        return self.forward_from_features(x_features, None if y is None else y.view(*lead), x, **kw)
+        with self._constant_weights(x):          # a span of its own when called outside evaluate() (see _constant_weights)
+            if x_features is None:
+                x_features = self._features_of(x)
+            return self.forward_from_features(x_features, None if y is None else y.view(*lead), x, **kw)
 
     def _dump_after_encoder_error(self, err, x, y):
         """cvae.py:476-488: a ValueError out of the encoder saves the model and the offending batch under
@@ -525,23 +527,44 @@ class ClassificationVariationalNetwork(nn.Module):
         The call opens a span in which the weights are constant (this forward and, in training, the backward that
         follows, until Optimizer.step()): the packed operand forms of all convolution weights are refreshed by ONE launch
         here instead of one launch in front of every convolution (jvae_hip/lib.py::pack_cache_begin)."""
-        self._pack_cache_begin(x)
-        try:
+        with self._constant_weights(x):
             return self._evaluate(x, y, batch, current_measures, with_beta, kl_var_weighting, gamma_weighting, z_output,
                                   epsilon, **kw)
+
+    @contextlib.contextmanager
+    def _constant_weights(self, x):
+        """The span in which the convolution weights are vouched for (packed operand forms served from the step's cache).
+        Opened by evaluate() and by a stand-alone forward(); closed when the call returns if no backward can follow (eval
+        mode / no_grad), else by the backward pass itself (ops._close_span_after_backward), by Optimizer.zero_grad() /
+        step(), and by everything that rewrites the weights wholesale (load_state_dict, load_weights, .to()/_apply).  A
+        nested call (forward() inside evaluate()) belongs to the outer span."""
+        if getattr(self, '_span_open', False) or not x.is_cuda:     # CPU tensors: the ops raise their own "no CPU fallback" error
+            yield
+            return
+        self._span_open = True
+        try:
+            ws = getattr(self, '_conv_weights', None)
+            if ws is None:
+                from module.vae_layers.conv import HipConv2d, HipConvTranspose2d
+                ws = self._conv_weights = [m.weight for m in self.modules() if isinstance(m, (HipConv2d, HipConvTranspose2d))]
+            _lib.pack_cache_begin(ws, x.device)
+            if torch.cuda.is_current_stream_capturing():
+                _lib.pack_cache_pin()            # the graph bakes this owner's slot addresses in: never recycle its region
+            yield
         finally:
+            self._span_open = False
             if not (self.training and torch.is_grad_enabled()):
                 _lib.pack_cache_end()            # no backward will follow: stop vouching for the weights now
 
-    def _pack_cache_begin(self, x):
-        if not x.is_cuda:
-            return                               # the ops raise their own "no CPU fallback" error
-        ws = getattr(self, '_conv_weights', None)
-        if ws is None:
-            from module.vae_layers.conv import HipConv2d, HipConvTranspose2d
-            ws = self._conv_weights = [m.weight for m in self.modules() if isinstance(m, (HipConv2d, HipConvTranspose2d))]
-        # owner = the weight addresses themselves: .to(), a re-flattened optimiser buffer or another model all change it
-        _lib.pack_cache_begin(hash(tuple(w.data_ptr() for w in ws)), x.device)
+    def _apply(self, fn, *a, **kw):
+        _lib.pack_cache_end()                    # .to() / .float() / .cuda(): the weights move or change
+        return super()._apply(fn, *a, **kw)
+
+    def load_state_dict(self, *a, **kw):
+        _lib.pack_cache_end()
+        if getattr(self, 'optimizer', None) is not None:
+            self.optimizer._scan_pending = True          # loaded values: the next check_nonfinite() scans every parameter
+        return super().load_state_dict(*a, **kw)
 
     def _evaluate(self, x, y=None, batch=0, current_measures=None, with_beta=False, kl_var_weighting=1.,
                   gamma_weighting=1, z_output=False, epsilon=None, **kw):
@@ -1053,20 +1076,46 @@ class ClassificationVariationalNetwork(nn.Module):
                     validation_sample_size=1024, full_test_every=10, ood_detection_every=10, train_accuracy=False,
                     save_dir=None, outputs=None, signal_handler=None, report_every=10):
         """Training loop with the reference's signature (cvae.py:2081-2104).  `trainset` is any map-style dataset of
-        (x in [0,1] float tensor, int label); the periodic accuracy / OOD phases of the reference are out of
-        scope and skipped.  `outputs.results` gets the running batch-mean losses the reference prints
-        (cvae.py:2463-2479), refreshed from the device every `report_every` batches (extra keyword, default 10) so that
-        the loop does not synchronise per batch."""
+        (image, int label): float tensors in [0,1] shaped like `input_shape`, or RAW uint8 images ((H,W,C) as torchvision's
+        CIFAR `.data`, or (C,H,W)), which are converted - and augmented - on the device.  The periodic accuracy / OOD
+        phases of the reference are out of scope and skipped.  `outputs.results` gets the running
+        batch-mean losses the reference prints (cvae.py:2463-2479), refreshed from the device every `report_every` batches
+        (extra keyword, default 10) so that the loop does not synchronise per batch.
+
+        data_augmentation: the reference hands the list to its dataset factory, which prepends RandomHorizontalFlip ('flip')
+        and RandomCrop(size, padding=size//8 [0 for imagenet sets], padding_mode='edge') ('crop') to the training
+        transforms (utils/torch_load.py:405-426, consumed through the loader of cvae.py:2245-2249).  Here the same two
+        transforms run on the device, one launch per batch (ops.augment_batch: flip, edge-pad crop, /255, bit-exact against
+        the torchvision chain), with per-image decisions from ops.draw_augmentation; they need the raw uint8 images.  A
+        float dataset with a non-empty `data_augmentation`, or a token other than 'flip' / 'crop', raises instead of
+        training silently un-augmented.  The batch size is clamped to `max_batch_sizes['train']` as in cvae.py:2180-2194."""
         if isinstance(trainset, str):
             raise NotImplementedError('named torchvision datasets are host-side plumbing outside this build: '
                                       'pass a torch.utils.data.Dataset')
         optimizer = optimizer or self.optimizer
-        if latent_sampling:
-            self._latent_samplings['train'] = latent_sampling
+        if not self.trained:                     # cvae.py:2121-2146: a partially trained net keeps its recorded parameters
+            if latent_sampling:
+                self._latent_samplings['train'] = latent_sampling
+                self.training_parameters['latent_sampling'] = latent_sampling
+            if data_augmentation:
+                self.training_parameters['data_augmentation'] = list(data_augmentation)
+        data_augmentation = list(self.training_parameters.get('data_augmentation') or [])
+        unknown = [t for t in data_augmentation if t not in ('flip', 'crop')]
+        if unknown:
+            raise ValueError('data_augmentation: only flip and crop exist (utils/torch_load.py:405-413), got {}'.format(unknown))
         device = device or self.device
+        max_batch_sizes = self.max_batch_sizes
+        test_batch_size = min(max_batch_sizes['test'], test_batch_size)
+        if batch_size:                           # cvae.py:2180-2194
+            train_batch_size = min(batch_size, max_batch_sizes['train'])
+        else:
+            train_batch_size = max_batch_sizes['train']
+        logging.info('Train batch size is {}'.format(train_batch_size))
+        batch_size = train_batch_size
         self.training_parameters.update({'batch_size': batch_size, 'warmup': list(warmup),
                                          'warmup_gamma': list(warmup_gamma), 'full_test_every': full_test_every})
         loader = torch.utils.data.DataLoader(trainset, batch_size=batch_size, shuffle=True, num_workers=0)
+        set_name = str(getattr(trainset, 'name', '') or '')
         done = self.trained
         sig = signal_handler
         for epoch in range(done, epochs):
@@ -1082,7 +1131,7 @@ class ClassificationVariationalNetwork(nn.Module):
             keys, acc = None, None          # running sums of the batch means of every loss: ONE device vector
             shown = {}
             for i, (x, y) in enumerate(loader):
-                x, y = x.to(device), y.to(device)
+                x, y = self._device_batch(x.to(device), data_augmentation, set_name), y.to(device)
                 losses, measures = self.train_step(x, y, batch=i, current_measures=measures,
                                                    kl_var_weighting=w_kl, gamma_weighting=w_gamma)
                 if keys is None:
@@ -1114,10 +1163,38 @@ class ClassificationVariationalNetwork(nn.Module):
                 self.save(save_dir)
         return self.train_history
 
+    def _device_batch(self, x, data_augmentation=(), set_name=''):
+        """Collated training batch -> the float32 (N, *input_shape) tensor the step takes.  Raw uint8 images go through the
+        input-pipeline kernel (flip / edge-pad crop decided per image on the device, then /255: the ToTensor of
+        utils/torch_load.py:415-426); float batches pass through and cannot be augmented."""
+        if x.dtype != torch.uint8:
+            if data_augmentation:
+                raise ValueError('data_augmentation={} needs the raw uint8 images (the reference augments PIL images before '
+                                 'ToTensor, utils/torch_load.py:405-426); this dataset yields {}'.format(list(data_augmentation), x.dtype))
+            return x
+        C, H, W = self.input_shape
+        if tuple(x.shape[1:]) == (H, W, C):
+            nhwc = True
+        elif tuple(x.shape[1:]) == (C, H, W):
+            nhwc = False
+        else:
+            raise ValueError('uint8 batch of shape {} matches neither (N,{},{},{}) nor (N,{},{},{})'.format(
+                tuple(x.shape), H, W, C, C, H, W))
+        pad = 0
+        if 'crop' in data_augmentation:          # utils/torch_load.py:409-411
+            pad = 0 if 'imagenet' in set_name else H // 8
+        flip, dy, dx = ops.draw_augmentation(x.shape[0], pad, x.device, generator=getattr(self, 'augmentation_generator', None),
+                                             flip='flip' in data_augmentation, crop=pad > 0)
+        return ops.augment_batch(x, flip, dy, dx, pad=pad, nhwc=nhwc)
+
     # ------------------------------------------------------------------------------------ persistence
-    def save(self, dir_name=None):
-        """params.json / train_params.json / history.json + state.pth + optimizer.pth (cvae.py:2650-2675)."""
-        dir_name = dir_name or getattr(self, 'saved_dir', None)
+    def save(self, dir_name=None, except_optimizer=False, except_state=False):
+        """params.json / train_params.json / test.json / ood.json / history.json, and - once the model is trained and
+        unless `except_state` - state.pth plus, unless `except_optimizer`, optimizer.pth (cvae.py:2650-2675; the
+        fine-tuning jobs save with except_optimizer=True and except_state=<bool>: ft/job.py:154-158)."""
+        if dir_name is None:
+            dir_name = getattr(self, 'saved_dir', None) or os.path.join('jobs', self.print_architecture(),
+                                                                        str(self.job_number))
         os.makedirs(dir_name, exist_ok=True)
         tp = dict(self.training_parameters)
         tp['sigma'] = self.sigma.params
@@ -1130,8 +1207,10 @@ class ClassificationVariationalNetwork(nn.Module):
         dump(self.testing, 'test.json')
         dump(self.ood_results, 'ood.json')
         dump(self.train_history, 'history.json')
-        torch.save(self.state_dict(), os.path.join(dir_name, 'state.pth'))
-        torch.save(self.optimizer.state_dict(), os.path.join(dir_name, 'optimizer.pth'))
+        if self.trained and not except_state:
+            torch.save(self.state_dict(), os.path.join(dir_name, 'state.pth'))
+            if not except_optimizer:
+                torch.save(self.optimizer.state_dict(), os.path.join(dir_name, 'optimizer.pth'))
         self.saved_dir = dir_name
         return dir_name
 
@@ -1194,6 +1273,8 @@ class ClassificationVariationalNetwork(nn.Module):
     def load_weights(self, dir_name, strict=True, with_optimizer=True):
         """Load state.pth (+ optimizer.pth) written by save() of this class or of the reference."""
         state = torch.load(os.path.join(dir_name, 'state.pth'), map_location=self.device)
+        _lib.pack_cache_end()                    # the weights change below
+        self.optimizer._scan_pending = True      # ... to values nobody has vouched for: scanned before the next backward
         with torch.no_grad():
             mine = self.state_dict()
             for k, v in state.items():

@@ -54,8 +54,9 @@ _SIGS = {
     'jvae_conv2d_fwd_aff_f32': (c_int, [P, P, P, P, P, POINTER(c_int), P, P, c_int] + [c_int] * 11 + [P, c_size_t, P]),
     'jvae_conv2d_wgrad_aff_f32': (c_int, [P, P, P, P, c_int, P, P, c_int] + [c_int] * 11 + [P, c_size_t, P]),
     'jvae_pack_cache_configure': (c_int, [P, c_size_t]),
-    'jvae_pack_cache_begin': (c_int, [P, c_longlong]),
+    'jvae_pack_cache_begin': (c_int, [P, c_longlong, P, c_int]),
     'jvae_pack_cache_end': (c_int, []),
+    'jvae_pack_cache_pin': (c_int, []),
     'jvae_pack_cache_reset': (c_int, []),
     'jvae_pack_cache_stats': (c_int, [POINTER(c_int), POINTER(c_longlong), POINTER(c_longlong), POINTER(c_longlong)]),
     'jvae_channel_sum_workspace_bytes': (c_size_t, [c_int]),
@@ -195,10 +196,11 @@ PACK_CACHE_BYTES = int(os.environ.get('JVAE_PACK_CACHE_MB', '64')) << 20       #
 _pack_cache = {}
 
 
-def pack_cache_begin(owner, device):
-    """Start of a span with constant weights (evaluate() ... backward): ONE launch on the current stream re-packs every
-    registered convolution weight, the convolutions of the span then skip their own pack launches.  `owner` changes
-    whenever the set of weight addresses changes (see jvae_pack_cache_begin)."""
+def pack_cache_begin(weights, device):
+    """Start of a span with constant weights (evaluate() ... end of backward): ONE launch on the current stream re-packs every
+    registered convolution weight, the convolutions of the span then skip their own pack launches.  `weights`: the tensors the
+    span vouches for - their addresses are both the owner key (another model, .to() or a re-flattened optimiser buffer change
+    it) and the only addresses the cache will create entries for (see jvae_pack_cache_begin)."""
     if not PACK_CACHE_BYTES:
         return
     lib = load()
@@ -214,13 +216,22 @@ def pack_cache_begin(owner, device):
             check(lib.jvae_pack_cache_configure(buf.data_ptr() + off, PACK_CACHE_BYTES), 'jvae_pack_cache_configure')
     if _pack_cache[idx] is None:
         return
-    check(lib.jvae_pack_cache_begin(stream_ptr(idx), owner), 'jvae_pack_cache_begin')
+    addrs = tuple(w.data_ptr() for w in weights)
+    arr = (ctypes.c_void_p * max(len(addrs), 1))(*addrs)
+    check(lib.jvae_pack_cache_begin(stream_ptr(idx), hash(addrs), arr, len(addrs)), 'jvae_pack_cache_begin')
 
 
 def pack_cache_end():
-    """The weights are about to change (optimiser) or are no longer vouched for: convolutions pack per call again."""
+    """Backward is over, the weights are about to change (optimiser, load_state_dict, .to()) or are no longer vouched for:
+    convolutions pack per call again."""
     if _lib is not None and _pack_cache:
         _lib.jvae_pack_cache_end()
+
+
+def pack_cache_pin():
+    """Inside a bracket: keep this owner's cache region for good (a HIP graph is being captured with its slot addresses)."""
+    if _lib is not None and _pack_cache and PACK_CACHE_BYTES:
+        _lib.jvae_pack_cache_pin()
 
 
 def pack_cache_stats():

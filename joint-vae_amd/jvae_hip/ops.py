@@ -48,6 +48,13 @@ def _join_after_backward():
     torch.autograd.Variable._execution_engine.queue_callback(L.join_side_stream)
 
 
+def _close_span_after_backward():
+    """The span of constant weights that a train-mode evaluate() / forward() opened (packed weights served from the step's
+    cache, lib.pack_cache_begin) ends with the backward pass that needed it: the engine's end-of-backward callback disarms
+    the cache, whether or not an optimiser step follows.  Queued by every convolution backward (a host-side flag flip each)."""
+    torch.autograd.Variable._execution_engine.queue_callback(L.pack_cache_end)
+
+
 # ------------------------------------------------------------------------------------------- gemm
 def gemm(M, N, K, A, sA, B, sB, C, sC, bias=None, bias_mode=0, flags=0, splitk=1, batch=1):
     """Raw strided product on the current stream.  sA = (sAm, sAk, sAb) etc. (elements)."""
@@ -332,6 +339,7 @@ class _Conv(torch.autograd.Function):
         x, w = ctx.saved_tensors
         gy = _c(gy)
         gx = gw = gb = None
+        _close_span_after_backward()
         want_b = ctx.has_bias and ctx.needs_input_grad[2] and not ctx.dead_bias
         w_slot = b_slot = None
         on_side = False

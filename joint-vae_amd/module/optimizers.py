@@ -99,6 +99,8 @@ class Optimizer:
         self._clip_pending = False
         self._sqnorm = None          # device scalar: squared global gradient norm of the last clip()
         self._flag = None            # device int: set by the Adam kernel when a parameter became NaN/Inf
+        self._scan_pending = True    # parameters not yet vouched for (fresh / loaded / moved): check_nonfinite() scans them once
+        self._flag_wanted = False    # somebody calls check_nonfinite(): only then is the flag copied to the host per step
         self._world = 1
         self._pg = None
         self._reduced = False
@@ -306,9 +308,12 @@ class Optimizer:
         self._restore_parked()
         self._sqnorm = None
         self._flag = None
+        self._scan_pending = True
 
     # ---- the step ------------------------------------------------------------------------------------
     def zero_grad(self, *a, **kw):
+        from jvae_hip import lib as _lib
+        _lib.pack_cache_end()                    # a new step: whatever span of constant weights was left open is over
         flat = self._flat_ids()
         for g in self._groups:
             g.g.zero_()
@@ -381,8 +386,9 @@ class Optimizer:
     # ---- NaN / Inf parameters: the reference scans every parameter before each backward (cvae.py:2454-2457) ---------
     def _post_flag(self, dev):
         """After the update: the kernel's non-finite flag travels to pinned host memory on the side stream (4 bytes, off
-        the critical path); check_nonfinite() reads it before the NEXT backward."""
-        if torch.cuda.is_current_stream_capturing():
+        the critical path); check_nonfinite() reads it before the NEXT backward.  Only when somebody reads it: a loop that
+        never calls check_nonfinite() pays neither the side-stream wait nor the copy."""
+        if not self._flag_wanted or torch.cuda.is_current_stream_capturing():
             return                               # a captured step reports through its measures (graph_train_step)
         from jvae_hip import lib as _lib
         if getattr(self, '_flag_host', None) is None:
@@ -395,10 +401,25 @@ class Optimizer:
             self._flag_event.record(side)
 
     def check_nonfinite(self):
-        """True if the previous update left a NaN / Inf parameter.  Called between the forward and the backward of the next
-        step - where the reference's scan sits (cvae.py:2454-2457: `print('GRAD NAN'); sys.exit(1)` before backward).  The
-        wait is for the PREVIOUS step's 4-byte copy, which finished while this step's forward was being enqueued: the host
-        never stalls on it unless it runs more than a step ahead of the GPU."""
+        """True if a parameter is NaN / Inf.  Call it between the forward and the backward of a step - where the reference's
+        scan sits (cvae.py:2454-2457: every parameter, `print('GRAD NAN'); sys.exit(1)` before backward); train_step() does,
+        a hand-written evaluate / backward / clip / step loop should too (this is the public check).
+
+        What is looked at: (i) ONCE after construction, load_state_dict() and .to() - parameters nobody has vouched for yet -
+        every parameter is scanned on the device (one host synchronisation), so NaN / Inf present at load time or written by
+        anything but the optimiser before the first step are caught on the very first step, as in the reference; (ii) from
+        then on the flag the update kernel raised while writing the PREVIOUS step's parameters: the only writer on the
+        training path.  Its 4-byte copy finished while this step's forward was being enqueued, so the host does not stall
+        on it unless it runs more than a step ahead of the GPU.  Narrower than the reference in one respect: a parameter
+        poisoned behind the optimiser's back (`.data` arithmetic) after the first step is seen only when it reaches the
+        update kernel (one step later, through its NaN gradient / moment)."""
+        self._flag_wanted = True
+        if self._scan_pending:
+            self._scan_pending = False
+            flat = self._flat_ids()
+            tensors = [g.p for g in self._groups] + [p.data for p in self._all if id(p) not in flat]
+            if any(t.is_cuda and t.is_floating_point() and not bool(torch.isfinite(t).all()) for t in tensors):
+                return True
         ev = getattr(self, '_flag_event', None)
         if ev is None:
             return False

@@ -257,6 +257,15 @@ def test_checkpoint_roundtrip(tmp_path):
     x, y, eps = det_inputs(8, kw['input_shape'], 10, 1, 64)
     x, y, eps = x.to(DEV), y.to(DEV), eps.to(DEV)
     net.train_step(x, y, epsilon=eps)
+    json_only = ['history.json', 'ood.json', 'params.json', 'test.json', 'train_params.json']
+    net.save(str(tmp_path / 'untrained'))                 # cvae.py:2667: tensors are written `if self.trained` only
+    assert sorted(os.listdir(tmp_path / 'untrained')) == json_only
+    net.trained = 1
+    net.save(str(tmp_path / 'nostate'), except_state=True)
+    assert sorted(os.listdir(tmp_path / 'nostate')) == json_only
+    net.save(str(tmp_path / 'noopt'), except_optimizer=True)
+    assert sorted(os.listdir(tmp_path / 'noopt')) == sorted(json_only + ['state.pth'])
+    tmp_path = tmp_path / 'full'
     net.save(str(tmp_path))
     assert sorted(os.listdir(tmp_path)) == ['history.json', 'ood.json', 'optimizer.pth', 'params.json', 'state.pth',
                                             'test.json', 'train_params.json']      # the reference's job-directory files
@@ -673,12 +682,106 @@ def test_train_model_epoch_with_a_ragged_last_batch(tmp_path):
     assert abs(float(net2.optimizer.grad_norm()) - gn) < 2e-4 * gn
 
 
+class _RawImages(torch.utils.data.Dataset):
+    """uint8 HWC images + labels, as torchvision's CIFAR10 `.data` / `.targets`; remembers the order it was read in."""
+
+    def __init__(self, n, side=32, classes=10, seed=0, name='cifar10'):
+        rng = np.random.default_rng(seed)
+        self.data = rng.integers(0, 256, size=(n, side, side, 3), dtype=np.uint8)
+        self.targets = rng.integers(0, classes, size=n)
+        self.name = name
+        self.order = []
+
+    def __len__(self):
+        return len(self.data)
+
+    def __getitem__(self, i):
+        self.order.append(int(i))
+        return torch.from_numpy(self.data[i]), int(self.targets[i])
+
+
+def test_train_model_augments_on_the_device_bit_exact(monkeypatch):
+    """VERDICT r3 item 3 / SURVEY.md §8f-2: train_model(data_augmentation=['flip', 'crop']) on a raw uint8 dataset feeds the
+    step the batches that the reference's transform chain (RandomHorizontalFlip, RandomCrop(32, padding=4, 'edge'), ToTensor:
+    utils/torch_load.py:405-426) would produce for the same per-image decisions - bit for bit, against
+    oracle/augment_oracle.py.  The decisions are those of ops.draw_augmentation (recorded here), the batches those handed to
+    train_step (recorded here); a ragged last batch included."""
+    from cvae import ClassificationVariationalNetwork as Net
+    from jvae_hip import ops
+    from oracle.augment_oracle import augment
+    torch.manual_seed(3)
+    net = Net(**dict(get_case('c2_n8')['net'])).to(DEV)
+    data = _RawImages(83, seed=11)
+    draws, batches = [], []
+    real_draw, real_step = ops.draw_augmentation, net.train_step
+
+    def draw(*a, **k):
+        out = real_draw(*a, **k)
+        draws.append(tuple(None if t is None else t.cpu().numpy().copy() for t in out))
+        return out
+
+    def step(x, y, **k):
+        batches.append((x.detach().cpu().numpy().copy(), y.cpu().numpy().copy()))
+        return real_step(x, y, **k)
+    monkeypatch.setattr(ops, 'draw_augmentation', draw)
+    monkeypatch.setattr(net, 'train_step', step)
+    hist = net.train_model(data, epochs=1, batch_size=32, data_augmentation=['flip', 'crop'], device=DEV)
+    assert hist['epochs'] == 1 and net.training_parameters['data_augmentation'] == ['flip', 'crop']
+    assert [b[0].shape[0] for b in batches] == [32, 32, 19] and len(draws) == 3 and sorted(data.order) == list(range(83))
+    at, flipped, shifted = 0, 0, 0
+    for (xb, yb), (flip, dy, dx) in zip(batches, draws):
+        idx = data.order[at:at + xb.shape[0]]
+        at += xb.shape[0]
+        ref = augment(data.data[idx], flip, dy, dx, 4)
+        assert xb.dtype == np.float32 and np.array_equal(xb, ref)
+        assert np.array_equal(yb, data.targets[idx])
+        flipped += int(flip.sum())
+        shifted += int(((dy != 4) | (dx != 4)).sum())
+    assert 0 < flipped < 83 and shifted > 40               # both transforms really drew
+    # no augmentation: the uint8 images are only converted (ToTensor)
+    batches.clear(); draws.clear(); data.order.clear()
+    net2 = Net(**dict(get_case('c2_n8')['net'])).to(DEV)
+    monkeypatch.setattr(net2, 'train_step', lambda x, y, **k: (batches.append(x.detach().cpu().numpy().copy()), real_step(x, y, **k))[1])
+    net2.train_model(data, epochs=1, batch_size=64, device=DEV)
+    assert np.array_equal(batches[0], data.data[data.order[:64]].transpose(0, 3, 1, 2).astype(np.float32) / np.float32(255))
+    # 'crop' on an imagenet set pads by 0 (utils/torch_load.py:410): flips only
+    batches.clear(); draws.clear(); data.order.clear()
+    data.name = 'imagenet20'
+    net3 = Net(**dict(get_case('c2_n8')['net'])).to(DEV)
+    monkeypatch.setattr(net3, 'train_step', lambda x, y, **k: (batches.append(x.detach().cpu().numpy().copy()), real_step(x, y, **k))[1])
+    net3.train_model(data, epochs=1, batch_size=83, data_augmentation=['flip', 'crop'], device=DEV)
+    flip, dy, dx = draws[0]
+    assert dy is None and dx is None and np.array_equal(batches[0], augment(data.data[data.order], flip, None, None, 0))
+
+
+def test_train_model_refuses_what_it_cannot_honour_and_clamps_the_batch(monkeypatch):
+    """A float dataset cannot be augmented the reference's way (it augments the PIL image before ToTensor), an unknown token
+    has no transform behind it (utils/torch_load.py:405-413 knows flip and crop): both raise instead of training silently
+    un-augmented.  The training batch size is min(batch_size, max_batch_sizes['train']) (cvae.py:2180-2194)."""
+    from cvae import ClassificationVariationalNetwork as Net
+    net = Net(**dict(get_case('c2_n8')['net'])).to(DEV)
+    floats = torch.utils.data.TensorDataset(torch.rand(24, 3, 32, 32), torch.randint(0, 10, (24,)))
+    with pytest.raises(ValueError, match='uint8'):
+        net.train_model(floats, epochs=1, batch_size=8, data_augmentation=['flip'], device=DEV)
+    net = Net(**dict(get_case('c2_n8')['net'])).to(DEV)
+    with pytest.raises(ValueError, match='rotate'):
+        net.train_model(_RawImages(8), epochs=1, batch_size=8, data_augmentation=['rotate'], device=DEV)
+    net = Net(**dict(get_case('c2_n8')['net'])).to(DEV)
+    monkeypatch.setattr(Net, 'max_batch_sizes', property(lambda self: {'train': 8, 'test': 4}))
+    sizes = []
+    real_step = net.train_step
+    monkeypatch.setattr(net, 'train_step', lambda x, y, **k: (sizes.append(x.shape[0]), real_step(x, y, **k))[1])
+    net.train_model(floats, epochs=1, batch_size=512, device=DEV)
+    assert sizes == [8, 8, 8] and net.training_parameters['batch_size'] == 8
+
+
 def test_encoder_value_error_dumps_model_and_batch(tmp_path, monkeypatch):
     """cvae.py:476-488: a ValueError raised by the encoder leaves log/dump-<job> with the model files and x.pt / y.pt,
     and propagates."""
     case = get_case('c2_n8')
     net = build(case)
     net.job_number = 4242
+    net.trained = 1                                        # an untrained net dumps its json files only (cvae.py:2667)
     x, y, eps = (t.to(DEV) for t in det_inputs(8, (3, 32, 32), 10, 1, 64))
     monkeypatch.chdir(tmp_path)
 
@@ -806,6 +909,67 @@ def test_pack_cache_is_transparent():
     assert (s1['hits'], s1['misses']) == (s0['hits'], s0['misses'])
 
 
+def test_pack_cache_span_closes_without_an_optimizer_step():
+    """a train-mode evaluate() leaves the span of constant weights open for the backward that needs it - and only
+    for that.  (i) the backward pass itself closes it (no optimiser step needed); (ii) a loss-only call (no backward) followed
+    by a weight change through .data: a stand-alone forward() opens a span of its own and sees the NEW weights; (iii) a
+    convolution of a tensor the model did not declare - here a temporary weight, inside an open span - is never registered;
+    (iv) load_state_dict() closes the span."""
+    from jvae_hip import lib as L
+    from jvae_hip import ops
+    case = full_config(2, 8)
+    net = build(case)
+    x, y, eps = (t.to(DEV) for t in det_inputs(8, (3, 32, 32), 10, 1, 64, seed=5))
+    net.train_step(x, y, epsilon=eps)                     # parameters settle in the flat buffer
+    net.train_step(x, y, epsilon=eps)
+
+    def served(f):
+        s0 = L.pack_cache_stats()
+        out = f()
+        s1 = L.pack_cache_stats()
+        return out, s1['hits'] - s0['hits'], s1['misses'] - s0['misses'], s1['entries'] - s0['entries']
+
+    z = torch.randn(4, *net.imager.input_shape, device=DEV)
+    # (i) evaluate + backward, no step: afterwards a stray convolution is not served from the cache
+    net.optimizer.zero_grad()
+    losses = net.evaluate(x, y, epsilon=eps, with_beta=True)[2]
+    _, hits, misses, _ = served(lambda: net.imager(z))
+    assert hits > 0 and misses == 0                      # still inside the span: backward has not run
+    losses['total'].mean().backward()
+    torch.cuda.synchronize()
+    _, hits, misses, _ = served(lambda: net.imager(z))
+    assert (hits, misses) == (0, 0)
+    # (ii) loss-only call, then a .data change, then a stand-alone forward()
+    net.evaluate(x, y, epsilon=eps, with_beta=True)
+    with torch.no_grad():
+        a = net(x, y, epsilon=eps)[0].clone()
+    net.evaluate(x, y, epsilon=eps, with_beta=True)       # span left open again (training mode, no backward)
+    net.imager[3].weight.data.mul_(0.5)
+    with torch.no_grad():
+        b = net(x, y, epsilon=eps)[0].clone()
+    L.pack_cache_end()
+    old = L.PACK_CACHE_BYTES
+    L.PACK_CACHE_BYTES = 0
+    try:
+        with torch.no_grad():
+            c = net(x, y, epsilon=eps)[0].clone()         # the uncached answer for the changed weights
+    finally:
+        L.PACK_CACHE_BYTES = old
+    assert not torch.equal(a, b) and torch.equal(b, c)
+    # (iii) an undeclared weight inside an open span
+    net.evaluate(x, y, epsilon=eps, with_beta=True)
+    spec = ops.ConvSpec(32, 32, 5, 1, 2, 0, False)
+    xt = torch.randn(8, 32, 16, 16, device=DEV)
+    wt = torch.randn(32, 32, 5, 5, device=DEV)
+    _, hits, misses, entries = served(lambda: ops.conv_fwd_raw(xt, wt, None, spec))
+    assert (hits, misses, entries) == (0, 0, 0)
+    # (iv) load_state_dict closes the span
+    net.load_state_dict(net.state_dict())
+    _, hits, misses, _ = served(lambda: net.imager(z))
+    assert (hits, misses) == (0, 0)
+    torch.cuda.synchronize()
+
+
 def test_nonfinite_parameters_end_the_run_before_the_next_backward(capsys):
     """cvae.py:2454-2457: the reference scans every parameter for NaN / Inf between evaluate() and backward() and ends the run
     with `print('GRAD NAN'); sys.exit(1)`.  Here the Adam kernel raises a device flag when an updated parameter is not finite;
@@ -823,6 +987,30 @@ def test_nonfinite_parameters_end_the_run_before_the_next_backward(capsys):
     assert ei.value.code == 1 and 'GRAD NAN' in capsys.readouterr().out
     torch.cuda.synchronize()
     assert float(net.optimizer._groups[0].g.abs().sum()) == 0.       # zero_grad ran, backward did not
+    # NaN / Inf present BEFORE the first step (a poisoned checkpoint, an initialisation gone wrong): the reference's scan
+    # sees it on the very first step (cvae.py:2454-2457 looks at every parameter); so does the one-off device scan of
+    # check_nonfinite() that follows construction, load_state_dict() and .to()
+    fresh = build(case)
+    with torch.no_grad():
+        fresh.imager[3].weight[0, 0, 0, 0] = float('inf')
+    with pytest.raises(SystemExit):
+        fresh.train_step(x, y, epsilon=eps)
+    assert 'GRAD NAN' in capsys.readouterr().out
+    healthy = build(case)
+    healthy.train_step(x, y, epsilon=eps)
+    sd = {k: v.clone() for k, v in healthy.state_dict().items()}
+    sd['encoder.dense_mean.weight'][0, 0] = float('nan')
+    healthy.load_state_dict(sd)
+    with pytest.raises(SystemExit):
+        healthy.train_step(x, y, epsilon=eps)
+    # a hand-written loop that never asks pays no flag copy
+    quiet = build(case)
+    quiet.optimizer.zero_grad()
+    quiet.evaluate(x, y, epsilon=eps, with_beta=True)[2]['total'].mean().backward()
+    quiet.optimizer.clip(quiet.parameters())
+    quiet.optimizer.step()
+    assert getattr(quiet.optimizer, '_flag_event', None) is None and not quiet.optimizer._flag_wanted
+    assert quiet.optimizer.check_nonfinite() is False and quiet.optimizer._flag_wanted
 
 
 def test_accuracy_loop_records_and_recovers(tmp_path):

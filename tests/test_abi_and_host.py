@@ -146,6 +146,43 @@ def test_batch_size_bounds_and_evaluation_slabs_follow_from_the_tensors():
     assert mlp._widest_decoder_activation() >= 784 and mlp.max_batch_sizes['train'] == 1 << 16
 
 
+def test_save_signature_serves_the_fine_tuning_subclasses(tmp_path):
+    """cvae.py:2650-2675 `save(dir_name=None, except_optimizer=False, except_state=False)`; the fine-tuning job classes
+    override it the way ft/job.py:154-158 does - `super().save(*a, except_state=except_state, except_optimizer=True)` plus a
+    json file of their own - so the drop-in must accept both keywords with the reference's meaning: tensors only once
+    `trained`, state.pth unless except_state, optimizer.pth unless except_optimizer.  Host logic only (CPU tensors)."""
+    import json
+    from cvae import ClassificationVariationalNetwork as Net
+
+    class Job(Net):
+        ft_param_file = 'ft.json'
+        ft_params = {'alpha': 0.5}
+
+        def save(self, *a, except_state=True, **kw):
+            kw['except_optimizer'] = True
+            dir_name = super().save(*a, except_state=except_state, **kw)
+            with open(os.path.join(dir_name, self.ft_param_file), 'w') as f:
+                json.dump(self.ft_params, f)
+            return dir_name
+    job = Job(**get_case('c2_n8')['net'])
+    jsons = {'params.json', 'train_params.json', 'test.json', 'ood.json', 'history.json', 'ft.json'}
+    job.trained = 3
+    a = job.save(str(tmp_path / 'a'))
+    assert a == str(tmp_path / 'a') and set(os.listdir(a)) == jsons
+    b = job.save(str(tmp_path / 'b'), except_state=False)
+    assert set(os.listdir(b)) == jsons | {'state.pth'}
+    assert list(torch.load(os.path.join(b, 'state.pth')).keys()) == list(job.state_dict().keys())
+    plain = Net(**get_case('c2_n8')['net'])
+    c = plain.save(str(tmp_path / 'c'))                     # untrained: json files only (cvae.py:2667 `if self.trained`)
+    assert set(os.listdir(c)) == jsons - {'ft.json'}
+    plain.trained = 1
+    d = plain.save(str(tmp_path / 'd'))
+    assert set(os.listdir(d)) == (jsons - {'ft.json'}) | {'state.pth', 'optimizer.pth'}
+    assert plain.save() == d                                 # dir_name=None: the directory of the last save / load
+    again = Net.load(d)
+    assert again.trained == plain.train_history['epochs'] == 0   # `trained` follows history.json, as in the reference
+
+
 def test_layer_dsl_shapes():
     from module.vae_layers.conv import build_de_conv_layers, find_input_shape, parse_conv_layer_name
     f = build_de_conv_layers((3, 32, 32), 'conv32', batch_norm=True)
