@@ -74,34 +74,11 @@ __device__ __forceinline__ float half_wave_sum_hi(float v) {
     return v;
 }
 
-// Transposing reduction over the 32 lanes of each half-wave: every lane brings 32 values v[0..31]; afterwards lane l
-// holds the sum, over the 32 lanes of its half-wave, of v[l & 31].  A value-halving butterfly - at every step a lane
-// keeps half of its values and hands the other half to its partner - needs 16 + 8 + 4 + 2 + 1 additions (65 vector
-// instructions) where 32 independent all-lane reductions need 160, and leaves ONE value per lane (one LDS store instead
-// of 32 single-lane ones).  Step 1 crosses the rows of 16 lanes with gfx950's v_permlane16_swap, steps 2 / 3 use DPP adds
-// whose bank mask restricts the write to the lanes that keep the value, steps 4 / 5 (inside a quad, where no write mask
-// exists) select with v_cndmask.  All lanes must be active.  Fixed order: results are run-to-run identical.
-__device__ __forceinline__ float half_wave_reduce32(const float (&v)[32]) {
+// Transposing reduction over the 16 lanes of each DPP row (lanes 16r .. 16r+15): every lane brings 16 values a[0..15];
+// afterwards lane l holds the sum, over the 16 lanes of its row, of a[l & 15].  Steps 2-5 of half_wave_reduce32 (see there).
+__device__ __forceinline__ float row_reduce16(const float (&a)[16]) {
     const int lane = threadIdx.x & 63;
-    float a[16], b[8], c[4], d[2];
-    // s_nop 1: a vector write needs two wait states before a DPP / permlane-swap read of the same register (inline asm is
-    // not covered by the compiler's hazard recogniser).  The swap is written as asm because this compiler's
-    // __builtin_amdgcn_permlane16_swap returns its first result twice.
-#pragma unroll
-    for (int i = 0; i < 16; i += 4) {   // lane bit 4: even rows keep v[i], odd rows v[i + 16]
-        float x[4], y[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { x[j] = v[i + j]; y[j] = v[i + j + 16]; }
-        // odd rows of x <-> even rows of y: afterwards x + y = (x.row0 + x.row1 | y.row0 + y.row1 | x.row2 + x.row3 | ...)
-        asm("s_nop 1\n\t"
-            "v_permlane16_swap_b32 %0, %4\n\t"
-            "v_permlane16_swap_b32 %1, %5\n\t"
-            "v_permlane16_swap_b32 %2, %6\n\t"
-            "v_permlane16_swap_b32 %3, %7"
-            : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]));
-#pragma unroll
-        for (int j = 0; j < 4; ++j) a[i + j] = x[j] + y[j];
-    }
+    float b[8], c[4], d[2];
 #pragma unroll
     for (int i = 0; i < 8; i += 4) {    // lane bit 3 (partner lane ^ 8 = row_ror:8): banks 0,1 keep a[i], banks 2,3 a[i + 8]
 #pragma unroll
@@ -140,6 +117,36 @@ __device__ __forceinline__ float half_wave_reduce32(const float (&v)[32]) {
     }
     const float keep = b0 ? d[1] : d[0], send = b0 ? d[0] : d[1];
     return keep + jvae_dpp<0xB1, 0xf>(send);      // lane bit 0 (partner lane ^ 1)
+}
+
+// Transposing reduction over the 32 lanes of each half-wave: every lane brings 32 values v[0..31]; afterwards lane l
+// holds the sum, over the 32 lanes of its half-wave, of v[l & 31].  A value-halving butterfly - at every step a lane
+// keeps half of its values and hands the other half to its partner - needs 16 + 8 + 4 + 2 + 1 additions (65 vector
+// instructions) where 32 independent all-lane reductions need 160, and leaves ONE value per lane (one LDS store instead
+// of 32 single-lane ones).  Step 1 crosses the rows of 16 lanes with gfx950's v_permlane16_swap, steps 2 / 3 use DPP adds
+// whose bank mask restricts the write to the lanes that keep the value, steps 4 / 5 (inside a quad, where no write mask
+// exists) select with v_cndmask.  All lanes must be active.  Fixed order: results are run-to-run identical.
+__device__ __forceinline__ float half_wave_reduce32(const float (&v)[32]) {
+    float a[16];
+    // s_nop 1: a vector write needs two wait states before a DPP / permlane-swap read of the same register (inline asm is
+    // not covered by the compiler's hazard recogniser).  The swap is written as asm because this compiler's
+    // __builtin_amdgcn_permlane16_swap returns its first result twice.
+#pragma unroll
+    for (int i = 0; i < 16; i += 4) {   // lane bit 4: even rows keep v[i], odd rows v[i + 16]
+        float x[4], y[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { x[j] = v[i + j]; y[j] = v[i + j + 16]; }
+        // odd rows of x <-> even rows of y: afterwards x + y = (x.row0 + x.row1 | y.row0 + y.row1 | x.row2 + x.row3 | ...)
+        asm("s_nop 1\n\t"
+            "v_permlane16_swap_b32 %0, %4\n\t"
+            "v_permlane16_swap_b32 %1, %5\n\t"
+            "v_permlane16_swap_b32 %2, %6\n\t"
+            "v_permlane16_swap_b32 %3, %7"
+            : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a[i + j] = x[j] + y[j];
+    }
+    return row_reduce16(a);
 }
 
 __device__ __forceinline__ float wave_max(float v) {

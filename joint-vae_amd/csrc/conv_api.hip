@@ -33,6 +33,7 @@ bool make_geom(int N, int Cin, int H, int W, int Cout, int KH, int KW, int S, in
 extern "C" {
 
 int jvae_conv2d_set_split_bf16(int mode) { return jvae_conv5_x3_set(mode); }
+int jvae_conv2d_set_split_shape16(int on) { return jvae_conv5_x3_set_shape16(on); }
 
 size_t jvae_conv2d_workspace_bytes(int N, int Cin, int H, int W, int Cout, int KH, int KW, int S, int P, int OP,
                                    int transposed) {

@@ -30,6 +30,7 @@ int jvae_conv5_pack(const float* w, float* wp, int C, int O, int swap, int flip,
 bool jvae_conv5_x3_ok(int Cin, int H, int W, int Cout, int OH, int OW, int S, int P);
 size_t jvae_conv5_x3_pack_bytes(int Cin, int Cout);
 int jvae_conv5_x3_set(int mode);
+int jvae_conv5_x3_set_shape16(int on);
 bool jvae_conv5_x3_enabled();
 int jvae_conv5_x3_wpack(const float* w, float* ws, int C, int O, int swap, int flip, hipStream_t st);
 // conv_t2_x3.hip: the 4-phase stride-2 transposed convolution in the same arithmetic (w = raw weight, [c][o][tap])

@@ -44,6 +44,12 @@ __global__ __launch_bounds__(256) void x3_wpack_kernel(const float* __restrict__
         jvae_pack_x3_elem(w, wp, i, C, O, swap, flip);
 }
 
+__global__ __launch_bounds__(256) void x3s_wpack_kernel(const float* __restrict__ w, __bf16* __restrict__ wp,
+                                                        int C, int O, long total, int swap, int flip) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
+        jvae_pack_x3s_elem(w, wp, i, C, O, swap, flip);
+}
+
 struct X3P {
     const float* in;     // (N, Cin, H, W) fp32
     const u32x4* wp;     // packed split weights (KB*5, 30, OP) units
@@ -54,7 +60,13 @@ struct X3P {
     InAff aff;           // deferred BatchNorm(+ReLU) of the input (sc == nullptr: none)
 };
 
-template <int S, int OW, int MT>
+// SH = false: v_mfma_f32_32x32x16_bf16, K index = 16 channels of one tap, weights staged per kernel row (5 taps).
+// SH = true:  v_mfma_f32_16x16x32_bf16, K index = 2 CONSECUTIVE taps (of the 25-tap sequence) x 16 channels - lane group
+//             kq = lane >> 4 supplies tap 2*pair + (kq >> 1), channel block kq & 1 - weights staged per GROUP of 2 tap pairs
+//             (7 groups per K step: 12 pairs + tap 24 with an all-zero partner; pack_elems.h JVAE_PACK_X3S).  Same output tile
+//             per wave, same patch image, same LDS reads per MFMA cycle; 4 % more MFMA cycles (the empty half pair).  The chip
+//             holds a higher clock on this shape (MI355X_MICROARCH.md, DVFS give-back item 7).
+template <int S, int OW, int MT, bool SH = false>
 struct X3Geom {
     static constexpr int OH = OW;
     static constexpr int PIX = MT * 128;
@@ -68,13 +80,19 @@ struct X3Geom {
     static constexpr int WP = WP0 > WP1 ? WP0 : WP1;          // units per patch row
     static constexpr int CH = ROWS * WP;                       // units per 8-channel block per image
     static constexpr int XS = NIMG * 2 * CH;                   // patch units of one plane (16 channels)
-    static constexpr int WGS = 3 * 5 * 2 * 32;                 // weight units of one kernel row (3 planes x 5 taps x 2 halves)
+    static constexpr int WGS = SH ? 2 * 3 * 4 * 32             // weight units of one group: 2 pairs x 3 planes x 4 lane groups
+                                  : 3 * 5 * 2 * 32;            // ... of one kernel row (3 planes x 5 taps x 2 halves)
+    static constexpr int GPK = SH ? 7 : 5;                     // weight groups per K step
+    static constexpr int WROWS = SH ? JVAE_X3S_PAIRS * 12 : 150;   // 32-unit rows of packed weights per K step and 32 channels
     static constexpr int LDS_BYTES = (3 * XS + 2 * WGS) * 16;
 };
 
-template <int S, int OW, int MT, bool AFF>
+template <bool SH, int MT> struct X3Acc { f32x16 t[MT]; };
+template <int MT> struct X3Acc<true, MT> { f32x4 t[2 * MT][2]; };       // [16-pixel tile][16-channel tile]
+
+template <int S, int OW, int MT, bool AFF, bool SH = false>
 __global__ __launch_bounds__(256, 2) void conv5_x3_kernel(X3P p) {
-    using G = X3Geom<S, OW, MT>;
+    using G = X3Geom<S, OW, MT, SH>;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     u32x4* Xs = reinterpret_cast<u32x4*>(lds_raw);            // [3 planes][XS]
     u32x4* Ws = Xs + 3 * G::XS;                                // [2 buffers][WGS]
@@ -95,7 +113,7 @@ __global__ __launch_bounds__(256, 2) void conv5_x3_kernel(X3P p) {
     const int row0 = (G::OHW >= G::PIX) ? (bx % TILES_PER_IMG) * G::TH : 0;
     const int o0 = blockIdx.y * 32;
     const int KB = (p.Cin + 15) / 16;
-    const int NG = KB * 5;                                     // weight groups: (K step, kernel row)
+    const int NG = KB * G::GPK;                                // weight groups: (K step, kernel row | group of 2 tap pairs)
 
     if (tid < 32) bias_s[tid] = (p.bias && o0 + tid < p.CoutReal) ? p.bias[o0 + tid] : 0.f;
     if (AFF)
@@ -107,22 +125,37 @@ __global__ __launch_bounds__(256, 2) void conv5_x3_kernel(X3P p) {
     // halo columns / out-of-image rows / missing images / missing channels are zeroed once and never written again
     for (int i = tid; i < 3 * G::XS; i += 256) Xs[i] = u32x4{0u, 0u, 0u, 0u};
 
-    int pixoff[MT];
+    // pixel tiles of this wave: MT groups of 32 pixels (32x32x16: the pixel on lane & 31, channel block `half`), or 2*MT tiles of 16
+    // (16x16x32: the pixel on lane & 15, lane group kq = lane >> 4 = (tap of the pair, channel block))
+    constexpr int NPT = SH ? 2 * MT : MT, TPX = SH ? 16 : 32;
+    const int l15 = lane & 15, kq = lane >> 4;
+    int pixoff[NPT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const int pix = (wave * MT + mt) * 32 + l31;
+    for (int mt = 0; mt < NPT; ++mt) {
+        const int pix = (wave * NPT + mt) * TPX + (SH ? l15 : l31);
         const int im = pix / (G::TH * OW), rem = pix % (G::TH * OW);
         const int r = rem / OW, c = rem % OW;
-        pixoff[mt] = im * (2 * G::CH) + half * G::CH + (r * S) * G::WP + c * S + 4 - p.P;
+        pixoff[mt] = im * (2 * G::CH) + (SH ? (kq & 1) : half) * G::CH + (r * S) * G::WP + c * S + 4 - p.P;
     }
 
     // two accumulator sets: the three small partial products are summed apart from the three large ones (added in
     // the epilogue), which also doubles the distance between dependent MFMAs
-    f32x16 acc[MT], acs[MT];
+    X3Acc<SH, MT> accA, accS;
+    auto& acc = accA.t;
+    auto& acs = accS.t;
+    if constexpr (SH) {
 #pragma unroll
-    for (int b = 0; b < MT; ++b)
+        for (int b = 0; b < NPT; ++b)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { acc[b][r] = 0.f; acs[b][r] = 0.f; }
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { acc[b][ct][r] = 0.f; acs[b][ct][r] = 0.f; }
+    } else {
+#pragma unroll
+        for (int b = 0; b < MT; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[b][r] = 0.f; acs[b][r] = 0.f; }
+    }
 
     const int in_row0 = row0 * S - p.P;
     constexpr int W2 = G::WIN / 2;
@@ -167,7 +200,7 @@ __global__ __launch_bounds__(256, 2) void conv5_x3_kernel(X3P p) {
     };
     auto gloadW = [&](int g) {
 #pragma unroll
-        for (int k = 0; k < WU; ++k) rw[k] = wsrc[k][(long)g * 30 * p.OP];
+        for (int k = 0; k < WU; ++k) rw[k] = wsrc[k][(long)g * (G::WGS / 32) * p.OP];
     };
     auto lstoreX = [&](int kb) {                    // kb: the K step whose data sits in rx
 #pragma unroll
@@ -217,6 +250,7 @@ __global__ __launch_bounds__(256, 2) void conv5_x3_kernel(X3P p) {
 
     // one kernel row (5 taps) of one K step: 6 MFMAs per tap and pixel group, fragments of tap kw+1 read ahead
     auto compute = [&](int buf, int rowoff) {
+      if constexpr (!SH) {
         const u32x4* Wb = Ws + buf * G::WGS + half * 32 + l31;
         u32x4 fa[2][3], fb[2][3][MT];
         auto frag = [&](int kw, u32x4 (&a)[3], u32x4 (&b)[3][MT]) {
@@ -244,6 +278,68 @@ __global__ __launch_bounds__(256, 2) void conv5_x3_kernel(X3P p) {
                 }
             __builtin_amdgcn_sched_barrier(0);
         }
+      }
+    };
+
+    // 16x16x32 form.  One group = 2 tap pairs (the last group of a K step: 1); per pair the wave issues 6 products x NPT pixel
+    // tiles x 2 channel tiles; the pair is worked through in halves of 2 pixel tiles (24 MFMAs), the fragments of the next half
+    // are read ahead.  Lane group kq reads tap 2*pair + (kq >> 1): the second tap of a pair lies one unit to the right, or - when
+    // the pair crosses a kernel row (taps 4|5, 14|15) - one row down and four units to the left; tap 25 does not exist (its
+    // weights are zero): those lanes re-read tap 24 so that no value from outside the receptive field enters a 0 * x.
+    auto computeSH = [&](int buf, int gi) {
+        constexpr int NH = SH ? MT : 1;                          // halves of 2 pixel tiles per pair
+        const u32x4* Wb = Ws + buf * G::WGS + kq * 32 + l15;
+        const int npair = gi == 6 ? 1 : 2;
+        u32x4 fa[2][3][2], fb[2][3][2];
+        auto offs = [&](int pq) {                                // LDS unit offset of this lane's tap of pair pq, without the pixel
+            const int ta = 4 * gi + 2 * pq, kh = ta / 5, kw = ta - 5 * kh;
+            const int second = ta == 24 ? 0 : (kw == 4 ? G::WP - 4 : 1);
+            return kh * G::WP + kw + (kq >> 1) * second;
+        };
+        auto fragA = [&](int pq, u32x4 (&a)[3][2]) {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) a[pl][ct] = Wb[((pq * 3 + pl) * 4) * 32 + ct * 16];
+        };
+        auto fragB = [&](int off, int hp, u32x4 (&b)[3][2]) {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) b[pl][j] = Xs[pl * G::XS + pixoff[(hp * 2 + j) % NPT] + off];
+        };
+        int off = offs(0);
+        fragA(0, fa[0]);
+        fragB(off, 0, fb[0]);
+#pragma unroll
+        for (int pq = 0; pq < 2; ++pq) {
+            if (pq < npair) {
+                const int offn = pq + 1 < npair ? offs(pq + 1) : off;
+#pragma unroll
+                for (int hp = 0; hp < NH; ++hp) {
+                    constexpr int DUMMY = 0;
+                    const int cur = (pq * NH + hp) & 1;
+                    if (hp + 1 < NH) fragB(off, hp + 1, fb[cur ^ 1]);
+                    else if (pq + 1 < npair) { fragA(pq + 1, fa[(pq + 1) & 1]); fragB(offn, 0, fb[cur ^ 1]); }
+                    __builtin_amdgcn_sched_barrier(DUMMY);
+                    constexpr int WPL[6] = {0, 0, 2, 1, 1, 0}, XPL[6] = {2, 1, 0, 0, 1, 0};
+#pragma unroll
+                    for (int t = 0; t < 6; ++t)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+#pragma unroll
+                            for (int ct = 0; ct < 2; ++ct) {
+                                if constexpr (SH) {
+                                    f32x4& d = (t & 1) ? acc[hp * 2 + j][ct] : acs[hp * 2 + j][ct];
+                                    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[pq & 1][WPL[t]][ct]),
+                                                                                __builtin_bit_cast(bf16x8, fb[cur][XPL[t]][j]), d, 0, 0, 0);
+                                }
+                            }
+                    __builtin_amdgcn_sched_barrier(DUMMY);
+                }
+                off = offn;
+            }
+        }
     };
 
     // LDS-only barrier: __syncthreads() also waits for vmcnt(0), i.e. for the global prefetches in flight
@@ -260,23 +356,79 @@ __global__ __launch_bounds__(256, 2) void conv5_x3_kernel(X3P p) {
     int kb = 0, kh = 0;
     for (int g = 0; g < NG; ++g) {
         // invariant: patch of K step kb in Xs, weight group g in buffer g&1, rw = weight group g+1 (in flight)
-        const bool more = g + 1 < NG, last_row = kh == 4;
+        const bool more = g + 1 < NG, last_row = kh == G::GPK - 1;
         // buffer (g+1)&1 was last read in group g-1: every wave is past it.  The store (which waits for the loads of
         // rw) must stay ahead of the next loads: the scheduler would otherwise issue them first and wait for all.
         if (more) lstoreW((g + 1) & 1);
         __builtin_amdgcn_sched_barrier(0);
         if (g + 2 < NG) gloadW(g + 2);
-        if (kh == 3 && kb + 1 < KB) gloadX(kb + 1);
+        if (kh == G::GPK - 2 && kb + 1 < KB) gloadX(kb + 1);
         __builtin_amdgcn_sched_barrier(0);
-        compute(g & 1, kh * G::WP);
+        if constexpr (SH) computeSH(g & 1, kh);
+        else compute(g & 1, kh * G::WP);
         lds_barrier();
         if (more && last_row) {                    // K step change: the patch is fully consumed
             lstoreX(kb + 1);
             lds_barrier();
         }
-        if (++kh == 5) { kh = 0; ++kb; }
+        if (++kh == G::GPK) { kh = 0; ++kb; }
     }
 
+    if constexpr (SH) {
+        // ---- epilogue, 16x16x32: lane holds pixel l15 of each 16-pixel tile, channels ct*16 + kq*4 + r
+#pragma unroll
+        for (int b = 0; b < NPT; ++b)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) acc[b][ct] += acs[b][ct];
+        float bv[2][4];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bv[ct][r] = p.bias ? bias_s[ct * 16 + kq * 4 + r] : 0.f;
+#pragma unroll
+        for (int pt = 0; pt < NPT; ++pt) {
+            const int pix = (wave * NPT + pt) * 16 + l15;
+            const int im = pix / (G::TH * OW), rem = pix % (G::TH * OW);
+            const int n = img0 + im;
+            if (n >= p.N) continue;
+            const int oy = row0 + rem / OW, ox = rem % OW;
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int o = o0 + ct * 16 + kq * 4 + r;
+                    if (o >= p.CoutReal) continue;
+                    p.out[(((long)n * p.CoutReal + o) * G::OH + oy) * OW + ox] = acc[pt][ct][r] + bv[ct][r];
+                }
+        }
+        if (p.stats) {
+            float* red = reinterpret_cast<float*>(lds_raw);       // [4 waves][32][2]
+            float sv[16];                                         // [sum | sum of squares][channel tile][register]
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                    for (int pt = 0; pt < NPT; ++pt) { const float v = acc[pt][ct][r]; s1 += v; s2 += v * v; }
+                    sv[ct * 4 + r] = s1;
+                    sv[8 + ct * 4 + r] = s2;
+                }
+            {   // lane l15 of every 16-lane row receives the row total of sv[l15]
+                const float tot = row_reduce16(sv);
+                const int j = l15 & 7, ch = (j >> 2) * 16 + kq * 4 + (j & 3);
+                red[(wave * 32 + ch) * 2 + (l15 >> 3)] = tot;
+            }
+            lds_barrier();                                        // LDS only: the output stores keep draining
+            if (tid < 32 && o0 + tid < p.CoutReal) {
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) { s1 += red[(w * 32 + tid) * 2]; s2 += red[(w * 32 + tid) * 2 + 1]; }
+                float* dst = p.stats + ((long)(o0 + tid) * gridDim.x + bx) * 2;
+                dst[0] = s1; dst[1] = s2;
+            }
+        }
+    } else {
 #pragma unroll
     for (int b = 0; b < MT; ++b)
 #pragma unroll
@@ -336,22 +488,23 @@ __global__ __launch_bounds__(256, 2) void conv5_x3_kernel(X3P p) {
             dst[0] = s1; dst[1] = s2;
         }
     }
+    }
 }
 
 thread_local int g_x3_splits = 0;
 
-template <int S, int OW, int MT>
+template <int S, int OW, int MT, bool SH = false>
 int launch_x3(const X3P& p, hipStream_t st) {
-    using G = X3Geom<S, OW, MT>;
+    using G = X3Geom<S, OW, MT, SH>;
     // stride 1: two workgroups per CU; stride 2 (the patch is 4x the output pixels): ONE 4-wave workgroup per CU (see
     // jvae_conv5_x3_ok)
     static_assert(G::LDS_BYTES + 2048 <= (S == 1 ? 80 : 160) * 1024, "workgroups per CU vs the 160 KB LDS");
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_x3_kernel<S, OW, MT, false>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_x3_kernel<S, OW, MT, false, SH>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
         if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_x3_kernel<S, OW, MT, true>),
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_x3_kernel<S, OW, MT, true, SH>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
@@ -362,9 +515,9 @@ int launch_x3(const X3P& p, hipStream_t st) {
     g_x3_splits = (int)grid.x;
     if (p.aff.sc) {
         if (p.Cin > 256) return JVAE_ENOTSUP;
-        hipLaunchKernelGGL((conv5_x3_kernel<S, OW, MT, true>), grid, dim3(256), G::LDS_BYTES, st, p);
+        hipLaunchKernelGGL((conv5_x3_kernel<S, OW, MT, true, SH>), grid, dim3(256), G::LDS_BYTES, st, p);
     } else {
-        hipLaunchKernelGGL((conv5_x3_kernel<S, OW, MT, false>), grid, dim3(256), G::LDS_BYTES, st, p);
+        hipLaunchKernelGGL((conv5_x3_kernel<S, OW, MT, false, SH>), grid, dim3(256), G::LDS_BYTES, st, p);
     }
     JVAE_LAUNCH_CHECK();
     return 0;
@@ -373,6 +526,7 @@ int launch_x3(const X3P& p, hipStream_t st) {
 }  // namespace
 
 static int g_x3 = -1;        // JVAE_X3=0: keep every layer on the fp32 matrix-core kernels (A/B switch)
+static int g_x3_sh16 = -1;   // JVAE_X3_SH16=0: the 32x32x16 MFMA shape in the stride-1 forward-type kernel (A/B switch)
 
 // Layers the split kernel takes over from conv_mfma.hip: stride 1, at least one full K step of input channels.
 static void x3_init() {
@@ -389,6 +543,19 @@ int jvae_conv5_x3_set(int mode) {
 bool jvae_conv5_x3_enabled() {
     x3_init();
     return g_x3 != 0;
+}
+
+static bool x3_sh16() {
+    if (g_x3_sh16 < 0) { const char* e = getenv("JVAE_X3_SH16"); g_x3_sh16 = (e && e[0] == '0') ? 0 : 1; }
+    return g_x3_sh16 != 0;
+}
+
+// MFMA shape of the stride-1 forward-type kernel: 1 = v_mfma_f32_16x16x32_bf16 (K = 2 taps x 16 channels), 0 = 32x32x16.
+// Returns the previous setting.
+int jvae_conv5_x3_set_shape16(int on) {
+    const int old = x3_sh16() ? 1 : 0;
+    g_x3_sh16 = on ? 1 : 0;
+    return old;
 }
 
 // split weights for conv5_x3_kernel / convt2_x3_kernel: ws must hold jvae_conv5_x3_pack_bytes(C, O)
@@ -421,20 +588,32 @@ bool jvae_conv5_x3_ok(int Cin, int H, int W, int Cout, int OH, int OW, int S, in
     return jvae_conv5_fwd_ok(Cin, H, W, Cout, OH, OW, S, P);
 }
 
+// bytes of the larger of the two packed forms (kernel-row groups / tap-pair groups)
 size_t jvae_conv5_x3_pack_bytes(int Cin, int Cout) {
-    return (size_t)((Cin + 15) / 16) * 25 * 2 * ((Cout + 31) / 32 * 32) * 16 * 3;
+    const size_t a = jvae_pack_bytes(JVAE_PACK_X3, Cin, Cout), b = jvae_pack_bytes(JVAE_PACK_X3S, Cin, Cout);
+    return a > b ? a : b;
+}
+
+static int x3s_wpack(const float* w, float* ws, int C, int O, int swap, int flip, hipStream_t st) {
+    const long total = jvae_pack_elems(JVAE_PACK_X3S, C, O);
+    const int blocks = (int)((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256);
+    hipLaunchKernelGGL(x3s_wpack_kernel, dim3(blocks), dim3(256), 0, st, w, (__bf16*)ws, C, O, total, swap, flip);
+    JVAE_LAUNCH_CHECK();
+    return 0;
 }
 
 int jvae_conv5_x3_fwd(const float* in, const float* w, int swap, int flip, const float* bias, float* out,
                       int N, int Cin, int H, int W, int Cout, int OW, int S, int P, float* ws, hipStream_t st,
                       float* stats, int* nsplit, const InAff* aff) {
     const int OP = (Cout + 31) / 32 * 32;
+    const bool sh = S == 1 && OW <= 32 && x3_sh16();        // 64-wide maps (config 5 in fp32) keep the 32x32x16 form
     {   // split weights: the step's cache slot (refreshed once per step, pack_cache.hip) or this call's workspace
         bool fresh = true;
-        float* slot = (float*)jvae_pack_cache_get(JVAE_PACK_X3, w, Cin, Cout, swap, flip, &fresh);
+        const int kind = sh ? JVAE_PACK_X3S : JVAE_PACK_X3;
+        float* slot = (float*)jvae_pack_cache_get(kind, w, Cin, Cout, swap, flip, &fresh);
         if (slot) ws = slot;
         if (!slot || !fresh) {
-            const int rc = jvae_conv5_x3_wpack(w, ws, Cin, Cout, swap, flip, st);
+            const int rc = sh ? x3s_wpack(w, ws, Cin, Cout, swap, flip, st) : jvae_conv5_x3_wpack(w, ws, Cin, Cout, swap, flip, st);
             if (rc) return rc;
         }
     }
@@ -446,6 +625,13 @@ int jvae_conv5_x3_fwd(const float* in, const float* w, int swap, int flip, const
             case 16: return launch_x3<2, 16, 1>(p, st);
         }
         return JVAE_ENOTSUP;
+    }
+    if (sh) {
+        switch (OW) {
+            case 8: return launch_x3<1, 8, 1, true>(p, st);
+            case 16: return launch_x3<1, 16, 2, true>(p, st);
+            case 32: return launch_x3<1, 32, 2, true>(p, st);
+        }
     }
     if (S != 1) return JVAE_ENOTSUP;
     switch (OW) {

@@ -66,6 +66,7 @@ __global__ __launch_bounds__(256) void pack_refresh_kernel(PackTable t) {
         if (i >= total) break;
         if (kind == JVAE_PACK_F32) jvae_pack_f32_elem(en.w, (float*)en.dst, i, en.C, en.O, swap, flip);
         else if (kind == JVAE_PACK_X3) jvae_pack_x3_elem(en.w, (__bf16*)en.dst, i, en.C, en.O, swap, flip);
+        else if (kind == JVAE_PACK_X3S) jvae_pack_x3s_elem(en.w, (__bf16*)en.dst, i, en.C, en.O, swap, flip);
         else jvae_pack_b8_elem(en.w, (__bf16*)en.dst, i, en.C, en.O, swap, flip);
     }
 }
@@ -212,13 +213,14 @@ int jvae_pack_cache_reset(void) {
     return 0;
 }
 
-// Host-side counters (tests / diagnostics): entries of all owners, lookups served from the cache, lookups that packed,
+// Host-side counters (tests / diagnostics): entries of the owner whose span was opened last, lookups served from the cache, lookups that packed,
 // refresh launches.
 int jvae_pack_cache_stats(int* entries, long long* hits, long long* misses, long long* refreshes) {
     std::lock_guard<std::mutex> lk(S.mu);
-    int n = 0;
-    for (const Region& r : S.reg) n += r.used ? r.tab.n : 0;
-    if (entries) *entries = n;
+    const Region* last = nullptr;                    // the owner whose span was opened last
+    for (const Region& r : S.reg)
+        if (r.used && (!last || r.stamp > last->stamp)) last = &r;
+    if (entries) *entries = last ? last->tab.n : 0;
     if (hits) *hits = S.hits;
     if (misses) *misses = S.misses;
     if (refreshes) *refreshes = S.refreshes;

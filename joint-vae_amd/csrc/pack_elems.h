@@ -5,7 +5,11 @@
 #include "common.h"
 #include "conv_x3.h"
 
-enum JvaePackKind { JVAE_PACK_F32 = 0, JVAE_PACK_X3 = 1, JVAE_PACK_B8 = 2 };
+enum JvaePackKind { JVAE_PACK_F32 = 0, JVAE_PACK_X3 = 1, JVAE_PACK_B8 = 2, JVAE_PACK_X3S = 3 };
+
+// tap pairs per K step of the 16x16x32 split-bf16 layout: 25 taps = 12 pairs + tap 24 with an all-zero partner, + one all-zero
+// pair so that every staging group of the kernel (2 pairs) is complete
+#define JVAE_X3S_PAIRS 14
 
 __host__ __device__ __forceinline__ int jvae_pack_op(int O) { return (O + 31) / 32 * 32; }
 
@@ -13,11 +17,12 @@ __host__ __device__ __forceinline__ int jvae_pack_op(int O) { return (O + 31) / 
 __host__ __device__ __forceinline__ long jvae_pack_elems(int kind, int C, int O) {
     const int OP = jvae_pack_op(O);
     if (kind == JVAE_PACK_F32) return (long)C * 25 * OP;
+    if (kind == JVAE_PACK_X3S) return (long)((C + 15) / 16) * JVAE_X3S_PAIRS * 4 * OP * 8;
     return (long)((C + 15) / 16) * 25 * 2 * OP * 8;
 }
 __host__ __device__ __forceinline__ size_t jvae_pack_bytes(int kind, int C, int O) {
     const long n = jvae_pack_elems(kind, C, O);
-    return (size_t)n * (kind == JVAE_PACK_F32 ? 4 : (kind == JVAE_PACK_X3 ? 6 : 2));
+    return (size_t)n * (kind == JVAE_PACK_F32 ? 4 : ((kind == JVAE_PACK_X3 || kind == JVAE_PACK_X3S) ? 6 : 2));
 }
 
 __device__ __forceinline__ float jvae_pack_src(const float* __restrict__ w, int C, int O, int c, int o, int tap, int swap, int flip) {
@@ -58,6 +63,26 @@ __device__ __forceinline__ void jvae_pack_x3_elem(const float* __restrict__ w, _
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl)
         wp[((((long)(kb * 5 + kh) * 30 + (pl * 5 + kw) * 2 + half) * OP) + o) * 8 + ci] = s[pl];
+}
+
+// split-bf16 operand of conv_x3.hip's 16x16x32 form (K index of one MFMA = 2 taps x 16 channels):
+// Wp[kb][pair][plane][kq][o][ci] = plane(W[o][c = kb*16 + (kq&1)*8 + ci][tap = 2*pair + (kq>>1)]), zero for tap >= 25
+__device__ __forceinline__ void jvae_pack_x3s_elem(const float* __restrict__ w, __bf16* __restrict__ wp, long i,
+                                                   int C, int O, int swap, int flip) {
+    const int OP = jvae_pack_op(O);
+    const int ci = (int)(i % 8);
+    long t = i / 8;
+    const int o = (int)(t % OP); t /= OP;
+    const int kq = (int)(t % 4); t /= 4;
+    const int pair = (int)(t % JVAE_X3S_PAIRS);
+    const int kb = (int)(t / JVAE_X3S_PAIRS);
+    const int tap = 2 * pair + (kq >> 1);
+    const float v = tap < 25 ? jvae_pack_src(w, C, O, kb * 16 + (kq & 1) * 8 + ci, o, tap, swap, flip) : 0.f;
+    __bf16 s[3];
+    x3_split(v, s[0], s[1], s[2]);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+        wp[(((((long)kb * JVAE_X3S_PAIRS + pair) * 3 + pl) * 4 + kq) * OP + o) * 8 + ci] = s[pl];
 }
 
 // bf16 operand of conv_b8.hip / conv_t2_b8.hip: Wp[kb][tap][half][o][ci] = bf16(W[o][c = kb*16 + half*8 + ci][tap])

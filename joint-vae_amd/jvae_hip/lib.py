@@ -21,6 +21,7 @@ _SIGS = {
     'jvae_splitk_fold_f32': (c_int, [P, P, P, c_int, c_long, c_int, c_int, c_int, P]),
     'jvae_conv2d_workspace_bytes': (c_size_t, [c_int] * 11),
     'jvae_conv2d_set_split_bf16': (c_int, [c_int]),
+    'jvae_conv2d_set_split_shape16': (c_int, [c_int]),
     'jvae_conv2d_out_shape': (c_int, [c_int] * 8 + [POINTER(c_int), POINTER(c_int)]),
     'jvae_conv2d_fwd_f32': (c_int, [P, P, P, P] + [c_int] * 11 + [P, c_size_t, P]),
     'jvae_conv2d_stats_splits': (c_int, [c_int] * 11),

@@ -145,7 +145,8 @@ def test_full_size_step_matches_reference_golden(name, golden_dir):
     # fp32 gradients sit 1e-4 ... 1.5e-3 (relative L2 per tensor, largest at the first encoder layer, the far end of the
     # chain) from the fp64 ones because ReLU pre-activations within fp32 rounding of zero take the other branch.  An
     # independent fp32 implementation cannot be closer to the reference's fp32 gradient than both are to the exact one,
-    # so each tensor must be (a) within 1e-3 of the reference's fp32 norm, (b) for every stored tensor, element-wise L2:
+    # so each tensor must be (a) within 1e-3 of the reference's fp32 norm (or no further from the fp64 norm than that
+    # is), (b) for every stored tensor, element-wise L2:
     # no further from the reference's fp64 gradient than max(3 x the reference's own fp32 distance, 3e-4).  Measured
     # (tests/diagnostics/full_grad_diag.py): 0.7-2.0 x the reference's distance at N = 512 (worst 2.4e-3 vs 1.2e-3 on
     # features.1.bias), 0.75-1.3 x on the 64x64 geometry; norms within 6.6e-4.
@@ -156,7 +157,12 @@ def test_full_size_step_matches_reference_golden(name, golden_dir):
         if dead_bias(k, g['state_keys']):       # exact-zero gradient: the reference holds rounding noise, we hold 0
             assert mine <= max(1e-6 * tot, 2 * ref32), k
             continue
-        assert abs(mine - ref32) <= 1e-3 * max(ref32, 1e-3 * tot), (k, mine, ref32)
+        # (a) the norm: within 1e-3 of the reference's fp32 value - or at least as close to the reference's fp64 value as
+        # the reference's own fp32 value is.  Second clause (round 4): on c5_n256 the reference's fp32 norm of features.1.bias
+        # is itself 1.11e-3 off its fp64 norm; the 32x32x16 kernels land at -2.6e-4 of fp64 (8.6e-4 from ref32), the 16x16x32
+        # ones at +1.4e-4 of fp64 (1.25e-3 from ref32): closer to the exact gradient, further from the reference's rounding.
+        assert (abs(mine - ref32) <= 1e-3 * max(ref32, 1e-3 * tot)
+                or abs(mine - ref64) <= abs(ref32 - ref64)), (k, mine, ref32, ref64)
         if 'grad64.' + k in g.files:
             g64 = g['grad64.' + k].astype(np.float64)
             d_ref = np.linalg.norm(g['grad.' + k].astype(np.float64) - g64) / max(ref64, 1e-4 * tot)
@@ -356,6 +362,8 @@ def test_reference_checkpoint_interop(tmp_path, golden_dir):
         assert rel(losses[k], g['loss.' + k]) < RTOL, k
     for n_, p in net.named_parameters():
         assert rel(p, g['param_after.' + n_], floor=1e-6) < 2e-5, n_     # second Adam step: moments came from the file
+    assert net.trained == 0                              # history.json of the fixture: no finished epoch
+    net.trained = 1                                      # as the fixture's generator did: tensors are saved `if self.trained`
     net.save(str(tmp_path))
     for f in ('params.json', 'train_params.json', 'test.json', 'ood.json', 'history.json', 'state.pth', 'optimizer.pth'):
         assert os.path.exists(os.path.join(tmp_path, f)), f
@@ -741,14 +749,16 @@ def test_train_model_augments_on_the_device_bit_exact(monkeypatch):
     # no augmentation: the uint8 images are only converted (ToTensor)
     batches.clear(); draws.clear(); data.order.clear()
     net2 = Net(**dict(get_case('c2_n8')['net'])).to(DEV)
-    monkeypatch.setattr(net2, 'train_step', lambda x, y, **k: (batches.append(x.detach().cpu().numpy().copy()), real_step(x, y, **k))[1])
+    step2 = net2.train_step
+    monkeypatch.setattr(net2, 'train_step', lambda x, y, **k: (batches.append(x.detach().cpu().numpy().copy()), step2(x, y, **k))[1])
     net2.train_model(data, epochs=1, batch_size=64, device=DEV)
     assert np.array_equal(batches[0], data.data[data.order[:64]].transpose(0, 3, 1, 2).astype(np.float32) / np.float32(255))
     # 'crop' on an imagenet set pads by 0 (utils/torch_load.py:410): flips only
     batches.clear(); draws.clear(); data.order.clear()
     data.name = 'imagenet20'
     net3 = Net(**dict(get_case('c2_n8')['net'])).to(DEV)
-    monkeypatch.setattr(net3, 'train_step', lambda x, y, **k: (batches.append(x.detach().cpu().numpy().copy()), real_step(x, y, **k))[1])
+    step3 = net3.train_step
+    monkeypatch.setattr(net3, 'train_step', lambda x, y, **k: (batches.append(x.detach().cpu().numpy().copy()), step3(x, y, **k))[1])
     net3.train_model(data, epochs=1, batch_size=83, data_augmentation=['flip', 'crop'], device=DEV)
     flip, dy, dx = draws[0]
     assert dy is None and dx is None and np.array_equal(batches[0], augment(data.data[data.order], flip, None, None, 0))
