@@ -7,6 +7,7 @@
 //
 // Numerics: per-channel sums are taken on data shifted by the channel's first element (robust against
 // |mean| >> std), per-block partials are combined in fp64 by a one-block finalize kernel.
+#include <stdlib.h>
 #include "common.h"
 #include "jvae_internal.h"
 
@@ -208,7 +209,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
                                                             float* __restrict__ partial, int N, int C, int P, int nsplit,
                                                             int relu) {
     __shared__ float red[17];
-    const int c = blockIdx.x, s = blockIdx.y;
+    const int c = blockIdx.x, s = (relu & 2) ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.y;
+    relu &= 1;
     const float mu = mean[c], is = invstd[c];
     const float g_ = gamma ? gamma[c] : 1.f, b_ = beta ? beta[c] : 0.f;
     float sc, sh;
@@ -260,7 +262,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            int N, int C, int P, int nsplit, int nchunk, int relu,
                                                            const float* __restrict__ gsums, int count_mult) {
     __shared__ float ms[2];
-    const int c = blockIdx.x, j = blockIdx.y;
+    const int c = blockIdx.x, j = (relu & 2) ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.y;
+    relu &= 1;
     if (threadIdx.x == 0) {
         double s1 = 0., s2 = 0.;
         for (int s = 0; s < nsplit; ++s) {
@@ -470,12 +473,18 @@ int jvae_bn_bwd_f32(const float* dy, const float* x, const float* gamma, const f
     hipStream_t st = (hipStream_t)stream;
     float* partial = (float*)ws;
     const int ns = pick_split(N, C, P);
+    // Traversal order against the 256 MB Infinity Cache: the reduction walks the image parts DOWNWARDS - it starts on the part of dy
+    // that the producing dgrad kernel wrote last - and the apply pass walks them upwards, i.e. starts on what the reduction
+    // read last: 113-118 us instead of 120-124 for the 134 MB activation (two 268 MB sweeps), about 1 % of the step.
+    // JVAE_BN_ORDER (bit 0: reduce downwards, bit 1: apply downwards; default 1) is the A/B switch; 0 and 3 measure alike.
+    static int order = -1;
+    if (order < 0) { const char* e = getenv("JVAE_BN_ORDER"); order = e ? atoi(e) : 1; }
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C, ns), dim3(256), 0, st, dy, x, gamma, beta, save_mean, save_invstd,
-                       partial, N, C, P, ns, relu);
+                       partial, N, C, P, ns, relu | ((order & 1) ? 2 : 0));
     JVAE_LAUNCH_CHECK();
     const int nc = pick_chunk(N, C, P);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(C, nc), dim3(256), 0, st, dy, x, gamma, beta, save_mean, save_invstd,
-                       partial, dx, dgamma, dbeta, accumulate, N, C, P, ns, nc, relu, (const float*)nullptr, 1);
+                       partial, dx, dgamma, dbeta, accumulate, N, C, P, ns, nc, relu | ((order & 2) ? 2 : 0), (const float*)nullptr, 1);
     JVAE_LAUNCH_CHECK();
     return 0;
 }
