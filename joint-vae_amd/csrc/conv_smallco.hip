@@ -7,6 +7,7 @@
 // ds_read_b128 and 5*CO weights (wave-uniform LDS broadcast) and issues 20*CO FMAs.  A 256-thread workgroup
 // covers 1024 pixels (32 rows of a 32-wide image, 16 rows of a 64-wide one); input channels are staged 8 at a
 // time, next chunk prefetched into registers under the FMAs.
+#include <stdlib.h>
 #include "common.h"
 #include "jvae_internal.h"
 #include "conv_dispatch.h"
@@ -125,9 +126,137 @@ __global__ __launch_bounds__(256) void conv5_smallco_kernel(SmP p) {
     }
 }
 
+// Round 4 form (default; JVAE_SMALLCO_V2=0 selects the kernel above for an A/B).  What the first form was bound by: per
+// (input channel, kernel row) a wave issued 3 + 5 ds_read_b128 - 3 for its 12 patch values, 5 for the 5 x CO weights, read as
+// wave-uniform LDS broadcasts - for 60 FMAs: 4 SIMDs x 8 reads x 4 LDS cycles = 128 LDS cycles per 120 FMA cycles.  The LDS,
+// not the vector ALU, set the pace (107 us for 5.03 GFLOP at N = 1024: 47 TFLOP/s of 157).  Here the weights never touch the
+// LDS: they are wave-uniform, so the compiler fetches them with scalar loads straight into SGPRs (s_load through the scalar
+// cache; the 9.6 KB of the layer stay resident) and every FMA takes its weight as the instruction's scalar operand.  The LDS
+// then serves 3 reads per 60 FMAs.  CC = 4 input channels per stage (23 KB): four workgroups per CU, so the 1024 workgroups
+// of the 32 x 32 head (one image each) are all resident at once - the first form ran 768 at a time, a second round for the
+// last third.
+template <int OW, int CO, int CC>
+__global__ __launch_bounds__(256, 4) void conv5_smallco2_kernel(SmP p) {
+    constexpr int OH = OW;
+    constexpr int TH = 1024 / OW;                  // rows per workgroup
+    constexpr int ROWS = TH + 4;
+    constexpr int WP = OW + 8;                     // data at col 4 (16-byte aligned), halo 2 each side (P <= 4)
+    constexpr int CH = ROWS * WP;
+    constexpr int XS = CC * CH;
+    __shared__ __attribute__((aligned(16))) float Xs[XS];
+    __shared__ float ctab[2 * 256];                // (scale, shift) of the deferred BatchNorm, all input channels (host: Cin <= 256)
+
+    const int tid = threadIdx.x;
+    constexpr int TPI = OH / TH;                   // tiles per image
+    const int n = blockIdx.x / TPI, row0 = (blockIdx.x % TPI) * TH;
+    constexpr int XQ = OW / 4;
+    const int r = tid / XQ, xq = tid % XQ;         // this thread: row r, pixels 4*xq .. 4*xq+3
+
+    constexpr int W4 = OW / 4;
+    constexpr int XUNITS = CC * ROWS * W4;
+    constexpr int XU = (XUNITS + 255) / 256;
+    f32x4 rx[XU];
+    const int in_row0 = row0 - p.P;
+    if (p.aff.sc)
+        for (int i = tid; i < p.Cin; i += 256) { ctab[i] = p.aff.sc[i]; ctab[256 + i] = p.aff.sh[i]; }
+    auto gload = [&](int c0) {
+#pragma unroll
+        for (int k = 0; k < XU; ++k) {
+            const int u = tid + k * 256;
+            const int x4 = u % W4;
+            const int t = u / W4;
+            const int lr = t % ROWS, c = t / ROWS;
+            const int ir = in_row0 + lr, ch = c0 + c;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (u < XUNITS && ir >= 0 && ir < OH && ch < p.Cin)
+                v = *reinterpret_cast<const f32x4*>(p.in + (((long)n * p.Cin + ch) * OH + ir) * OW + x4 * 4);
+            rx[k] = v;
+        }
+    };
+    gload(0);
+    // halo columns: zeroed once, never written again (rows are rewritten per stage, zeros outside the image)
+    for (int i = tid; i < CC * ROWS * 2; i += 256) {
+        f32x4* rowp = reinterpret_cast<f32x4*>(&Xs[(i >> 1) * WP]);
+        rowp[(i & 1) ? (WP / 4 - 1) : 0] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    float acc[CO][4];
+#pragma unroll
+    for (int o = 0; o < CO; ++o)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[o][j] = 0.f;
+
+    // constant address space: a wave-uniform load from it is a scalar load (s_load_dword*) whatever else the kernel stores
+    typedef const __attribute__((address_space(4))) float* const_f32_p;
+    const const_f32_p wq = (const_f32_p)(unsigned long long)p.w;
+    for (int c0 = 0; c0 < p.Cin; c0 += CC) {
+        __syncthreads();                           // every wave is past the previous stage's reads
+#pragma unroll
+        for (int k = 0; k < XU; ++k) {
+            const int u = tid + k * 256;
+            if (u < XUNITS) {
+                const int x4 = u % W4;
+                const int t = u / W4;
+                const int lr = t % ROWS, c = t / ROWS;
+                const int ir = in_row0 + lr, ch = c0 + c;
+                f32x4 v = rx[k];                   // padding rows / missing channels hold zeros and stay zeros
+                if (p.aff.sc && ir >= 0 && ir < OH && ch < p.Cin) v = aff4(v, ctab[ch], ctab[256 + ch], p.aff.relu);
+                *reinterpret_cast<f32x4*>(&Xs[c * CH + lr * WP + 4 + x4 * 4]) = v;
+            }
+        }
+        __syncthreads();
+        if (c0 + CC < p.Cin) gload(c0 + CC);
+#pragma unroll
+        for (int c = 0; c < CC; ++c) {
+            const int ch = min(c0 + c, p.Cin - 1);                 // channels beyond Cin: zero patch, any valid weight
+#pragma unroll
+            for (int kh = 0; kh < 5; ++kh) {
+                // 12 consecutive patch values starting at lds col 4*xq (input col 4*xq - 4)
+                const float* row = &Xs[c * CH + (r + kh) * WP + 4 * xq];
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(row);
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(row + 4);
+                const f32x4 v2 = *reinterpret_cast<const f32x4*>(row + 8);
+                const float in12[12] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3], v2[0], v2[1], v2[2], v2[3]};
+                float wv[CO][5];                                   // wave-uniform: scalar loads, SGPR operands
+#pragma unroll
+                for (int o = 0; o < CO; ++o)
+#pragma unroll
+                    for (int kw = 0; kw < 5; ++kw) wv[o][kw] = wq[((long)o * p.Cin + ch) * 25 + kh * 5 + kw];
+#pragma unroll
+                for (int kw = 0; kw < 5; ++kw)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float xv = in12[j + kw + 4 - 2];   // lds col = x + kw - P + 4 relative to 4*xq, P == 2
+#pragma unroll
+                        for (int o = 0; o < CO; ++o) acc[o][j] = fmaf(wv[o][kw], xv, acc[o][j]);
+                    }
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < CO; ++o) {
+        const float b = p.bias ? p.bias[o] : 0.f;
+        f32x4 v = {acc[o][0] + b, acc[o][1] + b, acc[o][2] + b, acc[o][3] + b};
+        *reinterpret_cast<f32x4*>(p.out + (((long)n * CO + o) * OH + row0 + r) * OW + 4 * xq) = v;
+    }
+}
+
 template <int OW>
 int launch_sm(const SmP& p, int CO, hipStream_t st) {
     dim3 grid((unsigned)(p.N * (OW * OW / 1024)));
+    static int v2 = -1;
+    if (v2 < 0) { const char* e = getenv("JVAE_SMALLCO_V2"); v2 = e ? atoi(e) : 1; }
+    if (v2) {
+        switch (CO) {
+            case 1: hipLaunchKernelGGL((conv5_smallco2_kernel<OW, 1, 4>), grid, dim3(256), 0, st, p); break;
+            case 2: hipLaunchKernelGGL((conv5_smallco2_kernel<OW, 2, 4>), grid, dim3(256), 0, st, p); break;
+            case 3: hipLaunchKernelGGL((conv5_smallco2_kernel<OW, 3, 4>), grid, dim3(256), 0, st, p); break;
+            case 4: hipLaunchKernelGGL((conv5_smallco2_kernel<OW, 4, 4>), grid, dim3(256), 0, st, p); break;
+            default: return JVAE_ENOTSUP;
+        }
+        JVAE_LAUNCH_CHECK();
+        return 0;
+    }
     switch (CO) {
         case 1: hipLaunchKernelGGL((conv5_smallco_kernel<OW, 1, 8>), grid, dim3(256), 0, st, p); break;
         case 2: hipLaunchKernelGGL((conv5_smallco_kernel<OW, 2, 8>), grid, dim3(256), 0, st, p); break;
@@ -148,6 +277,7 @@ bool jvae_conv5_smallco_ok(int Cin, int H, int W, int Cout, int KH, int KW, int 
 int jvae_conv5_smallco(const float* in, const float* w, const float* bias, float* out, int N, int Cin, int W, int Cout,
                        hipStream_t st, const InAff* aff) {
     SmP p{in, w, bias, out, N, Cin, 2, aff ? *aff : InAff{nullptr, nullptr, 0}};
+    if (p.aff.sc && Cin > 256) return JVAE_ENOTSUP;          // coefficient table of the deferred BatchNorm
     if (W == 32) return launch_sm<32>(p, Cout, st);
     if (W == 64) return launch_sm<64>(p, Cout, st);
     return JVAE_ENOTSUP;

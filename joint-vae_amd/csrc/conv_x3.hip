@@ -58,7 +58,29 @@ struct X3P {
     int N, Cin, H, W, OP, P, CoutReal;
     float* stats;        // optional (CoutReal, gridDim.x, 2)
     InAff aff;           // deferred BatchNorm(+ReLU) of the input (sc == nullptr: none)
+#ifdef JVAE_X3_STAMPS
+    unsigned long long* dbg;   // DIAGNOSTIC BUILD ONLY (tools/x3_stamps.py): 96 s_memtime stamps of wave 0 per workgroup
+#endif
 };
+
+// In-kernel anatomy (cdna_hip_programming.md section 7, In-kernel stamps): a separate diagnostic build (-DJVAE_X3_STAMPS, make stamps)
+// records s_memtime at the phase boundaries of wave 0 of every workgroup into a buffer of its own; the product build contains
+// no stamp.
+#ifdef JVAE_X3_STAMPS
+#define X3_STAMP(i)                                                                                              \
+    do {                                                                                                         \
+        if (p.dbg && threadIdx.x == 0)                                                                           \
+            p.dbg[((long)blockIdx.y * gridDim.x + blockIdx.x) * 96 + (i)] = __builtin_amdgcn_s_memtime();        \
+    } while (0)
+#define X3_STAMP_RT(i)                                                                                           \
+    do {                                                                                                         \
+        if (p.dbg && threadIdx.x == 0)                                                                           \
+            p.dbg[((long)blockIdx.y * gridDim.x + blockIdx.x) * 96 + (i)] = __builtin_amdgcn_s_memrealtime();    \
+    } while (0)
+#else
+#define X3_STAMP(i) do {} while (0)
+#define X3_STAMP_RT(i) do {} while (0)
+#endif
 
 // SH = false: v_mfma_f32_32x32x16_bf16, K index = 16 channels of one tap, weights staged per kernel row (5 taps).
 // SH = true:  v_mfma_f32_16x16x32_bf16, K index = 2 CONSECUTIVE taps (of the 25-tap sequence) x 16 channels - lane group
@@ -103,6 +125,8 @@ __global__ __launch_bounds__(256, 2) void conv5_x3_kernel(X3P p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
+    X3_STAMP(0);
+    X3_STAMP_RT(64);
     constexpr int TILES_PER_IMG = G::OHW >= G::PIX ? G::OHW / G::PIX : 1;
     // XCD-aware tile order: consecutive workgroup ids go round-robin to the 8 XCDs (each with its own L2), so the row tiles
     // of ONE image - which share their halo rows - used to sit on different XCDs and every halo row came from HBM again
@@ -122,9 +146,6 @@ __global__ __launch_bounds__(256, 2) void conv5_x3_kernel(X3P p) {
             ctab[i] = ok ? p.aff.sc[i] : 0.f;
             ctab[256 + i] = ok ? p.aff.sh[i] : 0.f;
         }
-    // halo columns / out-of-image rows / missing images / missing channels are zeroed once and never written again
-    for (int i = tid; i < 3 * G::XS; i += 256) Xs[i] = u32x4{0u, 0u, 0u, 0u};
-
     // pixel tiles of this wave: MT groups of 32 pixels (32x32x16: the pixel on lane & 31, channel block `half`), or 2*MT tiles of 16
     // (16x16x32: the pixel on lane & 15, lane group kq = lane >> 4 = (tap of the pair, channel block))
     constexpr int NPT = SH ? 2 * MT : MT, TPX = SH ? 16 : 32;
@@ -345,16 +366,32 @@ __global__ __launch_bounds__(256, 2) void conv5_x3_kernel(X3P p) {
     // LDS-only barrier: __syncthreads() also waits for vmcnt(0), i.e. for the global prefetches in flight
     auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
 
+    X3_STAMP(1);                                   // 0 = kernel entry (below the declarations), 1 = zero fill issued
     gloadX(0);
     gloadW(0);
-    __syncthreads();                               // zero fill + coefficient table complete
+    // The halo COLUMNS (4 units left of the image row, WP - 4 - WIN right of it) are zeroed once and never written again;
+    // every other cell - out-of-image rows, missing images and channels included - is rewritten by lstoreX at every K step.
+    // Issued behind the first global loads (they fly meanwhile).  Round 4: the whole 46 KB image used to be cleared, in front
+    // of the loads: 2 200 of a workgroup's 73 500 cycles (tools/x3_stamps.py).
+    {
+        constexpr int HALO = G::WP - G::WIN, NROW = 3 * G::NIMG * 2 * G::ROWS;
+        for (int i = tid; i < NROW * HALO; i += 256) {
+            const int r = i / HALO, c = i % HALO;
+            const int pl = r / (G::NIMG * 2 * G::ROWS), rr = r % (G::NIMG * 2 * G::ROWS);
+            Xs[pl * G::XS + rr * G::WP + (c < 4 ? c : c + G::WIN)] = u32x4{0u, 0u, 0u, 0u};
+        }
+    }
+    __syncthreads();                               // halo zero fill + coefficient table complete
+    X3_STAMP(2);
     lstoreX(0);
     lstoreW(0);
     __builtin_amdgcn_sched_barrier(0);
     if (NG > 1) gloadW(1);
     lds_barrier();
+    X3_STAMP(3);
     int kb = 0, kh = 0;
     for (int g = 0; g < NG; ++g) {
+        if (g < 14) X3_STAMP(8 + 4 * g);           // group start
         // invariant: patch of K step kb in Xs, weight group g in buffer g&1, rw = weight group g+1 (in flight)
         const bool more = g + 1 < NG, last_row = kh == G::GPK - 1;
         // buffer (g+1)&1 was last read in group g-1: every wave is past it.  The store (which waits for the loads of
@@ -364,16 +401,21 @@ __global__ __launch_bounds__(256, 2) void conv5_x3_kernel(X3P p) {
         if (g + 2 < NG) gloadW(g + 2);
         if (kh == G::GPK - 2 && kb + 1 < KB) gloadX(kb + 1);
         __builtin_amdgcn_sched_barrier(0);
+        if (g < 14) X3_STAMP(9 + 4 * g);           // weights stored, next loads issued
         if constexpr (SH) computeSH(g & 1, kh);
         else compute(g & 1, kh * G::WP);
+        if (g < 14) X3_STAMP(10 + 4 * g);          // MFMAs issued
         lds_barrier();
+        if (g < 14) X3_STAMP(11 + 4 * g);          // barrier passed
         if (more && last_row) {                    // K step change: the patch is fully consumed
             lstoreX(kb + 1);
             lds_barrier();
+            X3_STAMP(4);                           // (first) K step change done
         }
         if (++kh == G::GPK) { kh = 0; ++kb; }
     }
 
+    X3_STAMP(5);                                   // main loop done
     if constexpr (SH) {
         // ---- epilogue, 16x16x32: lane holds pixel l15 of each 16-pixel tile, channels ct*16 + kq*4 + r
 #pragma unroll
@@ -401,6 +443,7 @@ __global__ __launch_bounds__(256, 2) void conv5_x3_kernel(X3P p) {
                     p.out[(((long)n * p.CoutReal + o) * G::OH + oy) * OW + ox] = acc[pt][ct][r] + bv[ct][r];
                 }
         }
+        X3_STAMP(6);                               // output stores issued
         if (p.stats) {
             float* red = reinterpret_cast<float*>(lds_raw);       // [4 waves][32][2]
             float sv[16];                                         // [sum | sum of squares][channel tile][register]
@@ -428,6 +471,8 @@ __global__ __launch_bounds__(256, 2) void conv5_x3_kernel(X3P p) {
                 dst[0] = s1; dst[1] = s2;
             }
         }
+        X3_STAMP(7);                               // end of the workgroup's program
+        X3_STAMP_RT(65);
     } else {
 #pragma unroll
     for (int b = 0; b < MT; ++b)
@@ -525,6 +570,10 @@ int launch_x3(const X3P& p, hipStream_t st) {
 
 }  // namespace
 
+#ifdef JVAE_X3_STAMPS
+static unsigned long long* g_x3_dbg = nullptr;
+extern "C" void jvae_x3_set_stamp_buffer(void* buf) { g_x3_dbg = (unsigned long long*)buf; }     // diagnostic build only
+#endif
 static int g_x3 = -1;        // JVAE_X3=0: keep every layer on the fp32 matrix-core kernels (A/B switch)
 static int g_x3_sh16 = -1;   // JVAE_X3_SH16=0: the 32x32x16 MFMA shape in the stride-1 forward-type kernel (A/B switch)
 
@@ -618,6 +667,9 @@ int jvae_conv5_x3_fwd(const float* in, const float* w, int swap, int flip, const
         }
     }
     X3P p{in, (const u32x4*)ws, bias, out, N, Cin, H, W, OP, P, Cout, stats, aff ? *aff : InAff{nullptr, nullptr, 0}};
+#ifdef JVAE_X3_STAMPS
+    p.dbg = g_x3_dbg;
+#endif
     struct Fin { int* n; ~Fin() { if (n) *n = g_x3_splits; } } fin{nsplit};
     if (S == 2) {
         switch (OW) {
