@@ -230,7 +230,10 @@ class HipConvStack(nn.Sequential):
         ext = None
         aff = None           # (scale, shift, relu) of a BatchNorm deferred into the next bf16 convolution
         channels = x.shape[1]
+        tape = getattr(self, '_debug_tape', None)    # diagnostics only (tests/diagnostics/b8_stack_oracle_diag.py): (index, fp32 copy)
         while i < len(mods):
+            if tape is not None and i > 0:
+                tape.append((i - 1, (ops_b8.unpack(x.detach(), channels) if ops_b8.is_b8(x) else x.detach()).clone(), aff))
             m = mods[i]
             b8 = ops_b8.is_b8(x)
             if isinstance(m, (HipConv2d, HipConvTranspose2d)):

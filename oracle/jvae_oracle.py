@@ -248,25 +248,128 @@ def _tape(name, t):
     return t
 
 
+# ---- bf16 emulation of the product's mixed-precision mode (BASELINE configs[4]; the reference has no such mode) ----------------
+# BF16_CONV = True makes run_stack() round where the drop-in's bf16 path stores or multiplies bf16 (joint-vae_amd/module/
+# vae_layers/conv.py::_forward_b8, jvae_hip/ops_b8.py): a 5x5 (de)convolution - the geometries with bf16 kernels - multiplies
+# bf16(input) by bf16(weight) with fp32 accumulation and fp32 bias and stores its output in bf16 (the last convolution of a stack
+# that feeds the loss stores fp32); the BatchNorm behind it takes its batch statistics from the fp32 accumulators, normalises
+# the STORED bf16 tensor in fp32 and stores bf16 again; the gradients that travel between those layers are bf16 tensors too
+# (dgrad output, BatchNorm-backward output; the gradient arriving at an fp32 output is rounded when it becomes an MFMA
+# operand).  Everything else - other kernel sizes, dense layers, latent and loss arithmetic, parameter gradients, clip, Adam -
+# is fp32, as in the product.  This pins the bf16 model to a MODEL of its arithmetic instead of to a tolerance read off a run.
+BF16_CONV = False
+
+
+class bf16_convs:
+    """`with bf16_convs(): ...` - the oracle's conv stacks emulate the product's bf16 mode inside the block."""
+
+    def __enter__(self):
+        global BF16_CONV
+        self.old, BF16_CONV = BF16_CONV, True
+
+    def __exit__(self, *a):
+        global BF16_CONV
+        BF16_CONV = self.old
+
+
+def _rbf(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+class _StoredBF16(torch.autograd.Function):
+    """A tensor kept in bf16: the value is rounded on the way forward, its gradient on the way back."""
+
+    @staticmethod
+    def forward(ctx, t):
+        return _rbf(t)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _rbf(g)
+
+
+class _OperandBF16(torch.autograd.Function):
+    """fp32 master weights rounded when they become an MFMA operand; their gradient stays fp32."""
+
+    @staticmethod
+    def forward(ctx, t):
+        return _rbf(t)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+class _GradBF16(torch.autograd.Function):
+    """An fp32 output whose incoming gradient is rounded when the backward kernels take it as an operand."""
+
+    @staticmethod
+    def forward(ctx, t):
+        return t.view_as(t)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _rbf(g)
+
+
+def _bn_from(stat_src, x, rm, rv, gamma, beta, training, momentum, eps):
+    """BatchNorm2d of x with the batch statistics of `stat_src` (the fp32 accumulators the stored tensor x was rounded from);
+    the backward is the ordinary BatchNorm backward of x (what the product's kernel computes from the stored tensor)."""
+    if not training:
+        return F.batch_norm(x, rm, rv, gamma, beta, False, momentum, eps)
+    dims = (0, 2, 3)
+    n = x.numel() // x.shape[1]
+    mean_x, var_x = x.mean(dims), x.var(dims, unbiased=False)
+    with torch.no_grad():
+        m_s, v_s = stat_src.mean(dims), stat_src.var(dims, unbiased=False)
+        rm.mul_(1 - momentum).add_(momentum * m_s)
+        rv.mul_(1 - momentum).add_(momentum * v_s * n / max(n - 1, 1))
+    mean = mean_x + (m_s - mean_x).detach()          # value of the accumulators' statistics, gradient of x's own
+    var = var_x + (v_s - var_x).detach()
+    xh = (x - mean.view(1, -1, 1, 1)) * torch.rsqrt(var.view(1, -1, 1, 1) + eps)
+    return xh * gamma.view(1, -1, 1, 1) + beta.view(1, -1, 1, 1)
+
+
 def run_stack(P, prefix, layers, bn, x, last_act, training=True, momentum=0.1, eps=1e-5):
     """conv.py:186-230: (de)conv -> [BatchNorm2d] -> ReLU; the LAST activation is `last_act` for upsamplers."""
     i = 0
+    b8 = False                       # bf16 emulation: x is a tensor the product holds in bf16
     for li, d in enumerate(layers):
         w, b = P[f'{prefix}.{i}.weight'], P[f'{prefix}.{i}.bias']
+        native = BF16_CONV and d['k'] == 5
+        acc = None
+        if native:
+            if not b8:
+                x = _StoredBF16.apply(x)                 # to_b8(): the fp32 tensor enters the bf16 layout
+            w = _OperandBF16.apply(w)
         if d['kind'] == 'conv':
             x = F.conv2d(x, w, b, stride=d['s'], padding=d['p'])
         else:
             x = F.conv_transpose2d(x, w, b, stride=d['s'], padding=d['p'], output_padding=d['op'])
+        if native:
+            last_f32 = li == len(layers) - 1 and not bn   # the stack's last convolution writes fp32 for the loss
+            acc = x
+            x = _GradBF16.apply(x) if last_f32 else _StoredBF16.apply(x)
+            b8 = not last_f32
+        else:
+            b8 = False
         _tape(f'{prefix}.{i}', x)
         i += 1
         if bn:
-            x = F.batch_norm(x, P[f'{prefix}.{i}.running_mean'], P[f'{prefix}.{i}.running_var'],
+            if b8:
+                x = _bn_from(acc, x, P[f'{prefix}.{i}.running_mean'], P[f'{prefix}.{i}.running_var'],
                              P[f'{prefix}.{i}.weight'], P[f'{prefix}.{i}.bias'], training, momentum, eps)
+            else:
+                x = F.batch_norm(x, P[f'{prefix}.{i}.running_mean'], P[f'{prefix}.{i}.running_var'],
+                                 P[f'{prefix}.{i}.weight'], P[f'{prefix}.{i}.bias'], training, momentum, eps)
             if training:
                 P[f'{prefix}.{i}.num_batches_tracked'] += 1
             i += 1
         act = 'relu' if (last_act is None or li < len(layers) - 1) else last_act
-        x = _tape(f'{prefix}.{i}', _act(x, act))
+        x = _act(x, act)
+        if b8:
+            x = _StoredBF16.apply(x)                     # the normalised activation is stored (or becomes an operand) in bf16
+        x = _tape(f'{prefix}.{i}', x)
         i += 1
     return x
 

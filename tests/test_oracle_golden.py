@@ -140,3 +140,97 @@ def test_oracle_wim_step_matches_reference(name, golden_dir):
     for f in g.files:
         if f.startswith('buffer_after.'):
             _close(P[f[13:]].detach().double(), g[f], rtol=1e-5, what=f)
+
+
+def test_oracle_bf16_mode_rounds_where_the_product_does():
+    """The bf16-emulating mode of the oracle (bf16_convs; the reference has no bf16 mode - this models the PRODUCT's arithmetic
+    for BASELINE configs[4]): around 5x5 convolutions the stored activations are bf16 values, BatchNorm takes its batch statistics
+    from the fp32 accumulators, other kernel sizes stay fp32, activation gradients are rounded where they are stored, parameter
+    gradients are not; outside the context manager the oracle is the plain fp32 restatement again (bit for bit)."""
+    import torch
+    from oracle import jvae_oracle as O
+
+    def is_bf16(t):
+        return bool(torch.equal(t, t.to(torch.bfloat16).to(torch.float32)))
+    torch.manual_seed(0)
+    layers = O.parse_stack('32x5+2-64x5+2:2-8x3', (3, 16, 16), False)
+    P = {}
+    i = 0
+    for d in layers:
+        P[f's.{i}.weight'] = (torch.randn(d['c'], d['cin'], d['k'], d['k']) / (d['cin'] * d['k'] ** 2) ** 0.5).requires_grad_(True)
+        P[f's.{i}.bias'] = (0.1 * torch.randn(d['c'])).requires_grad_(True)
+        i += 1
+        P[f's.{i}.weight'] = (1 + 0.1 * torch.randn(d['c'])).requires_grad_(True)
+        P[f's.{i}.bias'] = (0.1 * torch.randn(d['c'])).requires_grad_(True)
+        P[f's.{i}.running_mean'], P[f's.{i}.running_var'] = torch.zeros(d['c']), torch.ones(d['c'])
+        P[f's.{i}.num_batches_tracked'] = torch.zeros((), dtype=torch.long)
+        i += 2
+    x = torch.rand(5, 3, 16, 16)
+
+    def run(bf16):
+        for k in list(P):
+            if k.endswith('running_mean'): P[k] = torch.zeros_like(P[k])
+            if k.endswith('running_var'): P[k] = torch.ones_like(P[k])
+            if P[k].requires_grad: P[k].grad = None
+        O.TAPE = tape = []
+        try:
+            if bf16:
+                with O.bf16_convs():
+                    y = O.run_stack(P, 's', layers, True, x, None, True)
+            else:
+                y = O.run_stack(P, 's', layers, True, x, None, True)
+        finally:
+            O.TAPE = None
+        y.square().sum().backward()
+        return y.detach().clone(), dict(tape), {k: v.grad.clone() for k, v in P.items() if v.requires_grad}
+    y0, t0, g0 = run(False)
+    y1, t1, g1 = run(True)
+    y2, t2, g2 = run(False)
+    assert torch.equal(y0, y2) and all(torch.equal(g0[k], g2[k]) for k in g0)        # the switch leaves no trace
+    assert not O.BF16_CONV
+    # 5x5 layers: stored conv output and stored activation are bf16 values; the 3x3 tail is fp32 again
+    assert is_bf16(t1['s.0'].detach()) and is_bf16(t1['s.2'].detach()) and is_bf16(t1['s.3'].detach()) and is_bf16(t1['s.5'].detach())
+    assert not is_bf16(t1['s.6'].detach()) and not is_bf16(y1)
+    assert not is_bf16(t0['s.0'].detach())
+    # close to fp32 at bf16 level, not equal; parameter gradients are fp32 values
+    rel = float((y1 - y0).norm() / y0.norm())
+    assert 1e-4 < rel < 3e-2, rel
+    assert not is_bf16(g1['s.0.weight']) and float((g1['s.0.weight'] - g0['s.0.weight']).norm() / g0['s.0.weight'].norm()) < 0.1
+    # BatchNorm statistics come from the fp32 accumulators: the running mean equals momentum * mean of the UNROUNDED conv output
+    with O.bf16_convs():
+        w = P['s.0.weight'].detach().to(torch.bfloat16).float()
+        acc = torch.nn.functional.conv2d(x.to(torch.bfloat16).float(), w, P['s.0.bias'].detach(), padding=2)
+    run(True)
+    assert torch.allclose(P['s.1.running_mean'], 0.1 * acc.mean((0, 2, 3)), rtol=1e-5, atol=1e-7)
+    assert not torch.allclose(P['s.1.running_mean'], 0.1 * acc.to(torch.bfloat16).float().mean((0, 2, 3)), rtol=1e-7, atol=0)
+
+
+def test_bf16_emulation_fixture_is_what_the_oracle_computes(golden_dir):
+    """tests/golden/c5_n256_bf16emu.npz (oracle/gen_bf16_golden.py) against the oracle run again at a batch that takes seconds:
+    the same code path at N = 8 is deterministic, its fp32 twin reproduces the plain oracle, and the stored N = 256 file carries
+    both the bf16-emulated and the fp32 step of the same inputs (the GPU test compares the product's bf16 mode with the former
+    and reports its distance to the latter)."""
+    import torch
+    from oracle import jvae_oracle as O
+    from oracle.det_init import det_inputs
+    g = np.load(os.path.join(golden_dir, 'c5_n256_bf16emu.npz'))
+    ref = np.load(os.path.join(golden_dir, 'c5_n256.npz'))
+    # the fixture's fp32 half is the oracle's plain step: it agrees with the REFERENCE's own golden of the same case
+    for k in ('total', 'cross_x', 'kl'):
+        a, b = g['loss.' + k + '.fp32'].astype(np.float64), ref['loss.' + k].astype(np.float64)
+        assert float(np.abs(a - b).max() / np.abs(b).max()) < 2e-5, k
+    assert abs(float(g['total_grad_norm.fp32']) / float(ref['total_grad_norm']) - 1) < 1e-4
+    # the bf16 half sits at bf16 distance from it: not equal, not far
+    d = float((np.abs(g['loss.total'].astype(np.float64) - g['loss.total.fp32']) / np.abs(g['loss.total.fp32'])).max())
+    assert 1e-4 < d < 2e-2, d
+    case = get_case('c5_n256')
+    kw = case['net']
+    sp = O.make_spec(**kw)
+    x, y, eps = det_inputs(8, kw['input_shape'], kw['num_labels'], 1, kw['latent_dim'])
+    outs = []
+    for _ in range(2):
+        P = O.init_state(sp, seed=0)
+        with O.bf16_convs():
+            o, grads, gn = O.train_step(sp, P, O.AdamState(sp), x, y, eps)
+        outs.append((o[2]['total'].detach().clone(), gn))
+    assert torch.equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1]
