@@ -101,7 +101,45 @@ def _graph_worker(rank, port, out_dir):
     g = torch.Generator().manual_seed(50 + rank)        # each rank its own shard
     x = torch.rand(16, 3, 32, 32, generator=g).cuda()
     y = torch.randint(0, 10, (16,), generator=g).cuda()
-    eager_losses, _ = net.train_step(x, y)               # one eager data-parallel step (early bucket + remainder)
+    # the early (decoder) bucket really is exchanged while the encoder's backward is still to come.  Every
+    # collective and every dgrad launch of this eager step is logged in host order with a HIP event on the stream it is issued on.
+    from jvae_hip import ops as _ops
+    order = []
+    real_ar, real_dg = dist.all_reduce, _ops.conv_dgrad_raw
+
+    def logged_all_reduce(t, *a, **k):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(torch.cuda.current_stream())
+        order.append(('allreduce', int(t.numel()), bool(k.get('async_op', False)), ev))
+        return real_ar(t, *a, **k)
+
+    def logged_dgrad(gy, w, spec, shape):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(torch.cuda.current_stream())
+        order.append(('dgrad', (spec.cin, spec.cout, bool(spec.transposed)), False, ev))
+        return real_dg(gy, w, spec, shape)
+    net.train_step(x, y)                                 # the first step moves the parameters into the flat buffer; from the
+    torch.cuda.synchronize()                             # second on the decoder's slice of it can leave early
+    dist.all_reduce, _ops.conv_dgrad_raw = logged_all_reduce, logged_dgrad
+    try:
+        eager_losses, _ = net.train_step(x, y)           # one eager data-parallel step (early bucket + remainder)
+    finally:
+        dist.all_reduce, _ops.conv_dgrad_raw = real_ar, real_dg
+    torch.cuda.synchronize()
+    kinds = [o[0] for o in order]
+    i_ar = kinds.index('allreduce')
+    from module.vae_layers.conv import HipConv2d, HipConvTranspose2d
+    n_dec = sum(isinstance(m, (HipConv2d, HipConvTranspose2d)) for m in net.imager.modules())
+    n_enc = sum(isinstance(m, (HipConv2d, HipConvTranspose2d)) for m in net.features.modules())
+    dec_elems = sum(p.numel() for m in (net.imager, net.decoder) for p in m.parameters())
+    first_enc = next(o for o in order[i_ar + 1:] if o[0] == 'dgrad')
+    overlap = {'n_allreduce': kinds.count('allreduce'), 'first_is_async': order[i_ar][2], 'early_elems': order[i_ar][1],
+               'dec_elems': dec_elems, 'dgrads_before': kinds[:i_ar].count('dgrad'), 'dgrads_after': kinds[i_ar:].count('dgrad'),
+               'n_dec': n_dec, 'n_enc': n_enc,
+               # device timeline: the point at which the bucket's gradients are complete (the collective's stream) against the
+               # start of the encoder's first dgrad on the main stream
+               'ms_bucket_ready_to_first_encoder_dgrad': order[i_ar][3].elapsed_time(first_enc[3]),
+               'later_allreduces_async': [o[2] for o in order[i_ar + 1:] if o[0] == 'allreduce']}
     first = float(eager_losses['total'].detach().mean())
     del eager_losses                                    # frees the eager autograd graph (its AccumulateGrad nodes are bound to the
     torch.cuda.synchronize()                            # default stream and must not survive into the capture)
@@ -119,7 +157,8 @@ def _graph_worker(rank, port, out_dir):
     del late
     eps_probe = torch.randn(4, device='cuda')           # the device generator was offset per rank: ranks draw different noise
     torch.save({'params': {k: v.detach().cpu() for k, v in net.state_dict().items()}, 'first': first, 'last': last,
-                'opt_step': net.optimizer._groups[0].step, 'eps_probe': eps_probe.cpu(), 'rmse': meas['rmse']},
+                'opt_step': net.optimizer._groups[0].step, 'eps_probe': eps_probe.cpu(), 'rmse': meas['rmse'],
+                'overlap': overlap},
                os.path.join(out_dir, f'g{rank}.pt'))
     dist.barrier()
     dist.destroy_process_group()
@@ -137,10 +176,18 @@ def test_graph_captured_data_parallel_step(tmp_path):
         if 'running_' in k or 'num_batches' in k:
             continue
         assert torch.equal(v, b['params'][k]), k
-    assert a['opt_step'] == b['opt_step'] == 1 + 1 + 6 + 1    # eager step + warm-up + replays + eager step after the graph
+    assert a['opt_step'] == b['opt_step'] == 2 + 1 + 6 + 1    # two eager steps + warm-up + replays + eager step after the graph
     assert a['last'] < a['first'] and b['last'] < b['first']
     assert not torch.equal(a['eps_probe'], b['eps_probe'])
     assert 0 < a['rmse'] < 10
+    # the eager data-parallel step: exactly two collectives - the decoder-side bucket, ASYNCHRONOUS, issued when every
+    # dgrad of the upsampler has been queued and none of the encoder's, and the contiguous remainder after backward
+    for r in (a, b):
+        ov = r['overlap']
+        assert ov['n_allreduce'] == 2 and ov['first_is_async'] and ov['later_allreduces_async'] == [False], ov
+        assert ov['dec_elems'] <= ov['early_elems'] <= ov['dec_elems'] + 64, ov      # + the 16-byte alignment gaps of the flat buffer
+        assert ov['dgrads_before'] == ov['n_dec'] and ov['dgrads_after'] == ov['n_enc'] - 1, ov    # the first layer has no dgrad
+        assert ov['ms_bucket_ready_to_first_encoder_dgrad'] >= 0., ov
 
 
 def _b8_worker(rank, port, out_dir):
