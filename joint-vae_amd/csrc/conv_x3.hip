@@ -88,10 +88,16 @@ struct X3P {
 //             (7 groups per K step: 12 pairs + tap 24 with an all-zero partner; pack_elems.h JVAE_PACK_X3S).  Same output tile
 //             per wave, same patch image, same LDS reads per MFMA cycle; 4 % more MFMA cycles (the empty half pair).  The chip
 //             holds a higher clock on this shape (MI355X_MICROARCH.md, DVFS give-back item 7).
+//             STRIDE 2 in this form (round 4; E1 / E3 forward, D2 / D4 dgrad of conv32 / deconv32): 64 output pixels per
+//             workgroup (one 16-pixel tile per wave), the patch columns stored DE-INTERLEAVED - even padded columns in the first
+//             WPH units of a row, odd ones in the second - so that the 16 pixels of a tile read 16 CONSECUTIVE units for every
+//             tap (2 units apart they would hit each bank twice): 11 rows x 40 units x 16 channels x 3 planes = 42 KB + 24 KB of
+//             weights, two workgroups per CU (the 32x32x16 form needed 73 + 30 KB: one per CU, slower than the fp32 kernel).
 template <int S, int OW, int MT, bool SH = false>
 struct X3Geom {
+    static constexpr bool DI = SH && S == 2;                   // de-interleaved patch columns
     static constexpr int OH = OW;
-    static constexpr int PIX = MT * 128;
+    static constexpr int PIX = DI ? 64 : MT * 128;
     static constexpr int OHW = OH * OW;
     static constexpr int NIMG = PIX >= OHW ? PIX / OHW : 1;
     static constexpr int TH = PIX >= OHW ? OH : PIX / OW;
@@ -99,18 +105,22 @@ struct X3Geom {
     static constexpr int WIN = OW * S;
     static constexpr int WP0 = (OW - 1) * S + 9;
     static constexpr int WP1 = WIN + 4;
-    static constexpr int WP = WP0 > WP1 ? WP0 : WP1;          // units per patch row
+    // DI: padded column pc = x + 4 sits in half pc & 1 at index pc >> 1; a tile reads indices c + 1 + (kw >> 1) <= OW + 2.  A
+    // 16-pixel tile of an 8-wide map spans two output rows = 2 * WP units apart: WP = 4 (mod 8) puts them on the other banks.
+    static constexpr int WPH = OW == 8 ? 14 : (OW + 3 + 3) / 4 * 4;
+    static constexpr int WP = DI ? 2 * WPH : (WP0 > WP1 ? WP0 : WP1);          // units per patch row
     static constexpr int CH = ROWS * WP;                       // units per 8-channel block per image
     static constexpr int XS = NIMG * 2 * CH;                   // patch units of one plane (16 channels)
     static constexpr int WGS = SH ? 2 * 3 * 4 * 32             // weight units of one group: 2 pairs x 3 planes x 4 lane groups
                                   : 3 * 5 * 2 * 32;            // ... of one kernel row (3 planes x 5 taps x 2 halves)
     static constexpr int GPK = SH ? 7 : 5;                     // weight groups per K step
     static constexpr int WROWS = SH ? JVAE_X3S_PAIRS * 12 : 150;   // 32-unit rows of packed weights per K step and 32 channels
+    static constexpr int NPT = SH ? PIX / 64 : MT;             // pixel tiles per wave (16 pixels each in the SH form, else 32)
     static constexpr int LDS_BYTES = (3 * XS + 2 * WGS) * 16;
 };
 
-template <bool SH, int MT> struct X3Acc { f32x16 t[MT]; };
-template <int MT> struct X3Acc<true, MT> { f32x4 t[2 * MT][2]; };       // [16-pixel tile][16-channel tile]
+template <bool SH, int NPT> struct X3Acc { f32x16 t[NPT]; };
+template <int NPT> struct X3Acc<true, NPT> { f32x4 t[NPT][2]; };        // [16-pixel tile][16-channel tile]
 
 template <int S, int OW, int MT, bool AFF, bool SH = false>
 __global__ __launch_bounds__(256, 2) void conv5_x3_kernel(X3P p) {
@@ -148,7 +158,7 @@ __global__ __launch_bounds__(256, 2) void conv5_x3_kernel(X3P p) {
         }
     // pixel tiles of this wave: MT groups of 32 pixels (32x32x16: the pixel on lane & 31, channel block `half`), or 2*MT tiles of 16
     // (16x16x32: the pixel on lane & 15, lane group kq = lane >> 4 = (tap of the pair, channel block))
-    constexpr int NPT = SH ? 2 * MT : MT, TPX = SH ? 16 : 32;
+    constexpr int NPT = G::NPT, TPX = SH ? 16 : 32;
     const int l15 = lane & 15, kq = lane >> 4;
     int pixoff[NPT];
 #pragma unroll
@@ -156,12 +166,15 @@ __global__ __launch_bounds__(256, 2) void conv5_x3_kernel(X3P p) {
         const int pix = (wave * NPT + mt) * TPX + (SH ? l15 : l31);
         const int im = pix / (G::TH * OW), rem = pix % (G::TH * OW);
         const int r = rem / OW, c = rem % OW;
-        pixoff[mt] = im * (2 * G::CH) + (SH ? (kq & 1) : half) * G::CH + (r * S) * G::WP + c * S + 4 - p.P;
+        if constexpr (G::DI)             // de-interleaved columns: tap kw of output column c is index c + 1 + (kw >> 1) of half kw & 1
+            pixoff[mt] = im * (2 * G::CH) + (kq & 1) * G::CH + (r * S) * G::WP + c;
+        else
+            pixoff[mt] = im * (2 * G::CH) + (SH ? (kq & 1) : half) * G::CH + (r * S) * G::WP + c * S + 4 - p.P;
     }
 
     // two accumulator sets: the three small partial products are summed apart from the three large ones (added in
     // the epilogue), which also doubles the distance between dependent MFMAs
-    X3Acc<SH, MT> accA, accS;
+    X3Acc<SH, NPT> accA, accS;
     auto& acc = accA.t;
     auto& acs = accS.t;
     if constexpr (SH) {
@@ -253,11 +266,13 @@ __global__ __launch_bounds__(256, 2) void conv5_x3_kernel(X3P p) {
                         s[j][0][ci] = a; s[j][1][ci] = b; s[j][2][ci] = c;
                     }
                 }
-                const int base = (im * 2 + h) * G::CH + lr * G::WP + 4 + 2 * xp;
+                // (DI: input column 2*xp + j is padded column 2*xp + 4 + j = index xp + 2 of half j)
+                const int base = (im * 2 + h) * G::CH + lr * G::WP + (G::DI ? xp + 2 : 4 + 2 * xp);
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) Xs[pl * G::XS + base + j] = __builtin_bit_cast(u32x4, s[j][pl]);
+                    for (int j = 0; j < 2; ++j)
+                        Xs[pl * G::XS + base + j * (G::DI ? G::WPH : 1)] = __builtin_bit_cast(u32x4, s[j][pl]);
             }
         }
     };
@@ -308,14 +323,19 @@ __global__ __launch_bounds__(256, 2) void conv5_x3_kernel(X3P p) {
     // the pair crosses a kernel row (taps 4|5, 14|15) - one row down and four units to the left; tap 25 does not exist (its
     // weights are zero): those lanes re-read tap 24 so that no value from outside the receptive field enters a 0 * x.
     auto computeSH = [&](int buf, int gi) {
-        constexpr int NH = SH ? MT : 1;                          // halves of 2 pixel tiles per pair
+        constexpr int TPH = NPT >= 2 ? 2 : 1;                    // pixel tiles per half
+        constexpr int NH = SH ? NPT / TPH : 1;                   // halves per pair
         const u32x4* Wb = Ws + buf * G::WGS + kq * 32 + l15;
         const int npair = gi == 6 ? 1 : 2;
-        u32x4 fa[2][3][2], fb[2][3][2];
-        auto offs = [&](int pq) {                                // LDS unit offset of this lane's tap of pair pq, without the pixel
-            const int ta = 4 * gi + 2 * pq, kh = ta / 5, kw = ta - 5 * kh;
-            const int second = ta == 24 ? 0 : (kw == 4 ? G::WP - 4 : 1);
-            return kh * G::WP + kw + (kq >> 1) * second;
+        u32x4 fa[2][3][2], fb[2][3][TPH];
+        auto tapoff = [&](int t) {                               // LDS unit offset of tap t relative to the lane's pixel
+            const int kh = t / 5, kw = t - 5 * kh;
+            return G::DI ? kh * G::WP + (kw & 1) * G::WPH + 1 + (kw >> 1) : kh * G::WP + kw;
+        };
+        auto offs = [&](int pq) {                                // ... of THIS lane's tap of pair pq (tap 25: tap 24 again)
+            const int ta = 4 * gi + 2 * pq;
+            const int oa = tapoff(ta), ob = ta == 24 ? oa : tapoff(ta + 1);
+            return (kq >> 1) ? ob : oa;
         };
         auto fragA = [&](int pq, u32x4 (&a)[3][2]) {
 #pragma unroll
@@ -323,11 +343,11 @@ __global__ __launch_bounds__(256, 2) void conv5_x3_kernel(X3P p) {
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct) a[pl][ct] = Wb[((pq * 3 + pl) * 4) * 32 + ct * 16];
         };
-        auto fragB = [&](int off, int hp, u32x4 (&b)[3][2]) {
+        auto fragB = [&](int off, int hp, u32x4 (&b)[3][TPH]) {
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) b[pl][j] = Xs[pl * G::XS + pixoff[(hp * 2 + j) % NPT] + off];
+                for (int j = 0; j < TPH; ++j) b[pl][j] = Xs[pl * G::XS + pixoff[(hp * TPH + j) % NPT] + off];
         };
         int off = offs(0);
         fragA(0, fa[0]);
@@ -338,25 +358,24 @@ __global__ __launch_bounds__(256, 2) void conv5_x3_kernel(X3P p) {
                 const int offn = pq + 1 < npair ? offs(pq + 1) : off;
 #pragma unroll
                 for (int hp = 0; hp < NH; ++hp) {
-                    constexpr int DUMMY = 0;
                     const int cur = (pq * NH + hp) & 1;
                     if (hp + 1 < NH) fragB(off, hp + 1, fb[cur ^ 1]);
                     else if (pq + 1 < npair) { fragA(pq + 1, fa[(pq + 1) & 1]); fragB(offn, 0, fb[cur ^ 1]); }
-                    __builtin_amdgcn_sched_barrier(DUMMY);
+                    __builtin_amdgcn_sched_barrier(0);
                     constexpr int WPL[6] = {0, 0, 2, 1, 1, 0}, XPL[6] = {2, 1, 0, 0, 1, 0};
 #pragma unroll
                     for (int t = 0; t < 6; ++t)
 #pragma unroll
-                        for (int j = 0; j < 2; ++j)
+                        for (int j = 0; j < TPH; ++j)
 #pragma unroll
                             for (int ct = 0; ct < 2; ++ct) {
                                 if constexpr (SH) {
-                                    f32x4& d = (t & 1) ? acc[hp * 2 + j][ct] : acs[hp * 2 + j][ct];
+                                    f32x4& d = (t & 1) ? acc[hp * TPH + j][ct] : acs[hp * TPH + j][ct];
                                     d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[pq & 1][WPL[t]][ct]),
                                                                                 __builtin_bit_cast(bf16x8, fb[cur][XPL[t]][j]), d, 0, 0, 0);
                                 }
                             }
-                    __builtin_amdgcn_sched_barrier(DUMMY);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
                 off = offn;
             }
@@ -373,7 +392,9 @@ __global__ __launch_bounds__(256, 2) void conv5_x3_kernel(X3P p) {
     // every other cell - out-of-image rows, missing images and channels included - is rewritten by lstoreX at every K step.
     // Issued behind the first global loads (they fly meanwhile).  Round 4: the whole 46 KB image used to be cleared, in front
     // of the loads: 2 200 of a workgroup's 73 500 cycles (tools/x3_stamps.py).
-    {
+    if constexpr (G::DI) {
+        for (int i = tid; i < 3 * G::XS; i += 256) Xs[i] = u32x4{0u, 0u, 0u, 0u};     // (de-interleaved image: all of it)
+    } else {
         constexpr int HALO = G::WP - G::WIN, NROW = 3 * G::NIMG * 2 * G::ROWS;
         for (int i = tid; i < NROW * HALO; i += 256) {
             const int r = i / HALO, c = i % HALO;
@@ -622,14 +643,19 @@ bool jvae_conv5_x3_ok(int Cin, int H, int W, int Cout, int OH, int OW, int S, in
     if (!g_x3) return false;
     if (Cin < 16 || Cin > 256) return false;
     if (S == 2) {
-        // Stride-2 forward-type layers (E1 / E3 forward, D2 / D4 dgrad of conv32 / deconv32): the patch of 128 output pixels is
-        // 19 rows x 39 columns x 16 channels x 3 planes = 71-84 KB, + 30 KB of weights: ONE workgroup (4 waves) per CU instead
-        // of two.  MEASURED SLOWER than the fp32 matrix-core kernel (round 3, one box: E1 forward 96.7 vs 70.7 us, E3 84.0 vs
-        // 71.3, D2 dgrad 118.8 vs 113.6, D4 dgrad 126.4 vs 113.1; the step 4.00 vs 3.84 ms): with one workgroup per CU nothing
-        // runs under its staging phases.  OFF by default; JVAE_X3_S2=1 selects it (A/B switch).
+        // Stride-2 forward-type layers (E1 / E3 forward, D2 / D4 dgrad of conv32 / deconv32) stay on the fp32 matrix-core kernel:
+        // both split-bf16 forms were built and measured SLOWER.  Round 3, 32x32x16 form (128-pixel tile, 73 KB patch + 30 KB
+        // weights, ONE workgroup per CU): E1 forward 96.7 vs 70.7 us, the step 4.00 vs 3.84 ms.  Round 4, 16x16x32 form on a
+        // de-interleaved 64-pixel patch, two workgroups per CU (X3Geom::DI; parity-green, tests/test_0_ops_gpu.py with
+        // JVAE_X3_S2=1): E1 forward 95.7 vs 70.9 us, E3 forward 85.8 vs 70.7, D2 dgrad 134 vs 117, D4 dgrad 133 vs 112
+        // (profiles/r04_conv_s2_x3_ab.txt).  With one 16-pixel tile per wave a weight group (2 tap pairs) feeds only 24 MFMAs
+        // = 384 matrix-pipe cycles per wave between two barriers - a quarter of the stride-1 kernel's - against ~650 cycles of
+        // weight store + load issue + barrier per group (tools/x3_stamps.py), and 9 ds_read_b128 per 12 MFMAs keep the LDS 75 %
+        // busy.  More pixels per workgroup need the 73 KB patch again, more channels 48 KB of weights: neither fits two
+        // workgroups per CU.  JVAE_X3_S2=1 selects the round-4 form (A/B switch).
         static int s2 = -1;
         if (s2 < 0) { const char* e = getenv("JVAE_X3_S2"); s2 = (e && e[0] == '1') ? 1 : 0; }
-        if (!s2 || (OW != 8 && OW != 16)) return false;
+        if (!s2 || !x3_sh16() || P != 2 || (OW != 8 && OW != 16 && OW != 32)) return false;
         return jvae_conv5_fwd_ok(Cin, H, W, Cout, OH, OW, S, P);
     }
     if (S != 1) return false;
@@ -655,7 +681,7 @@ int jvae_conv5_x3_fwd(const float* in, const float* w, int swap, int flip, const
                       int N, int Cin, int H, int W, int Cout, int OW, int S, int P, float* ws, hipStream_t st,
                       float* stats, int* nsplit, const InAff* aff) {
     const int OP = (Cout + 31) / 32 * 32;
-    const bool sh = S == 1 && OW <= 32 && x3_sh16();        // 64-wide maps (config 5 in fp32) keep the 32x32x16 form
+    const bool sh = (S == 2 || OW <= 32) && x3_sh16();      // 64-wide stride-1 maps (config 5 in fp32) keep the 32x32x16 form
     {   // split weights: the step's cache slot (refreshed once per step, pack_cache.hip) or this call's workspace
         bool fresh = true;
         const int kind = sh ? JVAE_PACK_X3S : JVAE_PACK_X3;
@@ -673,8 +699,9 @@ int jvae_conv5_x3_fwd(const float* in, const float* w, int swap, int flip, const
     struct Fin { int* n; ~Fin() { if (n) *n = g_x3_splits; } } fin{nsplit};
     if (S == 2) {
         switch (OW) {
-            case 8: return launch_x3<2, 8, 1>(p, st);
-            case 16: return launch_x3<2, 16, 1>(p, st);
+            case 8: return launch_x3<2, 8, 1, true>(p, st);
+            case 16: return launch_x3<2, 16, 1, true>(p, st);
+            case 32: return launch_x3<2, 32, 1, true>(p, st);
         }
         return JVAE_ENOTSUP;
     }
