@@ -20,7 +20,12 @@
 //   MODE 0 (S = 1, Cb >= 9): tile = 32 channels b x 1 tap   -> 25 tiles (wave w: taps w, w+4, ...)
 //   MODE 2 (S = 2, Cb >= 9): tile = 16 channels b x 2 taps  -> 13 tiles (the stride-2 patch is 4x the pixels: 16 channels
 //                                                              keep two workgroups per CU)
-//   MODE 1 (Cb <= 8):        tile = 8 channels b x 4 taps   ->  7 tiles (3-channel image side of the first / last layer)
+//   MODE 1 (4 < Cb <= 8):    tile = 8 channels b x 4 taps   ->  7 tiles
+//   MODE 3 (Cb <= 4):        tile = 4 channels b x 8 taps   ->  4 tiles, one per wave (3-channel image side of the first / last
+//                            layer; round 4).  The transposing read takes 8 bytes = 4 channels per lane at the lane's OWN address,
+//                            so a 16-column block is four taps' first half units (the 16-byte units hold 8 channels, the upper
+//                            four are padding that is simply never read): 75 real columns in 4 x 32 instead of 7 x 32 - the
+//                            MFMA work of these layers falls by 3/7 (it was two thirds padding).
 // The A fragments (3 planes x 2 transposed reads per 16 pixels) are shared by all tiles of a wave; every tile needs its
 // own B fragments.  Accumulators stay in registers over the whole image loop; each workgroup writes one fp32 slab,
 // reduced in a fixed order by jvae_wgrad_slab_reduce (deterministic, no float atomics).
@@ -67,7 +72,7 @@ struct WgX3Geom {
     static constexpr int NCBQ = MODE == 0 ? 4 : (MODE == 2 ? 2 : 1);   // 8-channel blocks of Q staged per item
     static constexpr int QS = NCBQ * CH;                       // units per plane
     static constexpr int PS = 4 * TPIX;                        // units per plane (32 channels a): [pixel][block]
-    static constexpr int NTILE = MODE == 0 ? 25 : (MODE == 2 ? 13 : 7);
+    static constexpr int NTILE = MODE == 0 ? 25 : (MODE == 2 ? 13 : (MODE == 3 ? 4 : 7));
     static constexpr int NBT = (NTILE + 3) / 4;                // per wave
     static constexpr int LDS_BYTES = NPL * (QS + PS) * 16;
     static constexpr int QITEMS = NCBQ * ROWS * (WB / 2);      // staging items: 2 pixels x 8 channels
@@ -144,10 +149,10 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_x3_kernel(WgX3P p) {
 #pragma unroll
     for (int t = 0; t < G::NBT; ++t) {
         const int tile = wave + 4 * t;
-        int tap, cbl;
-        const int sub = pp & 1;
+        int tap, cbl, sub = pp & 1;
         if (MODE == 0) { tap = tile; cbl = cg * 2 + (pp >> 1); }
         else if (MODE == 2) { tap = tile * 2 + cg; cbl = pp >> 1; }
+        else if (MODE == 3) { tap = tile * 8 + cg * 4 + pp; cbl = 0; sub = 0; }
         else { tap = tile * 4 + cg * 2 + (pp >> 1); cbl = 0; }
         if (tap > 24) tap = 24;                                // unused slots: any valid address
         const int kw = tap % 5;
@@ -170,8 +175,10 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_x3_kernel(WgX3P p) {
             for (int cb = 0; cb < (MODE == 0 ? 1 : 2); ++cb) {
                 const int tile = wave + 4 * t;
                 int tap, blk;
+                int sub16 = pp & 1;
                 if (MODE == 0) { tap = tile; blk = cb * 2 + (pp >> 1); }
                 else if (MODE == 2) { tap = tile * 2 + cb; blk = pp >> 1; }
+                else if (MODE == 3) { tap = tile * 8 + cb * 4 + pp; blk = 0; sub16 = 0; }
                 else { tap = tile * 4 + cb * 2 + (pp >> 1); blk = 0; }
                 if (tap > 24) tap = 24;
                 const int kw = tap % 5;
@@ -179,9 +186,9 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_x3_kernel(WgX3P p) {
                 const int slot = lane_pix16 + (tap / 5) * G::WPS + tslot;
                 if (SWZ) {
                     const int bit = ((pl16 % WS) + kw) >> 3 & 1;       // bit 3 of the padded column (both reads of the lane)
-                    boff16[t][cb] = (slot * G::NCBQ + (blk ^ (bit << 1))) * 16 + (pp & 1) * 8;
+                    boff16[t][cb] = (slot * G::NCBQ + (blk ^ (bit << 1))) * 16 + sub16 * 8;
                 } else {
-                    boff16[t][cb] = (slot * G::NCBQ + blk) * 16 + (pp & 1) * 8;
+                    boff16[t][cb] = (slot * G::NCBQ + blk) * 16 + sub16 * 8;
                 }
             }
     }
@@ -471,6 +478,7 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_x3_kernel(WgX3P p) {
                 int b, tap;
                 if (MODE == 0) { b = cbq0 * 8 + j; tap = tile; }
                 else if (MODE == 2) { b = cbq0 * 8 + c16; tap = tile * 2 + cb; }
+                else if (MODE == 3) { b = j & 3; tap = tile * 8 + (j >> 2); }
                 else { b = j & 7; tap = tile * 4 + (j >> 3); }
                 if (b >= p.Cb || tap > 24) continue;
 #pragma unroll
@@ -491,6 +499,7 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_x3_kernel(WgX3P p) {
         int b, tap;
         if (MODE == 0) { b = cbq0 * 8 + l31; tap = tile; }
         else if (MODE == 2) { b = cbq0 * 8 + (l31 & 15); tap = tile * 2 + (l31 >> 4); }
+        else if (MODE == 3) { b = l31 & 3; tap = tile * 8 + (l31 >> 2); }
         else { b = l31 & 7; tap = tile * 4 + (l31 >> 3); }
         if (b >= p.Cb || tap > 24) continue;
 #pragma unroll
@@ -506,7 +515,7 @@ int launch_wgx3(const WgX3P& p, hipStream_t st) {
     using G = WgX3Geom<S, WS, MODE, NPL>;
     static_assert(G::LDS_BYTES + 2048 <= 80 * 1024, "two workgroups per CU must fit the 160 KB LDS");
     dim3 grid(p.G, (p.Ca + 31) / 32, (p.Cb + 8 * G::NCBQ - 1) / (8 * G::NCBQ));
-    if (MODE == 1) grid.z = 1;
+    if (MODE == 1 || MODE == 3) grid.z = 1;
     const bool aff = p.aff_p.sc || p.aff_q.sc;
     if constexpr (NPL == 1) {
         static bool attr1 = false;
@@ -550,11 +559,16 @@ int launch_wgx3(const WgX3P& p, hipStream_t st) {
     }
 }
 
-inline int x3_mode(int S, int Cb) { return Cb <= 8 ? 1 : (S == 2 ? 2 : 0); }
+// JVAE_WGRAD_M3=0: the 3-channel layers on the 8-channel x 4-tap tiles of MODE 1 (A/B switch)
+inline int x3_mode(int S, int Cb) {
+    static int m3 = -1;
+    if (m3 < 0) { const char* e = getenv("JVAE_WGRAD_M3"); m3 = (e && e[0] == '0') ? 0 : 1; }
+    return Cb <= 4 && m3 ? 3 : (Cb <= 8 ? 1 : (S == 2 ? 2 : 0));
+}
 
 int slab_count_x3(int N, int Ca, int Cb, int S) {
     const int mode = x3_mode(S, Cb);
-    const int gz = mode == 1 ? 1 : (mode == 2 ? (Cb + 15) / 16 : (Cb + 31) / 32);
+    const int gz = (mode == 1 || mode == 3) ? 1 : (mode == 2 ? (Cb + 15) / 16 : (Cb + 31) / 32);
     const int per = ((Ca + 31) / 32) * gz;
     int target = 512 / per;                       // ~512 workgroups in total (2 per CU), equal image counts per slab
     if (target < 1) target = 1;
@@ -589,7 +603,11 @@ int jvae_conv5_wgrad_x3(const float* ps, const float* q, float* dw, int accumula
     int rc = JVAE_ENOTSUP;
     const int mode = x3_mode(S, Cb);
 #define WGX3_CASE(S_, WS_, M_) case WS_: rc = launch_wgx3<S_, WS_, M_>(p, st); break;
-    if (mode == 1 && S == 1) {
+    if (mode == 3 && S == 1) {
+        switch (WS) { WGX3_CASE(1, 8, 3) WGX3_CASE(1, 16, 3) WGX3_CASE(1, 32, 3) }
+    } else if (mode == 3) {
+        switch (WS) { WGX3_CASE(2, 8, 3) WGX3_CASE(2, 16, 3) WGX3_CASE(2, 32, 3) }
+    } else if (mode == 1 && S == 1) {
         switch (WS) { WGX3_CASE(1, 8, 1) WGX3_CASE(1, 16, 1) WGX3_CASE(1, 32, 1) }
     } else if (mode == 1) {
         switch (WS) { WGX3_CASE(2, 8, 1) WGX3_CASE(2, 16, 1) WGX3_CASE(2, 32, 1) }
@@ -626,7 +644,11 @@ int jvae_conv5_wgrad_b8x(const void* ps, const void* q, float* dw, int accumulat
     int rc = JVAE_ENOTSUP;
     const int mode = x3_mode(S, Cb);
 #define WGB8X_CASE(S_, WS_, M_) case WS_: rc = launch_wgx3<S_, WS_, M_, 1>(p, st); break;
-    if (mode == 1 && S == 1) {
+    if (mode == 3 && S == 1) {
+        switch (WS) { WGB8X_CASE(1, 8, 3) WGB8X_CASE(1, 16, 3) WGB8X_CASE(1, 32, 3) WGB8X_CASE(1, 64, 3) }
+    } else if (mode == 3) {
+        switch (WS) { WGB8X_CASE(2, 8, 3) WGB8X_CASE(2, 16, 3) WGB8X_CASE(2, 32, 3) }
+    } else if (mode == 1 && S == 1) {
         switch (WS) { WGB8X_CASE(1, 8, 1) WGB8X_CASE(1, 16, 1) WGB8X_CASE(1, 32, 1) WGB8X_CASE(1, 64, 1) }
     } else if (mode == 1) {
         switch (WS) { WGB8X_CASE(2, 8, 1) WGB8X_CASE(2, 16, 1) WGB8X_CASE(2, 32, 1) }
