@@ -51,6 +51,11 @@ bool jvae_conv5_smallco_ok(int Cin, int H, int W, int Cout, int KH, int KW, int 
 int jvae_conv5_smallco(const float* in, const float* w, const float* bias, float* out, int N, int Cin, int W, int Cout,
                        hipStream_t st, const InAff* aff = nullptr);
 
+// ... and with <= 4 INPUT channels (forward-type operator, any weight role: the first layer's forward, the head's dgrad)
+bool jvae_conv5_smallci_ok(int Cin, int H, int W, int Cout, int OW, int S, int P);
+int jvae_conv5_smallci(const float* in, const float* w, int swap, int flip, const float* bias, float* out,
+                       int N, int Cin, int W, int Cout, float* ws, hipStream_t st, float* stats = nullptr, int* nsplit = nullptr);
+
 // conv_wgrad_mfma.hip: dW[a][b][tap] = sum Ps[n][a][u][v] Q[n][b][u*S+kh-P][v*S+kw-P]
 bool jvae_conv5_wgrad_ok(int Ca, int HS, int WS, int Cb, int HB, int WB, int S, int P);
 size_t jvae_conv5_wgrad_ws_floats(int N, int Ca, int Cb, int S, int WS);

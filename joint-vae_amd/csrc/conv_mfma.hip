@@ -326,6 +326,8 @@ int jvae_conv5_fwd(const float* in, const float* w, int swap, int flip, const fl
                    float* stats, int* nsplit, const InAff* aff) {
     if (jvae_conv5_x3_ok(Cin, H, W, Cout, OW, OW, S, P))      // stride-1 layers with >= 16 input channels: conv_x3.hip
         return jvae_conv5_x3_fwd(in, w, swap, flip, bias, out, N, Cin, H, W, Cout, OW, S, P, ws, st, stats, nsplit, aff);
+    if (!aff && jvae_conv5_smallci_ok(Cin, H, W, Cout, OW, S, P))     // <= 4 input channels: vector ALUs (conv_smallco.hip)
+        return jvae_conv5_smallci(in, w, swap, flip, bias, out, N, Cin, W, Cout, ws, st, stats, nsplit);
     {   // packed weights: the step's cache slot (refreshed once per step, pack_cache.hip) or this call's workspace
         bool fresh = true;
         float* slot = (float*)jvae_pack_cache_get(JVAE_PACK_F32, w, Cin, Cout, swap, flip, &fresh);

@@ -11,6 +11,7 @@
 #include "common.h"
 #include "jvae_internal.h"
 #include "conv_dispatch.h"
+#include "pack_elems.h"
 
 namespace {
 
@@ -241,6 +242,124 @@ __global__ __launch_bounds__(256, 4) void conv5_smallco2_kernel(SmP p) {
     }
 }
 
+
+// ---- the mirror case: a handful of INPUT channels, many output channels (round 4) ---------------------------------------------------
+// First layer of conv32 (3 -> 32, forward with BatchNorm sums) and the dgrad of the image head (3 -> 32 with swapped / flipped
+// weights).  K = 3 x 25 = 75 is a poor fit for the matrix cores - the fp32 MFMA kernel pads it to 100 and reached 46-66 TFLOP/s - so
+// this is the same register-blocked direct convolution as above with the roles of the channel counts exchanged: one thread owns 4
+// adjacent pixels x 8 output channels (32 accumulators), a 256-thread workgroup 1024 pixels x 8 channels (blockIdx.y = the
+// channel group: the 3-channel patch is small enough to be staged by each of the four groups), weights are wave-uniform scalar
+// operands (s_load from the raw weight tensor, whatever its layout: swap / flip are index arithmetic).  Per (input channel, kernel
+// row): 3 ds_read_b128, 40 scalar loads, 160 FMAs.
+struct SciP {
+    const float* in;     // (N, CI, H, W)
+    const float* wp;     // packed weights [o / 8][c][tap][o % 8] (pack_elems.h JVAE_PACK_SCI; swap / flip resolved by the pack)
+    const float* bias;   // (Cout) or null
+    float* out;          // (N, Cout, H, W)
+    float* stats;        // optional (Cout, gridDim.x, 2): sums of (y - bias), (y - bias)^2 over this workgroup's pixels
+    int N, Cout;
+};
+
+__global__ __launch_bounds__(256) void sci_wpack_kernel(const float* __restrict__ w, float* __restrict__ wp, int C, int O, long total,
+                                                        int swap, int flip) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
+        jvae_pack_sci_elem(w, wp, i, C, O, swap, flip);
+}
+
+template <int OW, int CI>
+__global__ __launch_bounds__(256, 4) void conv5_smallci_kernel(SciP p) {
+    constexpr int OH = OW, OC = 8, GPW = 2;
+    constexpr int TH = 1024 / OW;                  // rows per workgroup
+    constexpr int ROWS = TH + 4;
+    constexpr int WP = OW + 8;                     // data at col 4 (16-byte aligned), halo 2 each side
+    constexpr int CH = ROWS * WP;
+    __shared__ __attribute__((aligned(16))) float Xs[CI * CH];
+    __shared__ float red[4][2 * OC];
+
+    const int tid = threadIdx.x;
+    constexpr int TPI = OH / TH;
+    const int n = blockIdx.x / TPI, row0 = (blockIdx.x % TPI) * TH;
+    constexpr int XQ = OW / 4;
+    const int r = tid / XQ, xq = tid % XQ;
+
+    // stage the patch (zeros outside the image: rows AND halo columns)
+    constexpr int UNITS = CI * ROWS * (WP / 4);
+    for (int u = tid; u < UNITS; u += 256) {
+        const int x4 = u % (WP / 4);
+        const int t = u / (WP / 4);
+        const int lr = t % ROWS, c = t / ROWS;
+        const int ir = row0 - 2 + lr;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (x4 >= 1 && x4 <= XQ && ir >= 0 && ir < OH)
+            v = *reinterpret_cast<const f32x4*>(p.in + (((long)n * CI + c) * OH + ir) * OW + (x4 - 1) * 4);
+        *reinterpret_cast<f32x4*>(&Xs[c * CH + lr * WP + x4 * 4]) = v;
+    }
+    __syncthreads();
+
+    // GPW channel groups per workgroup, one after the other on the same staged patch (halves the per-workgroup fixed cost)
+#pragma unroll 1
+    for (int gg = 0; gg < GPW; ++gg) {
+    const int o0 = (blockIdx.y * GPW + gg) * OC;
+    if (o0 >= p.Cout) break;                       // uniform
+    float acc[OC][4];
+#pragma unroll
+    for (int o = 0; o < OC; ++o)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[o][j] = 0.f;
+
+    typedef const __attribute__((address_space(4))) float* const_f32_p;      // uniform loads from it are scalar loads
+    const const_f32_p wg = (const_f32_p)(unsigned long long)p.wp + (long)(blockIdx.y * GPW + gg) * (CI * 25 * OC);
+    // NOT unrolled over (channel, kernel row): unrolled, the compiler hoists all 600 scalar loads to the top and spills SGPRs
+#pragma unroll 1
+    for (int c = 0; c < CI; ++c) {
+#pragma unroll 1
+        for (int kh = 0; kh < 5; ++kh) {
+            const float* row = &Xs[c * CH + (r + kh) * WP + 4 * xq];
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(row);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(row + 4);
+            const f32x4 v2 = *reinterpret_cast<const f32x4*>(row + 8);
+            const float in12[12] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3], v2[0], v2[1], v2[2], v2[3]};
+            float wv[5][OC];                                   // 40 consecutive floats: five s_load_dwordx8
+#pragma unroll
+            for (int kw = 0; kw < 5; ++kw)
+#pragma unroll
+                for (int o = 0; o < OC; ++o) wv[kw][o] = wg[((c * 5 + kh) * 5 + kw) * OC + o];
+#pragma unroll
+            for (int kw = 0; kw < 5; ++kw)
+#pragma unroll
+                for (int o = 0; o < OC; ++o)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[o][j] = fmaf(wv[kw][o], in12[j + kw + 2], acc[o][j]);
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < OC; ++o) {
+        if (o0 + o >= p.Cout) continue;
+        const float b = p.bias ? p.bias[o0 + o] : 0.f;
+        f32x4 v = {acc[o][0] + b, acc[o][1] + b, acc[o][2] + b, acc[o][3] + b};
+        *reinterpret_cast<f32x4*>(p.out + (((long)n * p.Cout + o0 + o) * OH + row0 + r) * OW + 4 * xq) = v;
+    }
+    if (p.stats) {          // BatchNorm partial sums of this workgroup's tile (pivot = bias), fixed order
+        const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+        for (int o = 0; o < OC; ++o) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { s1 += acc[o][j]; s2 += acc[o][j] * acc[o][j]; }
+            s1 = wave_sum(s1);
+            s2 = wave_sum(s2);
+            if (lane == 0) { red[wave][2 * o] = s1; red[wave][2 * o + 1] = s2; }
+        }
+        __syncthreads();
+        if (tid < 2 * OC && o0 + (tid >> 1) < p.Cout) {
+            const float t = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+            p.stats[((long)(o0 + (tid >> 1)) * gridDim.x + blockIdx.x) * 2 + (tid & 1)] = t;
+        }
+    }
+        if (p.stats) __syncthreads();              // `red` is reused by the next group
+    }
+}
+
 template <int OW>
 int launch_sm(const SmP& p, int CO, hipStream_t st) {
     dim3 grid((unsigned)(p.N * (OW * OW / 1024)));
@@ -281,4 +400,37 @@ int jvae_conv5_smallco(const float* in, const float* w, const float* bias, float
     if (W == 32) return launch_sm<32>(p, Cout, st);
     if (W == 64) return launch_sm<64>(p, Cout, st);
     return JVAE_ENOTSUP;
+}
+
+// Forward-type 5x5 stride-1 'same' convolution with <= 4 input channels (conv_mfma.hip hands these over): swap / flip as there.
+bool jvae_conv5_smallci_ok(int Cin, int H, int W, int Cout, int OW, int S, int P) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("JVAE_SMALLCI"); on = (e && e[0] == '0') ? 0 : 1; }      // A/B switch
+    return on && Cin >= 1 && Cin <= 4 && Cout >= 8 && S == 1 && P == 2 && H == W && OW == W && (W == 32 || W == 64);
+}
+
+int jvae_conv5_smallci(const float* in, const float* w, int swap, int flip, const float* bias, float* out,
+                       int N, int Cin, int W, int Cout, float* ws, hipStream_t st, float* stats, int* nsplit) {
+    {   // packed weights: the step's cache slot (refreshed once per step, pack_cache.hip) or this call's workspace
+        bool fresh = true;
+        float* slot = (float*)jvae_pack_cache_get(JVAE_PACK_SCI, w, Cin, Cout, swap, flip, &fresh);
+        if (slot) ws = slot;
+        if (!slot || !fresh) {
+            const long total = jvae_pack_elems(JVAE_PACK_SCI, Cin, Cout);
+            hipLaunchKernelGGL(sci_wpack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, ws, Cin, Cout, total, swap, flip);
+            JVAE_LAUNCH_CHECK();
+        }
+    }
+    SciP p{in, ws, bias, out, stats, N, Cout};
+    dim3 grid((unsigned)(N * (W * W / 1024)), (unsigned)((Cout + 15) / 16));      // 2 channel groups of 8 per workgroup
+    if (nsplit) *nsplit = stats ? (int)grid.x : 0;
+#define SCI_CASE(W_, C_) hipLaunchKernelGGL((conv5_smallci_kernel<W_, C_>), grid, dim3(256), 0, st, p); break;
+    if (W == 32) {
+        switch (Cin) { case 1: SCI_CASE(32, 1) case 2: SCI_CASE(32, 2) case 3: SCI_CASE(32, 3) case 4: SCI_CASE(32, 4) }
+    } else {
+        switch (Cin) { case 1: SCI_CASE(64, 1) case 2: SCI_CASE(64, 2) case 3: SCI_CASE(64, 3) case 4: SCI_CASE(64, 4) }
+    }
+#undef SCI_CASE
+    JVAE_LAUNCH_CHECK();
+    return 0;
 }

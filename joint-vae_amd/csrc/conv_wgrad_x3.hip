@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_x3_kernel(WgX3P p) {
                 int tap, blk;
                 int sub16 = pp & 1;
                 if (MODE == 0) { tap = tile; blk = cb * 2 + (pp >> 1); }
-                else if (MODE == 2) { tap = tile * 2 + cb; blk = pp >> 1; }
+                else if (MODE == 2) { tap = wave + 4 * (2 * t + cb); blk = pp >> 1; }     // 16-column blocks dealt tap by tap (below)
                 else if (MODE == 3) { tap = tile * 8 + cb * 4 + pp; blk = 0; sub16 = 0; }
                 else { tap = tile * 4 + cb * 2 + (pp >> 1); blk = 0; }
                 if (tap > 24) tap = 24;
@@ -411,7 +411,9 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_x3_kernel(WgX3P p) {
                     if (slot + 1 < NSLOT) read_b(ks, slot + 1, b[cur ^ 1]);
                     else if (ks + 1 < KS) read_b(ks + 1, 0, b[cur ^ 1]);
                     __builtin_amdgcn_sched_barrier(0);
-                    if (wave + 4 * t < G::NTILE) {                                 // wave-uniform
+                    // MODE 2 (16 channels x 1 tap per 16-column block): the 25 taps are dealt to the waves block by block - tap
+                    // = wave + 4 * slot: 7 / 6 / 6 / 6 blocks - instead of as 13 tiles of two taps (8 / 6 / 6 / 6 with the empty tap 25)
+                    if (MODE == 2 ? wave + 4 * slot <= 24 : wave + 4 * t < G::NTILE) {         // wave-uniform
                         constexpr int NPROD = NPL == 3 ? 6 : 1;        // one-plane form: the product itself
                         constexpr int APL[6] = {0, 2, 1, 0, 1, 0}, BPL[6] = {2, 0, 1, 1, 0, 0};
 #pragma unroll
@@ -471,13 +473,13 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_x3_kernel(WgX3P p) {
 #pragma unroll
         for (int t = 0; t < G::NBT; ++t) {
             const int tile = wave + 4 * t;
-            if (tile >= G::NTILE) continue;
+            if (MODE != 2 && tile >= G::NTILE) continue;
 #pragma unroll
             for (int cb = 0; cb < 2; ++cb) {
                 const int j = cb * 16 + c16;
                 int b, tap;
                 if (MODE == 0) { b = cbq0 * 8 + j; tap = tile; }
-                else if (MODE == 2) { b = cbq0 * 8 + c16; tap = tile * 2 + cb; }
+                else if (MODE == 2) { b = cbq0 * 8 + c16; tap = wave + 4 * (2 * t + cb); }
                 else if (MODE == 3) { b = j & 3; tap = tile * 8 + (j >> 2); }
                 else { b = j & 7; tap = tile * 4 + (j >> 3); }
                 if (b >= p.Cb || tap > 24) continue;

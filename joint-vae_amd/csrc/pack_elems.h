@@ -5,7 +5,7 @@
 #include "common.h"
 #include "conv_x3.h"
 
-enum JvaePackKind { JVAE_PACK_F32 = 0, JVAE_PACK_X3 = 1, JVAE_PACK_B8 = 2, JVAE_PACK_X3S = 3 };
+enum JvaePackKind { JVAE_PACK_F32 = 0, JVAE_PACK_X3 = 1, JVAE_PACK_B8 = 2, JVAE_PACK_X3S = 3, JVAE_PACK_SCI = 4 };
 
 // tap pairs per K step of the 16x16x32 split-bf16 layout: 25 taps = 12 pairs + tap 24 with an all-zero partner, + one all-zero
 // pair so that every staging group of the kernel (2 pairs) is complete
@@ -17,12 +17,13 @@ __host__ __device__ __forceinline__ int jvae_pack_op(int O) { return (O + 31) / 
 __host__ __device__ __forceinline__ long jvae_pack_elems(int kind, int C, int O) {
     const int OP = jvae_pack_op(O);
     if (kind == JVAE_PACK_F32) return (long)C * 25 * OP;
+    if (kind == JVAE_PACK_SCI) return (long)((O + 7) / 8) * C * 25 * 8;
     if (kind == JVAE_PACK_X3S) return (long)((C + 15) / 16) * JVAE_X3S_PAIRS * 4 * OP * 8;
     return (long)((C + 15) / 16) * 25 * 2 * OP * 8;
 }
 __host__ __device__ __forceinline__ size_t jvae_pack_bytes(int kind, int C, int O) {
     const long n = jvae_pack_elems(kind, C, O);
-    return (size_t)n * (kind == JVAE_PACK_F32 ? 4 : ((kind == JVAE_PACK_X3 || kind == JVAE_PACK_X3S) ? 6 : 2));
+    return (size_t)n * ((kind == JVAE_PACK_F32 || kind == JVAE_PACK_SCI) ? 4 : ((kind == JVAE_PACK_X3 || kind == JVAE_PACK_X3S) ? 6 : 2));
 }
 
 __device__ __forceinline__ float jvae_pack_src(const float* __restrict__ w, int C, int O, int c, int o, int tap, int swap, int flip) {
@@ -37,6 +38,17 @@ __device__ __forceinline__ void jvae_pack_f32_elem(const float* __restrict__ w, 
     const int OP = jvae_pack_op(O);
     const int o = (int)(i % OP), tap = (int)((i / OP) % 25), c = (int)(i / ((long)OP * 25));
     wp[i] = jvae_pack_src(w, C, O, c, o, tap, swap, flip);
+}
+
+// fp32 operand of conv_smallco.hip's few-input-channel kernel: Wp[o / 8][c][tap][o % 8] (the 40 weights of one (channel, kernel
+// row) and channel group are 160 contiguous bytes: five s_load_dwordx8), zero for o >= O
+__device__ __forceinline__ void jvae_pack_sci_elem(const float* __restrict__ w, float* __restrict__ wp, long i,
+                                                   int C, int O, int swap, int flip) {
+    const int o8 = (int)(i % 8);
+    long t = i / 8;
+    const int tap = (int)(t % 25); t /= 25;
+    const int c = (int)(t % C), g = (int)(t / C);
+    wp[i] = jvae_pack_src(w, C, O, c, g * 8 + o8, tap, swap, flip);
 }
 
 // i -> (kb, tap, half, o, ci) of the 16-byte-unit layouts (8 channels of one (tap, o) per unit)
