@@ -52,7 +52,7 @@ int jvae_conv5_smallco(const float* in, const float* w, const float* bias, float
                        hipStream_t st, const InAff* aff = nullptr);
 
 // ... and with <= 4 INPUT channels (forward-type operator, any weight role: the first layer's forward, the head's dgrad)
-bool jvae_conv5_smallci_ok(int Cin, int H, int W, int Cout, int OW, int S, int P);
+bool jvae_conv5_smallci_ok(int Cin, int H, int W, int Cout, int OW, int S, int P, bool dgrad_role);
 int jvae_conv5_smallci(const float* in, const float* w, int swap, int flip, const float* bias, float* out,
                        int N, int Cin, int W, int Cout, float* ws, hipStream_t st, float* stats = nullptr, int* nsplit = nullptr);
 

@@ -403,10 +403,11 @@ int jvae_conv5_smallco(const float* in, const float* w, const float* bias, float
 }
 
 // Forward-type 5x5 stride-1 'same' convolution with <= 4 input channels (conv_mfma.hip hands these over): swap / flip as there.
-bool jvae_conv5_smallci_ok(int Cin, int H, int W, int Cout, int OW, int S, int P) {
+bool jvae_conv5_smallci_ok(int Cin, int H, int W, int Cout, int OW, int S, int P, bool dgrad_role) {
     static int on = -1;
-    if (on < 0) { const char* e = getenv("JVAE_SMALLCI"); on = (e && e[0] == '0') ? 0 : 1; }      // A/B switch
-    return on && Cin >= 1 && Cin <= 4 && Cout >= 8 && S == 1 && P == 2 && H == W && OW == W && (W == 32 || W == 64);
+    if (on < 0) { const char* e = getenv("JVAE_SMALLCI"); on = e ? atoi(e) : 1; }      // 0: off, 1: dgrad role only, 2: forward too
+    if (!(on == 2 || (on == 1 && dgrad_role))) return false;
+    return Cin >= 1 && Cin <= 4 && Cout >= 8 && S == 1 && P == 2 && H == W && OW == W && (W == 32 || W == 64);
 }
 
 int jvae_conv5_smallci(const float* in, const float* w, int swap, int flip, const float* bias, float* out,

@@ -12,7 +12,7 @@ FAMS = [('bn_bwd_apply', 'BN bwd apply'), ('bn_bwd_reduce', 'BN bwd reduce'), ('
         ('wgrad_reduce', 'wgrad slab reduce'), ('conv5_x3_kernel', 'conv x3 (fwd/dgrad s1)'), ('convt2_x3', 'conv 4-phase x3'),
         ('conv5_fwd_kernel', 'conv f32 mfma'), ('convt2_kernel', 'conv 4-phase f32'), ('gemm_kernel', 'dense products (gemm + split-K fold)'),
         ('gemm_x3_kernel', 'dense products (gemm + split-K fold)'), ('splitk_fold', 'dense products (gemm + split-K fold)'), ('small_transpose', 'unfold/fold'), ('pack_refresh', 'weight packs'), ('unfold', 'unfold/fold'),
-        ('fold_kernel', 'unfold/fold'), ('smallco', 'head conv (3 ch)'), ('wpack', 'weight packs'), ('pack_kernel', 'weight packs'),
+        ('fold_kernel', 'unfold/fold'), ('smallco', '3-channel layers on the vector ALUs'), ('smallci', '3-channel layers on the vector ALUs'), ('sci_wpack', 'weight packs'), ('wpack', 'weight packs'), ('pack_kernel', 'weight packs'),
         ('bn_finalize', 'BN fwd'), ('bn_apply', 'BN fwd'), ('bn_stats', 'BN fwd'), ('adam', 'optimizer'), ('sqnorm', 'optimizer'),
         ('clip', 'optimizer')]
 for r in rows:
