@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256, 2) void conv5_b8_kernel(B8FwdP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     u32x4* Xs = reinterpret_cast<u32x4*>(lds_raw);
     u32x4* Ws = Xs + G::XS;
-    __shared__ float ctab[AFF ? 2 * 256 : 1];                 // (scale, shift) of all input channels (<= 256)
+    __shared__ __attribute__((aligned(16))) float ctab[AFF ? 2 * 256 : 4];   // (scale, shift) of all input channels (<= 256)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (AFF)

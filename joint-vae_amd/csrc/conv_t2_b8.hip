@@ -54,7 +54,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void convt2_b8_kernel(T2B
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     u32x4* Xs = reinterpret_cast<u32x4*>(lds_raw);
     u32x4* Ws = Xs + G::XS;
-    __shared__ float ctab[AFF ? 2 * 256 : 1];
+    __shared__ __attribute__((aligned(16))) float ctab[AFF ? 2 * 256 : 4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (AFF)
         for (int i = tid; i < p.CBin * 8; i += NW * 64) { ctab[i] = p.aff.sc[i]; ctab[256 + i] = p.aff.sh[i]; }

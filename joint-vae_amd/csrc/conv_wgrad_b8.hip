@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_b8_kernel(WgB8P p) {
     const int cbq0 = blockIdx.z * 4;                           // first channel block of Q (MODE 0)
 
     for (int i = tid; i < G::QS; i += 256) Qs[i] = u32x4{0u, 0u, 0u, 0u};
-    __shared__ float ctab[AFF ? 2 * 8 * (G::NCBQ + 4) : 1];     // (scale, shift) of this workgroup's q / ps channel blocks
+    __shared__ __attribute__((aligned(16))) float ctab[AFF ? 2 * 8 * (G::NCBQ + 4) : 4];     // (scale, shift) of this workgroup's q / ps channel blocks
     if (AFF && tid < 8 * (G::NCBQ + 4)) {
         constexpr int NQ = 8 * G::NCBQ;
         const bool isq = tid < NQ;

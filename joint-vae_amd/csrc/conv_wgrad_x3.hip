@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_x3_kernel(WgX3P p) {
     const unsigned char* Qb = lds_raw;
     const unsigned char* Pb = lds_raw + NPL * G::QS * 16;
     constexpr int NT8 = 8 * (G::NCBQ + 4);
-    __shared__ float ctab[AFF ? 2 * NT8 : 1];                  // (scale, shift) of this workgroup's q / ps channels
+    __shared__ __attribute__((aligned(16))) float ctab[AFF ? 2 * NT8 : 4];   // (scale, shift) of this workgroup's q / ps channels
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
@@ -284,6 +284,8 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_x3_kernel(WgX3P p) {
 #pragma unroll
         for (int ci = 0; ci < 8; ++ci) {
             f32x2 v = (live && ci < nch) ? r[ci] : f32x2{0.f, 0.f};
+            // (round 4: reading the 8 (scale, shift) pairs as four 16-byte LDS vectors up front made the stride-2 launches 3 % faster
+            // and run-to-run NON-deterministic - tools/x3_determinism.py; the same in conv_x3.hip, which now takes them as scalars)
             if (AFF && aff && live && ci < nch) {
                 v[0] = fmaf(v[0], sc[ci], sh[ci]);
                 v[1] = fmaf(v[1], sc[ci], sh[ci]);

@@ -128,7 +128,6 @@ __global__ __launch_bounds__(256, 2) void conv5_x3_kernel(X3P p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     u32x4* Xs = reinterpret_cast<u32x4*>(lds_raw);            // [3 planes][XS]
     u32x4* Ws = Xs + 3 * G::XS;                                // [2 buffers][WGS]
-    __shared__ float ctab[AFF ? 2 * 256 : 1];                 // (scale, shift) of all input channels (<= 256)
     __shared__ float bias_s[32];                              // this workgroup's 32 bias values: fetched while the first patch
                                                               // loads are in flight (a global load in the epilogue is an exposed
                                                               // round trip per workgroup: 36 us of the 32-wide layer)
@@ -150,12 +149,6 @@ __global__ __launch_bounds__(256, 2) void conv5_x3_kernel(X3P p) {
     const int NG = KB * G::GPK;                                // weight groups: (K step, kernel row | group of 2 tap pairs)
 
     if (tid < 32) bias_s[tid] = (p.bias && o0 + tid < p.CoutReal) ? p.bias[o0 + tid] : 0.f;
-    if (AFF)
-        for (int i = tid; i < KB * 16; i += 256) {
-            const bool ok = i < p.Cin;
-            ctab[i] = ok ? p.aff.sc[i] : 0.f;
-            ctab[256 + i] = ok ? p.aff.sh[i] : 0.f;
-        }
     // pixel tiles of this wave: MT groups of 32 pixels (32x32x16: the pixel on lane & 31, channel block `half`), or 2*MT tiles of 16
     // (16x16x32: the pixel on lane & 15, lane group kq = lane >> 4 = (tap of the pair, channel block))
     constexpr int NPT = G::NPT, TPX = SH ? 16 : 32;
@@ -193,8 +186,15 @@ __global__ __launch_bounds__(256, 2) void conv5_x3_kernel(X3P p) {
 
     const int in_row0 = row0 * S - p.P;
     constexpr int W2 = G::WIN / 2;
-    constexpr int XPAIRS = G::NIMG * 2 * G::ROWS * W2;         // (2 pixels x 8 channels) items per K step
-    constexpr int XU = (XPAIRS + 255) / 256, WU = (G::WGS + 255) / 256;
+    // Staging items = (2 pixels x 8 channels).  The 8-channel block `hq` of an item is WAVE-UNIFORM (round 4): waves 0, 1 stage
+    // block 0, waves 2, 3 block 1, each pair walking the PERH (image, row, pixel pair) items of its block in XU passes of 128 - so
+    // the channel of rx[k][ci] is the same for every lane of a wave and the deferred BatchNorm's coefficients are SCALAR operands
+    // (s_load from the coefficient vectors, no LDS table).  The first mapping (block = a per-lane function of the item index) read
+    // them from LDS inside the per-lane `live` branch: 16 dependent ds_read_b32 per item, 3 600 + 2 400 of a workgroup's 74 000
+    // cycles (tools/x3_stamps.py with AFF=0 / 1).
+    constexpr int PERH = G::NIMG * G::ROWS * W2;               // items per 8-channel block and K step
+    constexpr int XU = (PERH + 127) / 128, WU = (G::WGS + 255) / 256;
+    const int hq = __builtin_amdgcn_readfirstlane(tid >> 7);   // this wave's channel block (scalar)
     f32x2 rx[XU][8];
     u32x4 rw[WU];
 
@@ -206,14 +206,13 @@ __global__ __launch_bounds__(256, 2) void conv5_x3_kernel(X3P p) {
     const long cstride = (long)p.H * p.W;
 #pragma unroll
     for (int k = 0; k < XU; ++k) {
-        const int u = tid + k * 256;
+        const int u = (tid & 127) + k * 128;
         const int xp = u % W2;
-        int t = u / W2;
-        const int lr = t % G::ROWS; t /= G::ROWS;
-        const int h = t % 2, im = t / 2;
+        const int t = u / W2;
+        const int lr = t % G::ROWS, im = t / G::ROWS;
         const int ir = in_row0 + lr, n = img0 + im;
-        const bool ok = u < XPAIRS && ir >= 0 && ir < p.H && n < p.N;
-        xsrc[k] = p.in + (((long)(ok ? n : 0) * p.Cin + h * 8) * p.H + (ok ? ir : 0)) * p.W + 2 * xp;
+        const bool ok = u < PERH && ir >= 0 && ir < p.H && n < p.N;
+        xsrc[k] = p.in + (((long)(ok ? n : 0) * p.Cin + hq * 8) * p.H + (ok ? ir : 0)) * p.W + 2 * xp;
     }
 #pragma unroll
     for (int k = 0; k < WU; ++k) {
@@ -221,15 +220,17 @@ __global__ __launch_bounds__(256, 2) void conv5_x3_kernel(X3P p) {
         wsrc[k] = p.wp + (long)(u / 32) * p.OP + o0 + u % 32;
     }
     auto gloadX = [&](int kb) {
+        // channels beyond Cin: a clamped (valid) channel is loaded instead and zeroed in lstoreX - pure address arithmetic on
+        // wave-uniform values, so that the loads stay unconditional (a per-lane select between two ADDRESSES was compiled into
+        // branches around the loads with a vmcnt(0) behind each: 16 serialised round trips in the prologue)
+        const int cmax = p.Cin - 1 - (kb * 16 + hq * 8);       // last valid ci of this block (< 0: the whole block is beyond Cin)
+        const int cm = cmax < 0 ? 0 : (cmax > 7 ? 7 : cmax);
 #pragma unroll
         for (int k = 0; k < XU; ++k) {
-            const int h = ((tid + k * 256) / (W2 * G::ROWS)) % 2;
-            const float* src = xsrc[k] + (long)kb * 16 * cstride;
+            const float* src = cmax < 0 ? xsrc[k] : xsrc[k] + (long)kb * 16 * cstride;
 #pragma unroll
-            for (int ci = 0; ci < 8; ++ci) {
-                const bool okc = kb * 16 + h * 8 + ci < p.Cin;  // channels beyond Cin: stand-in address, zeroed in lstoreX
-                rx[k][ci] = *reinterpret_cast<const f32x2*>(okc ? src + ci * cstride : xsrc[k]);
-            }
+            for (int ci = 0; ci < 8; ++ci)
+                rx[k][ci] = *reinterpret_cast<const f32x2*>(src + (long)(ci < cm ? ci : cm) * cstride);
         }
     };
     auto gloadW = [&](int g) {
@@ -237,27 +238,38 @@ __global__ __launch_bounds__(256, 2) void conv5_x3_kernel(X3P p) {
         for (int k = 0; k < WU; ++k) rw[k] = wsrc[k][(long)g * (G::WGS / 32) * p.OP];
     };
     auto lstoreX = [&](int kb) {                    // kb: the K step whose data sits in rx
+        // deferred BatchNorm: (scale, shift) of this wave's 8 channels as scalars (uniform addresses in the constant address space)
+        typedef const __attribute__((address_space(4))) float* const_f32_p;
+        float csc[8], csh[8];
+        if constexpr (AFF) {
+            const const_f32_p gsc = (const_f32_p)(unsigned long long)p.aff.sc, gsh = (const_f32_p)(unsigned long long)p.aff.sh;
+#pragma unroll
+            for (int ci = 0; ci < 8; ++ci) {
+                const int ch = kb * 16 + hq * 8 + ci;
+                const int cc = ch < p.Cin ? ch : p.Cin - 1;                // (clamped: the value is zeroed below)
+                csc[ci] = gsc[cc]; csh[ci] = gsh[cc];
+            }
+        }
 #pragma unroll
         for (int k = 0; k < XU; ++k) {
-            const int u = tid + k * 256;
-            if (u < XPAIRS) {
+            const int u = (tid & 127) + k * 128;
+            if (u < PERH) {
                 const int xp = u % W2;
-                int t = u / W2;
-                const int lr = t % G::ROWS; t /= G::ROWS;
-                const int h = t % 2, im = t / 2;
+                const int t = u / W2;
+                const int lr = t % G::ROWS, im = t / G::ROWS;
+                const int h = hq;
                 // out-of-image rows / missing images / channels were loaded from a stand-in address: exact zeros
                 const int ir = in_row0 + lr, n = img0 + im;
                 const bool live = ir >= 0 && ir < p.H && n < p.N;
                 bf16x8 s[2][3];
 #pragma unroll
                 for (int ci = 0; ci < 8; ++ci) {
-                    f32x2 v = (live && kb * 16 + h * 8 + ci < p.Cin) ? rx[k][ci] : f32x2{0.f, 0.f};
-                    if (AFF && live) {
-                        const int ch = kb * 16 + h * 8 + ci;               // ctab is zero beyond Cin: 0*0 + 0
-                        const float sc = ctab[ch], sh = ctab[256 + ch];
-                        v[0] = fmaf(v[0], sc, sh);
-                        v[1] = fmaf(v[1], sc, sh);
-                        if (p.aff.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); }
+                    const bool keep = live && kb * 16 + h * 8 + ci < p.Cin;
+                    f32x2 v = keep ? rx[k][ci] : f32x2{0.f, 0.f};
+                    if constexpr (AFF) {
+                        f32x2 a{fmaf(v[0], csc[ci], csh[ci]), fmaf(v[1], csc[ci], csh[ci])};
+                        if (p.aff.relu) { a[0] = fmaxf(a[0], 0.f); a[1] = fmaxf(a[1], 0.f); }
+                        v = keep ? a : f32x2{0.f, 0.f};                    // padding rows / missing channels stay exact zeros
                     }
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {

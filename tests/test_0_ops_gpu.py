@@ -736,3 +736,46 @@ def test_split_bf16_stride2_transposed_conv(cin, cout, H, N, tr):
         L.jvae_conv2d_set_split_bf16(old)
     assert y1.shape == ref.shape
     assert rel(y1, ref) < 3e-6 and rel(y0, ref) < 5e-6 and rel(y1, y0) < 5e-6
+
+
+@pytest.mark.parametrize('N,cin,cout,H,s,tr', [(256, 32, 32, 32, 1, True), (256, 64, 32, 16, 1, True), (128, 64, 64, 8, 1, True),
+                                               (128, 32, 64, 16, 1, False), (8, 32, 768, 32, 1, False),
+                                               (128, 32, 32, 32, 2, False), (256, 64, 64, 8, 2, True)])
+def test_conv_kernels_are_run_to_run_deterministic(N, cin, cout, H, s, tr):
+    """Every launch of the same convolution on the same data gives the same BITS - forward with and without the deferred
+    BatchNorm (with its BatchNorm sums), dgrad, weight gradient with the deferred BatchNorm, in fp32 and (5x5 bf16 kernels) on
+    B8 operands.  Grids with several workgroups per CU, launched six times each.  (Round 4: a staging variant that read the
+    deferred BatchNorm's coefficients as 16-byte LDS vectors was 6 % faster and changed a few thousand to a few million outputs
+    from launch to launch while every single-launch parity test passed; tools/x3_determinism.py.)"""
+    from jvae_hip import ops, ops_b8
+    g = torch.Generator().manual_seed(N + cin + cout + H)
+    spec = ops.ConvSpec(cin, cout, 5, s, 2, 1 if (tr and s == 2) else 0, tr)
+    wshape = (cin, cout, 5, 5) if tr else (cout, cin, 5, 5)
+    x = torch.randn(N, cin, H, H, generator=g).to(DEV)
+    w = (torch.randn(wshape, generator=g) * 0.05).to(DEV)
+    b = torch.randn(cout, generator=g).to(DEV)
+    aff = ((torch.rand(cin, generator=g) + 0.5).to(DEV), (torch.randn(cin, generator=g) * 0.3).to(DEV), True)
+    y = ops.conv_fwd_raw(x, w, b, spec)
+    gy = torch.randn(y.shape, generator=g).to(DEV)
+
+    def wgrad():
+        gw = torch.zeros(wshape, device=DEV)
+        ops.conv_wgrad_raw(x, gy, spec, wshape, False, gw, None, aff=aff if ops.conv_affine_ok(spec, N, H, H) else None)
+        return gw
+    cases = {'forward': lambda: ops.conv_fwd_raw(x, w, b, spec),
+             'dgrad': lambda: ops.conv_dgrad_raw(gy, w, spec, x.shape),
+             'weight gradient': wgrad}
+    if ops.conv_affine_ok(spec, N, H, H):
+        cases['forward, deferred BatchNorm'] = lambda: ops.conv_fwd_aff_raw(x, w, b, spec, aff, True)[0]
+    if ops_b8.native_mask(spec, N, H, H) == 7 and ops_b8.conv_affine_ok(spec, N, H, H):
+        xb, gyb = ops_b8.pack(x), ops_b8.pack(gy)
+        C8 = (cin + 7) // 8 * 8
+        coef = torch.zeros(2, C8, device=DEV)
+        coef[0, :cin], coef[1, :cin] = aff[0], aff[1]
+        affb = (coef[0], coef[1], True)
+        cases['bf16 forward, deferred BatchNorm'] = lambda: ops_b8.conv_fwd_raw(xb, w, None, spec, aff=affb)[0]
+        cases['bf16 weight gradient, deferred BatchNorm'] = lambda: ops_b8.conv_wgrad_raw(xb, gyb, spec, wshape, False, aff=affb)[0]
+    for name, f in cases.items():
+        first = f().clone()
+        for _ in range(5):
+            assert torch.equal(f(), first), name

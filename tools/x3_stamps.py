@@ -17,7 +17,8 @@ x = torch.randn(N, C, H, H, device='cuda'); w = torch.randn(C, C, 5, 5, device='
 aff = (torch.rand(C, device='cuda') + 0.5, torch.randn(C, device='cuda') * 0.1, True)
 for sh in (1,):          # the stamped epilogue is the 16x16x32 form's
     lib.jvae_conv2d_set_split_shape16(sh)
-    f = lambda: ops.conv_fwd_aff_raw(x, w, b, spec, aff, True)
+    f = (lambda: ops.conv_fwd_aff_raw(x, w, b, spec, aff, True)) if os.environ.get('AFF', '1') != '0' else (lambda: ops.conv_fwd_stats_raw(x, w, b, spec))
+    print('deferred BatchNorm on the input:', os.environ.get('AFF', '1') != '0')
     raw.jvae_x3_set_stamp_buffer(None)
     t0 = time.time()
     while time.time() - t0 < 2.0:                    # clock settles under load
