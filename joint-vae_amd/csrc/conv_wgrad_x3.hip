@@ -215,6 +215,25 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_x3_kernel(WgX3P p) {
     constexpr int W2 = G::WB / 2;
     const long qcs = (long)HB * G::WB, pcs = (long)G::HS * WS;  // channel strides
     f32x2 rq[QU][8], rp[PU][8];                 // (dead in the one-plane form)
+    // Stride 2 (round 4): the channel block of a thread's staging items is a function of the thread index alone (u % NCBQ and
+    // u % 4 with u = tid + 256 k), and only the layer-input side carries a deferred BatchNorm: its 8 (scale, shift) pairs live in
+    // 16 registers for the whole kernel. The per-channel LDS reads inside the per-lane branch cost these launches 10-12 us each
+    // (74 vs 64 us on E1); the stride-1 forms have no registers to spare and keep the table in LDS.
+    constexpr bool REGC = AFF && S == 2 && NPL == 3;
+    static_assert(!REGC || (256 % G::NCBQ == 0), "one channel block per thread");
+    float cr[16];
+    if constexpr (REGC) {
+        const bool onq = p.aff_q.sc != nullptr;
+        const InAff& a = onq ? p.aff_q : p.aff_p;
+        const int ch0 = onq ? (cbq0 + threadIdx.x % G::NCBQ) * 8 : a0 + (threadIdx.x % 4) * 8;
+        const int cn = onq ? p.Cb : p.Ca;
+#pragma unroll
+        for (int ci = 0; ci < 8; ++ci) {
+            const bool ok = a.sc && ch0 + ci < cn;
+            cr[ci] = ok ? a.sc[ch0 + ci] : 0.f;
+            cr[8 + ci] = ok ? a.sh[ch0 + ci] : 0.f;
+        }
+    }
     const float* const qf = (const float*)p.q;
     const float* const psf = (const float*)p.ps;
     // one-plane form: B8 units straight from HBM
@@ -278,15 +297,22 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_x3_kernel(WgX3P p) {
         }
     };
     // 2 pixels x 8 channels of fp32 -> [deferred BatchNorm] -> three bf16 planes, two 16-byte units each
+    // sc / sh: the item's (scale, shift) in LDS (ctab) - or, with REGC (stride 2), in registers (creg: loaded once per kernel)
     auto split_store = [&](const f32x2 (&r)[8], bool live, int nch, const float* sc, const float* sh, int relu,
-                           bool aff, u32x4* dst0, u32x4* dst1, int plane_stride) {
+                           bool aff, u32x4* dst0, u32x4* dst1, int plane_stride, const float (&creg)[16]) {
         bf16x8 s[2][3];
 #pragma unroll
         for (int ci = 0; ci < 8; ++ci) {
             f32x2 v = (live && ci < nch) ? r[ci] : f32x2{0.f, 0.f};
             // (round 4: reading the 8 (scale, shift) pairs as four 16-byte LDS vectors up front made the stride-2 launches 3 % faster
             // and run-to-run NON-deterministic - tools/x3_determinism.py; the same in conv_x3.hip, which now takes them as scalars)
-            if (AFF && aff && live && ci < nch) {
+            if constexpr (REGC) {
+                if (aff) {
+                    f32x2 a{fmaf(v[0], creg[ci], creg[8 + ci]), fmaf(v[1], creg[ci], creg[8 + ci])};
+                    if (relu) { a[0] = fmaxf(a[0], 0.f); a[1] = fmaxf(a[1], 0.f); }
+                    v = (live && ci < nch) ? a : f32x2{0.f, 0.f};         // padding rows / missing channels stay exact zeros
+                }
+            } else if (AFF && aff && live && ci < nch) {
                 v[0] = fmaf(v[0], sc[ci], sh[ci]);
                 v[1] = fmaf(v[1], sc[ci], sh[ci]);
                 if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); }
@@ -354,7 +380,8 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_x3_kernel(WgX3P p) {
                 const int s0 = S == 1 ? c0 : (c0 & 1) * G::WPH + (c0 >> 1), s1 = S == 1 ? c1 : (c1 & 1) * G::WPH + (c1 >> 1);
                 const int z0 = SWZ ? (s0 >> 3 & 1) << 1 : 0, z1 = SWZ ? (s1 >> 3 & 1) << 1 : 0;    // swizzle: keyed on the column
                 split_store(rq[k], live, p.Cb - (cbq0 + c) * 8, AFF ? &ctab[c * 8] : ctab, AFF ? &ctab[NT8 + c * 8] : ctab, p.aff_q.relu,
-                            p.aff_q.sc != nullptr, &Qs[(lr * G::WPS + s0) * G::NCBQ + (c ^ z0)], &Qs[(lr * G::WPS + s1) * G::NCBQ + (c ^ z1)], G::QS);
+                            p.aff_q.sc != nullptr, &Qs[(lr * G::WPS + s0) * G::NCBQ + (c ^ z0)], &Qs[(lr * G::WPS + s1) * G::NCBQ + (c ^ z1)], G::QS,
+                            cr);
             }
         }
 #pragma unroll
@@ -364,7 +391,8 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_x3_kernel(WgX3P p) {
                 const int c = u % 4, px2 = u / 4;
                 const int zp = SWZ ? (px2 >> 2 & 1) << 1 : 0;      // bit 3 of the pixel index (shared by the two pixels)
                 split_store(rp[k], true, p.Ca - (a0 + c * 8), AFF ? &ctab[(G::NCBQ + c) * 8] : ctab, AFF ? &ctab[NT8 + (G::NCBQ + c) * 8] : ctab,
-                            p.aff_p.relu, p.aff_p.sc != nullptr, &Pt[(2 * px2) * 4 + (c ^ zp)], &Pt[(2 * px2 + 1) * 4 + (c ^ zp)], G::PS);
+                            p.aff_p.relu, p.aff_p.sc != nullptr, &Pt[(2 * px2) * 4 + (c ^ zp)], &Pt[(2 * px2 + 1) * 4 + (c ^ zp)], G::PS,
+                            cr);
             }
         }
     };
