@@ -122,6 +122,11 @@ struct X3Geom {
 template <bool SH, int NPT> struct X3Acc { f32x16 t[NPT]; };
 template <int NPT> struct X3Acc<true, NPT> { f32x4 t[NPT][2]; };        // [16-pixel tile][16-channel tile]
 
+#ifndef JVAE_X3_MID
+#define JVAE_X3_MID 0    // 1: the next weight group is staged behind a group's first 24 MFMAs instead of in front of them.  Measured
+#endif                   // neutral (imager.15 239 vs 241-247 us, the 8-wide layers +2 %: profiles/r04_x3_mid_ab.txt) - the other
+                         // workgroup of the CU already fills the matrix pipe during those 550 cycles.  Kept for A/B builds.
+
 template <int S, int OW, int MT, bool AFF, bool SH = false>
 __global__ __launch_bounds__(256, 2) void conv5_x3_kernel(X3P p) {
     using G = X3Geom<S, OW, MT, SH>;
@@ -334,7 +339,7 @@ __global__ __launch_bounds__(256, 2) void conv5_x3_kernel(X3P p) {
     // are read ahead.  Lane group kq reads tap 2*pair + (kq >> 1): the second tap of a pair lies one unit to the right, or - when
     // the pair crosses a kernel row (taps 4|5, 14|15) - one row down and four units to the left; tap 25 does not exist (its
     // weights are zero): those lanes re-read tap 24 so that no value from outside the receptive field enters a 0 * x.
-    auto computeSH = [&](int buf, int gi) {
+    auto computeSH = [&](int buf, int gi, auto&& mid) {        // mid(): issued behind the first block of MFMAs (weight staging)
         constexpr int TPH = NPT >= 2 ? 2 : 1;                    // pixel tiles per half
         constexpr int NH = SH ? NPT / TPH : 1;                   // halves per pair
         const u32x4* Wb = Ws + buf * G::WGS + kq * 32 + l15;
@@ -388,6 +393,7 @@ __global__ __launch_bounds__(256, 2) void conv5_x3_kernel(X3P p) {
                                 }
                             }
                     __builtin_amdgcn_sched_barrier(0);
+                    if (pq == 0 && hp == 0) { mid(); __builtin_amdgcn_sched_barrier(0); }
                 }
                 off = offn;
             }
@@ -429,14 +435,28 @@ __global__ __launch_bounds__(256, 2) void conv5_x3_kernel(X3P p) {
         const bool more = g + 1 < NG, last_row = kh == G::GPK - 1;
         // buffer (g+1)&1 was last read in group g-1: every wave is past it.  The store (which waits for the loads of
         // rw) must stay ahead of the next loads: the scheduler would otherwise issue them first and wait for all.
-        if (more) lstoreW((g + 1) & 1);
-        __builtin_amdgcn_sched_barrier(0);
-        if (g + 2 < NG) gloadW(g + 2);
-        if (kh == G::GPK - 2 && kb + 1 < KB) gloadX(kb + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        if (g < 14) X3_STAMP(9 + 4 * g);           // weights stored, next loads issued
-        if constexpr (SH) computeSH(g & 1, kh);
-        else compute(g & 1, kh * G::WP);
+        auto stage = [&] {
+            if (more) lstoreW((g + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (g + 2 < NG) gloadW(g + 2);
+            if (kh == G::GPK - 2 && kb + 1 < KB) gloadX(kb + 1);
+        };
+        if constexpr (SH) {
+#if JVAE_X3_MID
+            if (g < 14) X3_STAMP(9 + 4 * g);
+            computeSH(g & 1, kh, stage);
+#else
+            stage();
+            __builtin_amdgcn_sched_barrier(0);
+            if (g < 14) X3_STAMP(9 + 4 * g);           // weights stored, next loads issued
+            computeSH(g & 1, kh, [] {});
+#endif
+        } else {
+            stage();
+            __builtin_amdgcn_sched_barrier(0);
+            if (g < 14) X3_STAMP(9 + 4 * g);
+            compute(g & 1, kh * G::WP);
+        }
         if (g < 14) X3_STAMP(10 + 4 * g);          // MFMAs issued
         lds_barrier();
         if (g < 14) X3_STAMP(11 + 4 * g);          // barrier passed
@@ -455,11 +475,12 @@ __global__ __launch_bounds__(256, 2) void conv5_x3_kernel(X3P p) {
         for (int b = 0; b < NPT; ++b)
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct) acc[b][ct] += acs[b][ct];
-        float bv[2][4];
+        float bv[2][4];                            // (bias_s holds zeros without a bias)
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) bv[ct][r] = p.bias ? bias_s[ct * 16 + kq * 4 + r] : 0.f;
+            for (int r = 0; r < 4; ++r) bv[ct][r] = bias_s[ct * 16 + kq * 4 + r];
+        const bool fullc = o0 + 32 <= p.CoutReal;
 #pragma unroll
         for (int pt = 0; pt < NPT; ++pt) {
             const int pix = (wave * NPT + pt) * 16 + l15;
@@ -467,14 +488,22 @@ __global__ __launch_bounds__(256, 2) void conv5_x3_kernel(X3P p) {
             const int n = img0 + im;
             if (n >= p.N) continue;
             const int oy = row0 + rem / OW, ox = rem % OW;
+            // one base address per pixel tile, the lane's 8 channels at constant strides from it; a full 32-channel block (the
+            // uniform, usual case) needs no per-channel bound check - it was a compare + exec branch + 64-bit address chain in
+            // front of each of the 32 stores
+            float* const dst = p.out + (((long)n * p.CoutReal + o0 + kq * 4) * G::OH + oy) * OW + ox;
+            if (fullc) {
 #pragma unroll
-            for (int ct = 0; ct < 2; ++ct)
+                for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int o = o0 + ct * 16 + kq * 4 + r;
-                    if (o >= p.CoutReal) continue;
-                    p.out[(((long)n * p.CoutReal + o) * G::OH + oy) * OW + ox] = acc[pt][ct][r] + bv[ct][r];
-                }
+                    for (int r = 0; r < 4; ++r) dst[(ct * 16 + r) * G::OHW] = acc[pt][ct][r] + bv[ct][r];
+            } else {
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (o0 + ct * 16 + kq * 4 + r < p.CoutReal) dst[(ct * 16 + r) * G::OHW] = acc[pt][ct][r] + bv[ct][r];
+            }
         }
         X3_STAMP(6);                               // output stores issued
         if (p.stats) {
