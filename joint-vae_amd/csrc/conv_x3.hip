@@ -27,6 +27,7 @@
 #include "jvae_internal.h"
 #include "conv_dispatch.h"
 #include "conv_x3.h"
+#include <type_traits>
 #include "pack_elems.h"
 
 namespace {
@@ -121,11 +122,6 @@ struct X3Geom {
 
 template <bool SH, int NPT> struct X3Acc { f32x16 t[NPT]; };
 template <int NPT> struct X3Acc<true, NPT> { f32x4 t[NPT][2]; };        // [16-pixel tile][16-channel tile]
-
-#ifndef JVAE_X3_MID
-#define JVAE_X3_MID 0    // 1: the next weight group is staged behind a group's first 24 MFMAs instead of in front of them.  Measured
-#endif                   // neutral (imager.15 239 vs 241-247 us, the 8-wide layers +2 %: profiles/r04_x3_mid_ab.txt) - the other
-                         // workgroup of the CU already fills the matrix pipe during those 550 cycles.  Kept for A/B builds.
 
 template <int S, int OW, int MT, bool AFF, bool SH = false>
 __global__ __launch_bounds__(256, 2) void conv5_x3_kernel(X3P p) {
@@ -339,11 +335,17 @@ __global__ __launch_bounds__(256, 2) void conv5_x3_kernel(X3P p) {
     // are read ahead.  Lane group kq reads tap 2*pair + (kq >> 1): the second tap of a pair lies one unit to the right, or - when
     // the pair crosses a kernel row (taps 4|5, 14|15) - one row down and four units to the left; tap 25 does not exist (its
     // weights are zero): those lanes re-read tap 24 so that no value from outside the receptive field enters a 0 * x.
-    auto computeSH = [&](int buf, int gi, auto&& mid) {        // mid(): issued behind the first block of MFMAs (weight staging)
+    // npair (1 for the last group of a K step) is a COMPILE-TIME constant (round 4): as a run-time value it put the read-ahead
+    // of the next half behind a branch, and at the join the compiler's s_waitcnt had to assume the path WITHOUT the new reads -
+    // lgkmcnt(2) / (0) right behind twelve fresh ds_read_b128, i.e. the read-ahead was waited for before the MFMAs it was meant
+    // to hide under (one exposed LDS round trip per pair).
+    // pre(): the staging of the next weight group, issued BEHIND the group's first fragment reads (their LDS round trip runs under
+    // its ~500 cycles of address arithmetic, waits for the weight loads and LDS stores) and in front of the first MFMA.
+    auto computeSH = [&](int buf, int gi, auto npair_c, auto&& pre) {
         constexpr int TPH = NPT >= 2 ? 2 : 1;                    // pixel tiles per half
         constexpr int NH = SH ? NPT / TPH : 1;                   // halves per pair
         const u32x4* Wb = Ws + buf * G::WGS + kq * 32 + l15;
-        const int npair = gi == 6 ? 1 : 2;
+        constexpr int npair = decltype(npair_c)::value;
         u32x4 fa[2][3][2], fb[2][3][TPH];
         auto tapoff = [&](int t) {                               // LDS unit offset of tap t relative to the lane's pixel
             const int kh = t / 5, kw = t - 5 * kh;
@@ -378,6 +380,7 @@ __global__ __launch_bounds__(256, 2) void conv5_x3_kernel(X3P p) {
                     const int cur = (pq * NH + hp) & 1;
                     if (hp + 1 < NH) fragB(off, hp + 1, fb[cur ^ 1]);
                     else if (pq + 1 < npair) { fragA(pq + 1, fa[(pq + 1) & 1]); fragB(offn, 0, fb[cur ^ 1]); }
+                    if (pq == 0 && hp == 0) { __builtin_amdgcn_sched_barrier(0); pre(); }
                     __builtin_amdgcn_sched_barrier(0);
                     constexpr int WPL[6] = {0, 0, 2, 1, 1, 0}, XPL[6] = {2, 1, 0, 0, 1, 0};
 #pragma unroll
@@ -393,7 +396,6 @@ __global__ __launch_bounds__(256, 2) void conv5_x3_kernel(X3P p) {
                                 }
                             }
                     __builtin_amdgcn_sched_barrier(0);
-                    if (pq == 0 && hp == 0) { mid(); __builtin_amdgcn_sched_barrier(0); }
                 }
                 off = offn;
             }
@@ -428,44 +430,67 @@ __global__ __launch_bounds__(256, 2) void conv5_x3_kernel(X3P p) {
     if (NG > 1) gloadW(1);
     lds_barrier();
     X3_STAMP(3);
-    int kb = 0, kh = 0;
-    for (int g = 0; g < NG; ++g) {
-        if (g < 14) X3_STAMP(8 + 4 * g);           // group start
-        // invariant: patch of K step kb in Xs, weight group g in buffer g&1, rw = weight group g+1 (in flight)
-        const bool more = g + 1 < NG, last_row = kh == G::GPK - 1;
-        // buffer (g+1)&1 was last read in group g-1: every wave is past it.  The store (which waits for the loads of
-        // rw) must stay ahead of the next loads: the scheduler would otherwise issue them first and wait for all.
-        auto stage = [&] {
-            if (more) lstoreW((g + 1) & 1);
+    if constexpr (SH) {
+        // 16x16x32 form: K steps outside, the GPK - 1 two-pair groups of a K step inside, its one-pair group with the K-step change
+        // behind them - so that the registers of the next patch (rx: loaded at the start of the one-pair group, split and stored
+        // behind it) are live in that tail only and not across the two-pair code, which needs the room for its read-ahead
+        typedef std::integral_constant<int, 1> one_pair;
+        typedef std::integral_constant<int, 2> two_pairs;
+        int g = 0;
+        auto stageW = [&] {
+            // buffer (g+1)&1 was last read in group g-1: every wave is past it.  The store (which waits for the loads of
+            // rw) must stay ahead of the next loads: the scheduler would otherwise issue them first and wait for all.
+            if (g + 1 < NG) lstoreW((g + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (g + 2 < NG) gloadW(g + 2);
+        };
+        for (int kb = 0; kb < KB; ++kb) {
+            // invariant: patch of K step kb in Xs, weight group g in buffer g&1, rw = weight group g+1 (in flight)
+            for (int kh = 0; kh < G::GPK - 1; ++kh, ++g) {
+                if (g < 14) X3_STAMP(8 + 4 * g);           // group start
+                computeSH(g & 1, kh, two_pairs{}, [&] {
+                    stageW();
+                    if (g < 14) X3_STAMP(9 + 4 * g);       // first fragment reads issued, weights stored, next loads issued
+                });
+                if (g < 14) X3_STAMP(10 + 4 * g);          // MFMAs issued
+                lds_barrier();
+                if (g < 14) X3_STAMP(11 + 4 * g);          // barrier passed
+            }
+            const bool nextk = kb + 1 < KB;
+            if (g < 14) X3_STAMP(8 + 4 * g);
+            computeSH(g & 1, G::GPK - 1, one_pair{}, [&] {
+                stageW();
+                if (nextk) gloadX(kb + 1);
+                if (g < 14) X3_STAMP(9 + 4 * g);
+            });
+            if (g < 14) X3_STAMP(10 + 4 * g);
+            lds_barrier();
+            if (g < 14) X3_STAMP(11 + 4 * g);
+            if (nextk) {                                   // K step change: the patch is fully consumed
+                lstoreX(kb + 1);
+                lds_barrier();
+                X3_STAMP(4);                               // (first) K step change done
+            }
+            ++g;
+        }
+    } else {
+        int kb = 0, kh = 0;
+        for (int g = 0; g < NG; ++g) {
+            // invariant: patch of K step kb in Xs, weight group g in buffer g&1, rw = weight group g+1 (in flight)
+            const bool more = g + 1 < NG, last_row = kh == G::GPK - 1;
+            if (more) lstoreW((g + 1) & 1);                // (order: see stageW above)
             __builtin_amdgcn_sched_barrier(0);
             if (g + 2 < NG) gloadW(g + 2);
             if (kh == G::GPK - 2 && kb + 1 < KB) gloadX(kb + 1);
-        };
-        if constexpr (SH) {
-#if JVAE_X3_MID
-            if (g < 14) X3_STAMP(9 + 4 * g);
-            computeSH(g & 1, kh, stage);
-#else
-            stage();
             __builtin_amdgcn_sched_barrier(0);
-            if (g < 14) X3_STAMP(9 + 4 * g);           // weights stored, next loads issued
-            computeSH(g & 1, kh, [] {});
-#endif
-        } else {
-            stage();
-            __builtin_amdgcn_sched_barrier(0);
-            if (g < 14) X3_STAMP(9 + 4 * g);
             compute(g & 1, kh * G::WP);
-        }
-        if (g < 14) X3_STAMP(10 + 4 * g);          // MFMAs issued
-        lds_barrier();
-        if (g < 14) X3_STAMP(11 + 4 * g);          // barrier passed
-        if (more && last_row) {                    // K step change: the patch is fully consumed
-            lstoreX(kb + 1);
             lds_barrier();
-            X3_STAMP(4);                           // (first) K step change done
+            if (more && last_row) {                        // K step change: the patch is fully consumed
+                lstoreX(kb + 1);
+                lds_barrier();
+            }
+            if (++kh == G::GPK) { kh = 0; ++kb; }
         }
-        if (++kh == G::GPK) { kh = 0; ++kb; }
     }
 
     X3_STAMP(5);                                   // main loop done
