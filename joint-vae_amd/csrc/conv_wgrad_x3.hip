@@ -196,6 +196,7 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_x3_kernel(WgX3P p) {
 
     f32x16 acc[SH16 ? 1 : G::NBT];
     f32x4 acc16[SH16 ? G::NBT : 1][2][2];
+    f32x4 accq = {0.f, 0.f, 0.f, 0.f};                         // MODE 0, 16x16x32: this wave's 16x16 block of tap 24
     if (SH16) {
 #pragma unroll
         for (int t = 0; t < G::NBT; ++t)
@@ -407,8 +408,13 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_x3_kernel(WgX3P p) {
         if constexpr (SH16) {
             // slots = (K step of 32 pixels, tile, 16-column block): the fragments of the next slot are read before the 12
             // MFMAs (2 row blocks x 6 products) of the current one are issued
-            constexpr int KS = G::TPIX / 32, NSLOT = G::NBT * 2;
+            // MODE 0 (32 channels x 1 tap per tile, 25 tiles): 25 taps over 4 waves is 7 / 6 / 6 / 6 - wave 0 kept its SIMD busy for
+            // seven tiles while the other three idled through the seventh.  Tap 24 is therefore split by 16x16 BLOCK (round 4): wave w
+            // takes block (rb, cb) = (w >> 1, w & 1) of it - 6 full taps + a quarter = 150 MFMAs per K step and wave instead of 168 / 144.
+            constexpr bool QS = MODE == 0;
+            constexpr int KS = G::TPIX / 32, NSLOT = QS ? (G::NBT - 1) * 2 + 1 : G::NBT * 2;
             bf16x8 a[2][NPL], b[2][NPL];
+            const int bq = QS ? (SWZ ? ((wave & 1) ? boff16[G::NBT - 1][0] ^ 32 : boff16[G::NBT - 1][0]) : boff16[G::NBT - 1][0] + (wave & 1) * 32) : 0;
             auto read_a = [&](int ks) {
 #pragma unroll
                 for (int rb = 0; rb < 2; ++rb)
@@ -423,7 +429,9 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_x3_kernel(WgX3P p) {
                 constexpr int HI16 = (WS >= 32 ? 16 : G::WPS) * G::NCBQ * 16;
 #pragma unroll
                 for (int plane = 0; plane < NPL; ++plane) {
-                    if constexpr (SWZ)
+                    if (QS && slot == NSLOT - 1)
+                        d[plane] = tr_pair<SWZ ? HI16 : 64 * G::NCBQ>(Qb + plane * G::QS * 16, bq + qoff);
+                    else if constexpr (SWZ)
                         d[plane] = tr_pair<HI16>(Qb + plane * G::QS * 16, ((slot & 1) ? boff16[slot >> 1][0] ^ 32 : boff16[slot >> 1][0]) + qoff);
                     else
                         d[plane] = tr_pair<64 * G::NCBQ>(Qb + plane * G::QS * 16,
@@ -443,9 +451,22 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_x3_kernel(WgX3P p) {
                     __builtin_amdgcn_sched_barrier(0);
                     // MODE 2 (16 channels x 1 tap per 16-column block): the 25 taps are dealt to the waves block by block - tap
                     // = wave + 4 * slot: 7 / 6 / 6 / 6 blocks - instead of as 13 tiles of two taps (8 / 6 / 6 / 6 with the empty tap 25)
-                    if (MODE == 2 ? wave + 4 * slot <= 24 : wave + 4 * t < G::NTILE) {         // wave-uniform
-                        constexpr int NPROD = NPL == 3 ? 6 : 1;        // one-plane form: the product itself
-                        constexpr int APL[6] = {0, 2, 1, 0, 1, 0}, BPL[6] = {2, 0, 1, 1, 0, 0};
+                    constexpr int NPROD = NPL == 3 ? 6 : 1;            // one-plane form: the product itself
+                    constexpr int APL[6] = {0, 2, 1, 0, 1, 0}, BPL[6] = {2, 0, 1, 1, 0, 0};
+                    if (QS && slot == NSLOT - 1) {                     // the wave's quarter of tap 24 (row block by select: no branch)
+                        bf16x8 aq[NPL];
+#pragma unroll
+                        for (int plane = 0; plane < NPL; ++plane) {            // dword by dword: a select of whole vectors became a
+                            const u32x4 x1 = __builtin_bit_cast(u32x4, a[1][plane]), x0 = __builtin_bit_cast(u32x4, a[0][plane]);
+                            u32x4 xs;                                          // run-time indexed stack array in the one-plane form
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) xs[e] = (wave & 2) ? x1[e] : x0[e];
+                            aq[plane] = __builtin_bit_cast(bf16x8, xs);
+                        }
+#pragma unroll
+                        for (int m = 0; m < NPROD; ++m)
+                            accq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[NPL == 3 ? APL[m] : 0], b[cur][NPL == 3 ? BPL[m] : 0], accq, 0, 0, 0);
+                    } else if (QS || (MODE == 2 ? wave + 4 * slot <= 24 : wave + 4 * t < G::NTILE)) {         // wave-uniform
 #pragma unroll
                         for (int m = 0; m < NPROD; ++m)
 #pragma unroll
@@ -500,8 +521,18 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_x3_kernel(WgX3P p) {
     float* slab = p.slab + (long)blockIdx.x * p.Ca * (p.Cb * 25);
     if constexpr (SH16) {
         // 16x16 block (rb, cb): lane holds column c16 of the block, rows 4 * g16 + r
+        if constexpr (MODE == 0) {                             // the wave's block (rb, cb) = (wave >> 1, wave & 1) of tap 24
+            const int b = cbq0 * 8 + (wave & 1) * 16 + c16;
+            if (b < p.Cb) {
 #pragma unroll
-        for (int t = 0; t < G::NBT; ++t) {
+                for (int r = 0; r < 4; ++r) {
+                    const int a = a0 + (wave >> 1) * 16 + g16 * 4 + r;
+                    if (a < p.Ca) slab[((long)a * 25 + 24) * p.Cb + b] = accq[r];
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < (MODE == 0 ? G::NBT - 1 : G::NBT); ++t) {
             const int tile = wave + 4 * t;
             if (MODE != 2 && tile >= G::NTILE) continue;
 #pragma unroll

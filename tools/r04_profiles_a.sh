@@ -12,3 +12,5 @@ bash tools/prof_noov.sh r04_noov > gpurun_out/r04/r04_bench_no_overlap_step_brea
 cp $(find gpurun_out/r04_noov -name "*kernel_stats.csv") gpurun_out/r04/r04_bench_no_overlap_kernel_stats.csv
 bash tools/prof_trace.sh r04_trace
 cp gpurun_out/r04_trace/step_trace.txt gpurun_out/r04/r04_step_trace_no_overlap.txt
+bash tools/prof_gaps.sh r04_gaps
+cp gpurun_out/r04_gaps/step_trace_two_stream.txt gpurun_out/r04/r04_step_trace_two_stream.txt
