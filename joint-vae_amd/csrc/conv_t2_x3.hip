@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256, 2) void convt2_x3_kernel(T2X3P p) {
                 const int h = t % 2, i2 = t / 2;
                 const int ir = row0 - 1 + lr, n = img0 + i2;
                 const bool live = ir >= 0 && ir < G::HS && n < p.N;
-                bf16x8 s[2][3];
+                f32x2 vv[8];
 #pragma unroll
                 for (int ci = 0; ci < 8; ++ci) {
                     f32x2 v = (live && kb * 16 + h * 8 + ci < p.C) ? rx[k][ci] : f32x2{0.f, 0.f};
@@ -151,18 +151,22 @@ __global__ __launch_bounds__(256, 2) void convt2_x3_kernel(T2X3P p) {
                         v[1] = fmaf(v[1], sc, sh);
                         if (p.aff.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); }
                     }
+                    vv[ci] = v;
+                }
+                u32x4 s[2][3];                      // [pixel][plane]: 8 channels = 4 packed pairs (x3_split2: two values at once)
+#pragma unroll
+                for (int cp = 0; cp < 4; ++cp)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
-                        __bf16 a, b, c;
-                        x3_split(v[j], a, b, c);
-                        s[j][0][ci] = a; s[j][1][ci] = b; s[j][2][ci] = c;
+                        unsigned hh, mm, ll;
+                        x3_split2(f32x2{vv[2 * cp][j], vv[2 * cp + 1][j]}, hh, mm, ll);
+                        s[j][0][cp] = hh; s[j][1][cp] = mm; s[j][2][cp] = ll;
                     }
-                }
                 const int base = (i2 * 2 + h) * G::CH + lr * G::WP + 1 + 2 * xp;
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) Xs[pl * G::XS + base + j] = __builtin_bit_cast(u32x4, s[j][pl]);
+                    for (int j = 0; j < 2; ++j) Xs[pl * G::XS + base + j] = s[j][pl];
             }
         }
     };

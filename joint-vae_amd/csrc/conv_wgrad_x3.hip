@@ -301,7 +301,7 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_x3_kernel(WgX3P p) {
     // sc / sh: the item's (scale, shift) in LDS (ctab) - or, with REGC (stride 2), in registers (creg: loaded once per kernel)
     auto split_store = [&](const f32x2 (&r)[8], bool live, int nch, const float* sc, const float* sh, int relu,
                            bool aff, u32x4* dst0, u32x4* dst1, int plane_stride, const float (&creg)[16]) {
-        bf16x8 s[2][3];
+        f32x2 vv[8];
 #pragma unroll
         for (int ci = 0; ci < 8; ++ci) {
             f32x2 v = (live && ci < nch) ? r[ci] : f32x2{0.f, 0.f};
@@ -318,17 +318,21 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_x3_kernel(WgX3P p) {
                 v[1] = fmaf(v[1], sc[ci], sh[ci]);
                 if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); }
             }
+            vv[ci] = v;
+        }
+        u32x4 s[2][3];                              // [pixel][plane]: 8 channels = 4 packed pairs (x3_split2: two values at once)
+#pragma unroll
+        for (int cp = 0; cp < 4; ++cp)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                __bf16 a, b, c;
-                x3_split(v[j], a, b, c);
-                s[j][0][ci] = a; s[j][1][ci] = b; s[j][2][ci] = c;
+                unsigned hh, mm, ll;
+                x3_split2(f32x2{vv[2 * cp][j], vv[2 * cp + 1][j]}, hh, mm, ll);
+                s[j][0][cp] = hh; s[j][1][cp] = mm; s[j][2][cp] = ll;
             }
-        }
 #pragma unroll
         for (int plane = 0; plane < 3; ++plane) {
-            dst0[plane * plane_stride] = __builtin_bit_cast(u32x4, s[0][plane]);
-            dst1[plane * plane_stride] = __builtin_bit_cast(u32x4, s[1][plane]);
+            dst0[plane * plane_stride] = s[0][plane];
+            dst1[plane * plane_stride] = s[1][plane];
         }
     };
     auto lstore = [&](int item) {                  // item: the work item whose data sits in rq / rp

@@ -242,6 +242,7 @@ __global__ __launch_bounds__(256, 2) void conv5_x3_kernel(X3P p) {
         // deferred BatchNorm: (scale, shift) of this wave's 8 channels as scalars (uniform addresses in the constant address space)
         typedef const __attribute__((address_space(4))) float* const_f32_p;
         float csc[8], csh[8];
+        const float relu_lo = p.aff.relu ? 0.f : -__builtin_inff();
         if constexpr (AFF) {
             const const_f32_p gsc = (const_f32_p)(unsigned long long)p.aff.sc, gsh = (const_f32_p)(unsigned long long)p.aff.sh;
 #pragma unroll
@@ -262,30 +263,33 @@ __global__ __launch_bounds__(256, 2) void conv5_x3_kernel(X3P p) {
                 // out-of-image rows / missing images / channels were loaded from a stand-in address: exact zeros
                 const int ir = in_row0 + lr, n = img0 + im;
                 const bool live = ir >= 0 && ir < p.H && n < p.N;
-                bf16x8 s[2][3];
+                f32x2 vv[8];                                               // [channel](pixel 0, pixel 1)
 #pragma unroll
                 for (int ci = 0; ci < 8; ++ci) {
                     const bool keep = live && kb * 16 + h * 8 + ci < p.Cin;
-                    f32x2 v = keep ? rx[k][ci] : f32x2{0.f, 0.f};
-                    if constexpr (AFF) {
-                        f32x2 a{fmaf(v[0], csc[ci], csh[ci]), fmaf(v[1], csc[ci], csh[ci])};
-                        if (p.aff.relu) { a[0] = fmaxf(a[0], 0.f); a[1] = fmaxf(a[1], 0.f); }
-                        v = keep ? a : f32x2{0.f, 0.f};                    // padding rows / missing channels stay exact zeros
+                    f32x2 v = rx[k][ci];                                   // (a stand-in value where !keep: replaced below)
+                    if constexpr (AFF) {                                   // ReLU as max(., lo) with lo = 0 or -inf: no select
+                        v = f32x2{fmaxf(fmaf(v[0], csc[ci], csh[ci]), relu_lo), fmaxf(fmaf(v[1], csc[ci], csh[ci]), relu_lo)};
                     }
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        __bf16 a, b, c;
-                        x3_split(v[j], a, b, c);
-                        s[j][0][ci] = a; s[j][1][ci] = b; s[j][2][ci] = c;
-                    }
+                    vv[ci] = keep ? v : f32x2{0.f, 0.f};                   // padding rows / missing channels stay exact zeros
                 }
+                u32x4 s[2][3];                                             // [pixel][plane]: 8 channels = 4 packed pairs
+#pragma unroll
+                for (int cp = 0; cp < 4; ++cp)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                    {
+                        unsigned hh, mm, ll;
+                        x3_split2(f32x2{vv[2 * cp][j], vv[2 * cp + 1][j]}, hh, mm, ll);
+                        s[j][0][cp] = hh; s[j][1][cp] = mm; s[j][2][cp] = ll;
+                    }
                 // (DI: input column 2*xp + j is padded column 2*xp + 4 + j = index xp + 2 of half j)
                 const int base = (im * 2 + h) * G::CH + lr * G::WP + (G::DI ? xp + 2 : 4 + 2 * xp);
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
-                        Xs[pl * G::XS + base + j * (G::DI ? G::WPH : 1)] = __builtin_bit_cast(u32x4, s[j][pl]);
+                        Xs[pl * G::XS + base + j * (G::DI ? G::WPH : 1)] = s[j][pl];
             }
         }
     };

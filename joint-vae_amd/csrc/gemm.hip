@@ -11,6 +11,7 @@
 // the 1x1 -> kxk first transposed conv of the upsampler, and the generic (im2col) convolution path.
 #include <stdlib.h>
 #include "common.h"
+#include "conv_x3.h"
 #include "jvae_internal.h"
 #include "conv_dispatch.h"
 
@@ -220,19 +221,14 @@ typedef __attribute__((address_space(3))) gx_bf16x4 gx_lds_bf16x4;
 constexpr int BKX = 32;              // K step: 32 keeps the images at 32 KB -> four workgroups per CU (the products here are
                                      // latency-bound: few tiles, short K slices)
 
+// (round 4: two values per conversion / residual instruction - x3_split2, conv_x3.h; the same bits as the scalar form)
 __device__ __forceinline__ void gx_split4(const f32x4& v, gx_u32x2 (&out)[3]) {
-    gx_bf16x4 h, m, l;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const __bf16 a = (__bf16)v[j];
-        float r = v[j] - (float)a;
-        const __bf16 b = (__bf16)r;
-        r -= (float)b;
-        h[j] = a; m[j] = b; l[j] = (__bf16)r;
+    for (int j = 0; j < 2; ++j) {
+        unsigned h, m, l;
+        x3_split2(x3_f32x2{v[2 * j], v[2 * j + 1]}, h, m, l);
+        out[0][j] = h; out[1][j] = m; out[2][j] = l;
     }
-    out[0] = __builtin_bit_cast(gx_u32x2, h);
-    out[1] = __builtin_bit_cast(gx_u32x2, m);
-    out[2] = __builtin_bit_cast(gx_u32x2, l);
 }
 
 template <bool KC>           // KC: the operand is k-contiguous ([row][k] image), else [k][row]
