@@ -246,7 +246,7 @@ struct GxImg {
 // 64 x 64 tiles ((64 + 64) K operand elements per 64 * 64 * K multiplications: the 7x7 head's forward moves 205 MB for 32 MB of
 // distinct data).  JVAE_GEMM_DEPTH=1 selects the one-stage form.
 template <bool AK, bool BNC, int DEPTH = 1>
-__global__ __launch_bounds__(256, 4) void gemm_x3_kernel(GemmP p) {
+__global__ __launch_bounds__(256, DEPTH > 1 ? 3 : 4) void gemm_x3_kernel(GemmP p) {
     using IA = GxImg<AK>;
     using IB = GxImg<!BNC>;
     constexpr int BM = 64, BN = 64, G4 = BM * BKX / 4 / 256;   // float4 groups per thread and operand
@@ -381,17 +381,32 @@ __global__ __launch_bounds__(256, 4) void gemm_x3_kernel(GemmP p) {
         // prologue: DEPTH steps in flight (steps beyond kend load the stand-in address: harmless, never stored)
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) gload(d, kbeg + d * BKX);
-        for (int k0 = kbeg; k0 < kend; k0 += DEPTH * BKX) {
+        // Round 4: the rounds of DEPTH full steps run in a loop WITHOUT branches, the 0 ... DEPTH-1 remaining steps behind it.  With
+        // `if (kk < kend)` around every step the loop header was a join of paths with different numbers of loads in flight, and the
+        // compiler put s_waitcnt vmcnt(0) in front of the first stage's LDS stores: every third K step waited for the loads that
+        // had just been issued for three steps ahead - the deep prefetch was one step deep (tools/e4_probe.py: 37 us for the 7x7
+        // head's product, MFMA busy 0.20, and nothing inside the step mattered).
+        const int nst = (kend - kbeg + BKX - 1) / BKX;
+        int k0 = kbeg;
+        for (int it = 0; it < nst / DEPTH; ++it, k0 += DEPTH * BKX) {
 #pragma unroll
             for (int d = 0; d < DEPTH; ++d) {
                 const int kk = k0 + d * BKX;
-                if (kk < kend) {                         // block-uniform
-                    __syncthreads();                     // previous tile's fragment reads are done
-                    lstore(d, kk);
-                    __syncthreads();
-                    gload(d, kk + DEPTH * BKX);          // stage d is free again: three steps ahead, under the MFMAs below
-                    multiply();
-                }
+                __syncthreads();                         // previous tile's fragment reads are done
+                lstore(d, kk);
+                __syncthreads();
+                gload(d, kk + DEPTH * BKX);              // stage d is free again: three steps ahead, under the MFMAs below
+                multiply();
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < DEPTH - 1; ++d) {            // (the loads issued for steps beyond kend read the stand-in address)
+            const int kk = k0 + d * BKX;
+            if (kk < kend) {                             // block-uniform
+                __syncthreads();
+                lstore(d, kk);
+                __syncthreads();
+                multiply();
             }
         }
     } else {
