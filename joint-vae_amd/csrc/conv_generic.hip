@@ -267,10 +267,11 @@ int jvae_fold_fwd(const ConvGeom& g, const float* xb, const float* w, const floa
             if (ws_bytes < 4 * (size_t)(colf + want * outf)) return JVAE_EWORKSPACE;
             float* part = ws + colf;
             int S = 0;
+            // partial products as [slice][q][n][cs] (rows of cs: coalesced stores), folded into ys[n][cs][q]
             int rc = jvae_gemm_launch_part(g.N, g.Cs, Kd, Ps, ws, Kd, 1, (long)g.N * Kd, w, 1, Kd, 0,
-                                           part, (long)g.Cs * Ps, Ps, 1, outf, want, &S, st);
+                                           part, g.Cs, 1, (long)g.N * g.Cs, outf, want, &S, st);
             if (rc) return rc;
-            return jvae_splitk_fold(part, bias, ys, S, outf, g.Cs, 0, 0, st, Ps);
+            return jvae_splitk_fold_qn(part, bias, ys, S, g.N, g.Cs, Ps, st);
         }
         return jvae_gemm_launch(g.N, g.Cs, Kd, Ps, ws, Kd, 1, (long)g.N * Kd, w, 1, Kd, 0,
                                 ys, (long)g.Cs * Ps, Ps, 1, bias, bias ? 1 : 0, 0, 1, st);

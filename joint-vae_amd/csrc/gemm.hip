@@ -246,7 +246,7 @@ struct GxImg {
 // 64 x 64 tiles ((64 + 64) K operand elements per 64 * 64 * K multiplications: the 7x7 head's forward moves 205 MB for 32 MB of
 // distinct data).  JVAE_GEMM_DEPTH=1 selects the one-stage form.
 template <bool AK, bool BNC, int DEPTH = 1>
-__global__ __launch_bounds__(256, DEPTH > 1 ? 3 : 4) void gemm_x3_kernel(GemmP p) {
+__global__ __launch_bounds__(256, 4) void gemm_x3_kernel(GemmP p) {
     using IA = GxImg<AK>;
     using IB = GxImg<!BNC>;
     constexpr int BM = 64, BN = 64, G4 = BM * BKX / 4 / 256;   // float4 groups per thread and operand
@@ -582,6 +582,32 @@ __global__ __launch_bounds__(256) void splitk_fold_kernel(const float* __restric
         if (accumulate) v += y[i];
         y[i] = relu ? fmaxf(v, 0.f) : v;
     }
+}
+
+// The same for partial products stored [slice][position q][image n][channel cs] - rows of cs: the product's lanes run along cs, so its
+// stores are 128-byte segments; in the OUTPUT's own layout [n][cs][q] they were 4-byte stores 4 * Ps bytes apart (26 MB of
+// partial-sector writes for 6.5 MB of partial products, ~6 of the 36 us of the 7x7 head's forward product) - folded into
+// y[n][cs][q] = bias[cs] + sum_s part[s][q][n][cs]: coalesced reads, the small output written with the stride.
+__global__ __launch_bounds__(256) void splitk_fold_qn_kernel(const float* __restrict__ part, const float* __restrict__ bias,
+                                                             float* __restrict__ y, int S, int N, int Cs, int Ps) {
+    const long total = (long)Ps * N * Cs;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cs = (int)(i % Cs);
+        const long r = i / Cs;
+        const int n = (int)(r % N), q = (int)(r / N);
+        float v = bias ? bias[cs] : 0.f;
+        for (int s = 0; s < S; ++s) v += part[(long)s * total + i];
+        y[((long)n * Cs + cs) * Ps + q] = v;
+    }
+}
+
+int jvae_splitk_fold_qn(const float* part, const float* bias, float* y, int S, int N, int Cs, int Ps, hipStream_t st) {
+    const long total = (long)Ps * N * Cs;
+    if (total == 0) return 0;
+    const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipLaunchKernelGGL(splitk_fold_qn_kernel, dim3(blocks), dim3(256), 0, st, part, bias, y, S, N, Cs, Ps);
+    JVAE_LAUNCH_CHECK();
+    return 0;
 }
 
 int jvae_splitk_fold(const float* part, const float* bias, float* y, int S, long MN, int N, int relu, int accumulate,

@@ -19,6 +19,7 @@ int jvae_gemm_launch_ex(int M, int N, int K, int batch,
 
 // y[i] = [relu]([y[i] +] bias[i % N] + sum_s part[s][i]): fixed-order fold of S partial products (gemm.hip)
 // bias index = (i / bias_div) % N
+int jvae_splitk_fold_qn(const float* part, const float* bias, float* y, int S, int N, int Cs, int Ps, hipStream_t st);
 int jvae_splitk_fold(const float* part, const float* bias, float* y, int S, long MN, int N, int relu, int accumulate,
                      hipStream_t st, int bias_div = 1);
 
