@@ -209,9 +209,10 @@ inline int fwd_slices(const ConvGeom& g) {
     const long Kd = (long)g.Cb * g.KH * g.KW;
     const long tiles = (long)cdiv(g.N, 64) * cdiv(g.Cs, 64) * g.Hs * g.Ws;
     if (tiles >= 512 || Kd < 1024) return 1;
-    // at most one residency round (2 workgroups x 256 CUs of gemm_x3_kernel); measured neutral against one slice more
-    // (features.12 of conv32: 36.9 vs 36.4 us) - one partial result less to fold
-    int s = (int)(512 / tiles);
+    // one residency round of FOUR workgroups per CU: the phases of a K step (loads, split + LDS stores, fragment reads + MFMAs) run
+    // one after the other inside a workgroup, so it takes several of them per SIMD to keep the matrix pipe fed (round 4, with the
+    // coalesced partial-product layout: features.12 of conv32 51.4 -> 50.1 us against the two-per-CU choice of round 3)
+    int s = (int)(1024 / tiles);
     return s > 8 ? 8 : (s < 1 ? 1 : s);
 }
 
