@@ -408,7 +408,7 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_x3_kernel(WgX3P p) {
         __syncthreads();                           // every wave is past the fragments of the previous item
         lstore(item);
         __syncthreads();
-        if (item + 1 < item_end) gload(item + 1);
+        if (!SH16 && item + 1 < item_end) gload(item + 1);
         if constexpr (SH16) {
             // slots = (K step of 32 pixels, tile, 16-column block): the fragments of the next slot are read before the 12
             // MFMAs (2 row blocks x 6 products) of the current one are issued
@@ -444,6 +444,11 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_x3_kernel(WgX3P p) {
             };
             read_a(0);
             read_b(0, 0, b[0]);
+            // the next item's global loads (24 of them, with their address arithmetic) are issued BEHIND the item's first fragment
+            // reads, whose LDS round trip they cover (round 4, as the weight staging in conv_x3.hip)
+            __builtin_amdgcn_sched_barrier(0);
+            if (item + 1 < item_end) gload(item + 1);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
