@@ -309,7 +309,11 @@ def test_linear(act):
 
 AFF_CONVS = [(32, 32, 5, 2, 2, 0, False, 32), (32, 64, 5, 1, 2, 0, False, 16), (64, 64, 5, 1, 2, 0, True, 8),
              (64, 64, 5, 2, 2, 1, True, 8), (32, 32, 5, 2, 2, 1, True, 16), (32, 32, 5, 1, 2, 0, True, 32),
-             (32, 3, 5, 1, 2, 0, False, 32), (64, 32, 5, 1, 2, 0, True, 16)]
+             (32, 3, 5, 1, 2, 0, False, 32), (64, 32, 5, 1, 2, 0, True, 16),
+             # channel counts that are no multiples of the 16-channel K step / 8-channel staging block / 32-channel output block
+             # (round 4: the staging clamps the channel address and the coefficient index of the missing channels)
+             (24, 32, 5, 1, 2, 0, False, 16), (48, 40, 5, 1, 2, 0, False, 16), (17, 33, 5, 1, 2, 0, False, 8),
+             (40, 32, 5, 2, 2, 0, False, 16)]
 
 
 @pytest.mark.parametrize('cin,cout,k,s,p,op,tr,H', AFF_CONVS)
