@@ -59,6 +59,7 @@ struct X3P {
     int N, Cin, H, W, OP, P, CoutReal;
     float* stats;        // optional (CoutReal, gridDim.x, 2)
     InAff aff;           // deferred BatchNorm(+ReLU) of the input (sc == nullptr: none)
+    int tpw;             // tiles per workgroup (16x16x32 form: 1 or 2 consecutive tiles; gridDim.x * tpw = number of tiles)
 #ifdef JVAE_X3_STAMPS
     unsigned long long* dbg;   // DIAGNOSTIC BUILD ONLY (tools/x3_stamps.py): 96 s_memtime stamps of wave 0 per workgroup
 #endif
@@ -142,9 +143,14 @@ __global__ __launch_bounds__(256, 2) void conv5_x3_kernel(X3P p) {
     // of ONE image - which share their halo rows - used to sit on different XCDs and every halo row came from HBM again
     // (profiles/r02_x3_fwd_pmc.json: 188 MB read for 134 MB of input).  Workgroup w = (xcd, k) takes tile xcd * (tiles / 8) + k:
     // neighbouring tiles run on the same XCD at about the same time, the halo is an L2 hit.
-    const int bx = xcd_tile(blockIdx.x, gridDim.x);
-    const int img0 = (G::OHW >= G::PIX) ? bx / TILES_PER_IMG : bx * G::NIMG;
-    const int row0 = (G::OHW >= G::PIX) ? (bx % TILES_PER_IMG) * G::TH : 0;
+    // Two tiles per workgroup (16x16x32 form, p.tpw = 2; round 4): consecutive tiles, so that the second tile's first patch and
+    // first weight groups are loaded under the last weight groups of the first one and its prologue (entry, address set-up, zero
+    // fill, the round trip of the first loads: 3 500 of a tile's 63 000 cycles) is paid once.
+    const int TPW = SH ? p.tpw : 1;
+    int bx = xcd_tile(blockIdx.x, gridDim.x) * TPW;
+    const int ntiles = gridDim.x * TPW;
+    int img0 = (G::OHW >= G::PIX) ? bx / TILES_PER_IMG : bx * G::NIMG;
+    int row0 = (G::OHW >= G::PIX) ? (bx % TILES_PER_IMG) * G::TH : 0;
     const int o0 = blockIdx.y * 32;
     const int KB = (p.Cin + 15) / 16;
     const int NG = KB * G::GPK;                                // weight groups: (K step, kernel row | group of 2 tap pairs)
@@ -185,7 +191,7 @@ __global__ __launch_bounds__(256, 2) void conv5_x3_kernel(X3P p) {
             for (int r = 0; r < 16; ++r) { acc[b][r] = 0.f; acs[b][r] = 0.f; }
     }
 
-    const int in_row0 = row0 * S - p.P;
+    int in_row0 = row0 * S - p.P;
     constexpr int W2 = G::WIN / 2;
     // Staging items = (2 pixels x 8 channels).  The 8-channel block `hq` of an item is WAVE-UNIFORM (round 4): waves 0, 1 stage
     // block 0, waves 2, 3 block 1, each pair walking the PERH (image, row, pixel pair) items of its block in XU passes of 128 - so
@@ -203,24 +209,30 @@ __global__ __launch_bounds__(256, 2) void conv5_x3_kernel(X3P p) {
     // LDS): with branches around them the compiler cannot count outstanding loads and falls back to vmcnt(0).  Their
     // addresses are computed once: per K step / weight group only a uniform stride is added.
     const float* xsrc[XU];
+    const float* xsrcN[XU];                                    // ... of the workgroup's next tile
     const u32x4* wsrc[WU];
     const long cstride = (long)p.H * p.W;
+    auto tile_src = [&](int timg0, int tin_row0, const float* (&dst)[XU]) {
 #pragma unroll
-    for (int k = 0; k < XU; ++k) {
-        const int u = (tid & 127) + k * 128;
-        const int xp = u % W2;
-        const int t = u / W2;
-        const int lr = t % G::ROWS, im = t / G::ROWS;
-        const int ir = in_row0 + lr, n = img0 + im;
-        const bool ok = u < PERH && ir >= 0 && ir < p.H && n < p.N;
-        xsrc[k] = p.in + (((long)(ok ? n : 0) * p.Cin + hq * 8) * p.H + (ok ? ir : 0)) * p.W + 2 * xp;
-    }
+        for (int k = 0; k < XU; ++k) {
+            const int u = (tid & 127) + k * 128;
+            const int xp = u % W2;
+            const int t = u / W2;
+            const int lr = t % G::ROWS, im = t / G::ROWS;
+            const int ir = tin_row0 + lr, n = timg0 + im;
+            const bool ok = u < PERH && ir >= 0 && ir < p.H && n < p.N;
+            dst[k] = p.in + (((long)(ok ? n : 0) * p.Cin + hq * 8) * p.H + (ok ? ir : 0)) * p.W + 2 * xp;
+        }
+    };
+    tile_src(img0, in_row0, xsrc);
+#pragma unroll
+    for (int k = 0; k < XU; ++k) xsrcN[k] = xsrc[k];
 #pragma unroll
     for (int k = 0; k < WU; ++k) {
         const int u = min(tid + k * 256, G::WGS - 1);          // the tail threads re-read the last unit (not stored)
         wsrc[k] = p.wp + (long)(u / 32) * p.OP + o0 + u % 32;
     }
-    auto gloadX = [&](int kb) {
+    auto gloadX = [&](int kb, bool next_tile = false) {
         // channels beyond Cin: a clamped (valid) channel is loaded instead and zeroed in lstoreX - pure address arithmetic on
         // wave-uniform values, so that the loads stay unconditional (a per-lane select between two ADDRESSES was compiled into
         // branches around the loads with a vmcnt(0) behind each: 16 serialised round trips in the prologue)
@@ -228,7 +240,8 @@ __global__ __launch_bounds__(256, 2) void conv5_x3_kernel(X3P p) {
         const int cm = cmax < 0 ? 0 : (cmax > 7 ? 7 : cmax);
 #pragma unroll
         for (int k = 0; k < XU; ++k) {
-            const float* src = cmax < 0 ? xsrc[k] : xsrc[k] + (long)kb * 16 * cstride;
+            const float* base = next_tile ? xsrcN[k] : xsrc[k];       // (uniform select)
+            const float* src = cmax < 0 ? base : base + (long)kb * 16 * cstride;
 #pragma unroll
             for (int ci = 0; ci < 8; ++ci)
                 rx[k][ci] = *reinterpret_cast<const f32x2*>(src + (long)(ci < cm ? ci : cm) * cstride);
@@ -409,96 +422,10 @@ __global__ __launch_bounds__(256, 2) void conv5_x3_kernel(X3P p) {
     // LDS-only barrier: __syncthreads() also waits for vmcnt(0), i.e. for the global prefetches in flight
     auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
 
-    X3_STAMP(1);                                   // 0 = kernel entry (below the declarations), 1 = zero fill issued
-    gloadX(0);
-    gloadW(0);
-    // The halo COLUMNS (4 units left of the image row, WP - 4 - WIN right of it) are zeroed once and never written again;
-    // every other cell - out-of-image rows, missing images and channels included - is rewritten by lstoreX at every K step.
-    // Issued behind the first global loads (they fly meanwhile).  Round 4: the whole 46 KB image used to be cleared, in front
-    // of the loads: 2 200 of a workgroup's 73 500 cycles (tools/x3_stamps.py).
-    if constexpr (G::DI) {
-        for (int i = tid; i < 3 * G::XS; i += 256) Xs[i] = u32x4{0u, 0u, 0u, 0u};     // (de-interleaved image: all of it)
-    } else {
-        constexpr int HALO = G::WP - G::WIN, NROW = 3 * G::NIMG * 2 * G::ROWS;
-        for (int i = tid; i < NROW * HALO; i += 256) {
-            const int r = i / HALO, c = i % HALO;
-            const int pl = r / (G::NIMG * 2 * G::ROWS), rr = r % (G::NIMG * 2 * G::ROWS);
-            Xs[pl * G::XS + rr * G::WP + (c < 4 ? c : c + G::WIN)] = u32x4{0u, 0u, 0u, 0u};
-        }
-    }
-    __syncthreads();                               // halo zero fill + coefficient table complete
-    X3_STAMP(2);
-    lstoreX(0);
-    lstoreW(0);
-    __builtin_amdgcn_sched_barrier(0);
-    if (NG > 1) gloadW(1);
-    lds_barrier();
-    X3_STAMP(3);
-    if constexpr (SH) {
-        // 16x16x32 form: K steps outside, the GPK - 1 two-pair groups of a K step inside, its one-pair group with the K-step change
-        // behind them - so that the registers of the next patch (rx: loaded at the start of the one-pair group, split and stored
-        // behind it) are live in that tail only and not across the two-pair code, which needs the room for its read-ahead
-        typedef std::integral_constant<int, 1> one_pair;
-        typedef std::integral_constant<int, 2> two_pairs;
-        int g = 0;
-        auto stageW = [&] {
-            // buffer (g+1)&1 was last read in group g-1: every wave is past it.  The store (which waits for the loads of
-            // rw) must stay ahead of the next loads: the scheduler would otherwise issue them first and wait for all.
-            if (g + 1 < NG) lstoreW((g + 1) & 1);
-            __builtin_amdgcn_sched_barrier(0);
-            if (g + 2 < NG) gloadW(g + 2);
-        };
-        for (int kb = 0; kb < KB; ++kb) {
-            // invariant: patch of K step kb in Xs, weight group g in buffer g&1, rw = weight group g+1 (in flight)
-            for (int kh = 0; kh < G::GPK - 1; ++kh, ++g) {
-                if (g < 14) X3_STAMP(8 + 4 * g);           // group start
-                computeSH(g & 1, kh, two_pairs{}, [&] {
-                    stageW();
-                    if (g < 14) X3_STAMP(9 + 4 * g);       // first fragment reads issued, weights stored, next loads issued
-                });
-                if (g < 14) X3_STAMP(10 + 4 * g);          // MFMAs issued
-                lds_barrier();
-                if (g < 14) X3_STAMP(11 + 4 * g);          // barrier passed
-            }
-            const bool nextk = kb + 1 < KB;
-            if (g < 14) X3_STAMP(8 + 4 * g);
-            computeSH(g & 1, G::GPK - 1, one_pair{}, [&] {
-                stageW();
-                if (nextk) gloadX(kb + 1);
-                if (g < 14) X3_STAMP(9 + 4 * g);
-            });
-            if (g < 14) X3_STAMP(10 + 4 * g);
-            lds_barrier();
-            if (g < 14) X3_STAMP(11 + 4 * g);
-            if (nextk) {                                   // K step change: the patch is fully consumed
-                lstoreX(kb + 1);
-                lds_barrier();
-                X3_STAMP(4);                               // (first) K step change done
-            }
-            ++g;
-        }
-    } else {
-        int kb = 0, kh = 0;
-        for (int g = 0; g < NG; ++g) {
-            // invariant: patch of K step kb in Xs, weight group g in buffer g&1, rw = weight group g+1 (in flight)
-            const bool more = g + 1 < NG, last_row = kh == G::GPK - 1;
-            if (more) lstoreW((g + 1) & 1);                // (order: see stageW above)
-            __builtin_amdgcn_sched_barrier(0);
-            if (g + 2 < NG) gloadW(g + 2);
-            if (kh == G::GPK - 2 && kb + 1 < KB) gloadX(kb + 1);
-            __builtin_amdgcn_sched_barrier(0);
-            compute(g & 1, kh * G::WP);
-            lds_barrier();
-            if (more && last_row) {                        // K step change: the patch is fully consumed
-                lstoreX(kb + 1);
-                lds_barrier();
-            }
-            if (++kh == G::GPK) { kh = 0; ++kb; }
-        }
-    }
-
-    X3_STAMP(5);                                   // main loop done
-    if constexpr (SH) {
+    // ---- epilogue of one tile, 16x16x32 form (called per tile; resets the accumulators)
+    __shared__ float red_s[SH ? 4 * 32 * 2 : 1];
+    auto epilogueSH = [&] {
+      if constexpr (SH) {
         // ---- epilogue, 16x16x32: lane holds pixel l15 of each 16-pixel tile, channels ct*16 + kq*4 + r
 #pragma unroll
         for (int b = 0; b < NPT; ++b)
@@ -536,7 +463,8 @@ __global__ __launch_bounds__(256, 2) void conv5_x3_kernel(X3P p) {
         }
         X3_STAMP(6);                               // output stores issued
         if (p.stats) {
-            float* red = reinterpret_cast<float*>(lds_raw);       // [4 waves][32][2]
+            float* red = red_s;                                   // [4 waves][32][2] (not the patch area: its halo cells stay zero
+                                                                  // for the workgroup's next tile)
             float sv[16];                                         // [sum | sum of squares][channel tile][register]
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct)
@@ -558,10 +486,134 @@ __global__ __launch_bounds__(256, 2) void conv5_x3_kernel(X3P p) {
                 float s1 = 0.f, s2 = 0.f;
 #pragma unroll
                 for (int w = 0; w < 4; ++w) { s1 += red[(w * 32 + tid) * 2]; s2 += red[(w * 32 + tid) * 2 + 1]; }
-                float* dst = p.stats + ((long)(o0 + tid) * gridDim.x + bx) * 2;
+                float* dst = p.stats + ((long)(o0 + tid) * ntiles + bx) * 2;
                 dst[0] = s1; dst[1] = s2;
             }
         }
+#pragma unroll
+        for (int b = 0; b < NPT; ++b)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { acc[b][ct][r] = 0.f; acs[b][ct][r] = 0.f; }
+      }
+    };
+
+    X3_STAMP(1);                                   // 0 = kernel entry (below the declarations), 1 = zero fill issued
+    gloadX(0);
+    gloadW(0);
+    // The halo COLUMNS (4 units left of the image row, WP - 4 - WIN right of it) are zeroed once and never written again;
+    // every other cell - out-of-image rows, missing images and channels included - is rewritten by lstoreX at every K step.
+    // Issued behind the first global loads (they fly meanwhile).  Round 4: the whole 46 KB image used to be cleared, in front
+    // of the loads: 2 200 of a workgroup's 73 500 cycles (tools/x3_stamps.py).
+    if constexpr (G::DI) {
+        for (int i = tid; i < 3 * G::XS; i += 256) Xs[i] = u32x4{0u, 0u, 0u, 0u};     // (de-interleaved image: all of it)
+    } else {
+        constexpr int HALO = G::WP - G::WIN, NROW = 3 * G::NIMG * 2 * G::ROWS;
+        for (int i = tid; i < NROW * HALO; i += 256) {
+            const int r = i / HALO, c = i % HALO;
+            const int pl = r / (G::NIMG * 2 * G::ROWS), rr = r % (G::NIMG * 2 * G::ROWS);
+            Xs[pl * G::XS + rr * G::WP + (c < 4 ? c : c + G::WIN)] = u32x4{0u, 0u, 0u, 0u};
+        }
+    }
+    __syncthreads();                               // halo zero fill + coefficient table complete
+    X3_STAMP(2);
+    lstoreX(0);
+    lstoreW(0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (NG > 1) gloadW(1);
+    lds_barrier();
+    X3_STAMP(3);
+    if constexpr (SH) {
+        // 16x16x32 form: K steps outside, the GPK - 1 two-pair groups of a K step inside, its one-pair group with the K-step change
+        // behind them - so that the registers of the next patch (rx: loaded at the start of the one-pair group, split and stored
+        // behind it) are live in that tail only and not across the two-pair code, which needs the room for its read-ahead
+        typedef std::integral_constant<int, 1> one_pair;
+        typedef std::integral_constant<int, 2> two_pairs;
+        int g = 0, gbase = 0;                          // group inside the tile; groups of the workgroup's earlier tiles
+        bool has_next = false;
+        auto stageW = [&] {
+            // buffer (gg+1)&1 was last read in group gg-1: every wave is past it.  The store (which waits for the loads of
+            // rw) must stay ahead of the next loads: the scheduler would otherwise issue them first and wait for all.  The group
+            // sequence runs on into the workgroup's next tile (whose weight groups are the same ones again).
+            const int gg = gbase + g;
+            if (g + 1 < NG || has_next) lstoreW((gg + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (g + 2 < NG || has_next) gloadW(g + 2 < NG ? g + 2 : g + 2 - NG);
+        };
+        for (int ti = 0; ti < TPW; ++ti) {
+            has_next = ti + 1 < TPW;
+            if (has_next) {                                // the next tile's coordinates and patch addresses
+                const int nb = bx + 1;
+                const int nimg0 = (G::OHW >= G::PIX) ? nb / TILES_PER_IMG : nb * G::NIMG;
+                const int nrow0 = (G::OHW >= G::PIX) ? (nb % TILES_PER_IMG) * G::TH : 0;
+                tile_src(nimg0, nrow0 * S - p.P, xsrcN);
+            }
+            g = 0;
+            for (int kb = 0; kb < KB; ++kb) {
+                // invariant: patch of K step kb in Xs, weight group g in buffer (gbase+g)&1, rw = the next weight group (in flight)
+                for (int kh = 0; kh < G::GPK - 1; ++kh, ++g) {
+                    if (g < 14) X3_STAMP(8 + 4 * g);           // group start
+                    computeSH((gbase + g) & 1, kh, two_pairs{}, [&] {
+                        stageW();
+                        if (g < 14) X3_STAMP(9 + 4 * g);       // first fragment reads issued, weights stored, next loads issued
+                    });
+                    if (g < 14) X3_STAMP(10 + 4 * g);          // MFMAs issued
+                    lds_barrier();
+                    if (g < 14) X3_STAMP(11 + 4 * g);          // barrier passed
+                }
+                const bool nextk = kb + 1 < KB;
+                if (g < 14) X3_STAMP(8 + 4 * g);
+                computeSH((gbase + g) & 1, G::GPK - 1, one_pair{}, [&] {
+                    stageW();
+                    if (nextk || has_next) gloadX(nextk ? kb + 1 : 0, !nextk);     // (the next tile's first patch behind the last K step)
+                    if (g < 14) X3_STAMP(9 + 4 * g);
+                });
+                if (g < 14) X3_STAMP(10 + 4 * g);
+                lds_barrier();
+                if (g < 14) X3_STAMP(11 + 4 * g);
+                if (nextk) {                                   // K step change: the patch is fully consumed
+                    lstoreX(kb + 1);
+                    lds_barrier();
+                    X3_STAMP(4);                               // (first) K step change done
+                }
+                ++g;
+            }
+            epilogueSH();                                      // (its LDS use is red_s; the stores drain under what follows)
+            if (has_next) {                                    // enter the next tile: its first patch sits in rx
+                gbase += NG;
+                ++bx;
+                img0 = (G::OHW >= G::PIX) ? bx / TILES_PER_IMG : bx * G::NIMG;
+                row0 = (G::OHW >= G::PIX) ? (bx % TILES_PER_IMG) * G::TH : 0;
+                in_row0 = row0 * S - p.P;
+#pragma unroll
+                for (int k = 0; k < XU; ++k) xsrc[k] = xsrcN[k];
+                lstoreX(0);
+                lds_barrier();
+            }
+        }
+    } else {
+        int kb = 0, kh = 0;
+        for (int g = 0; g < NG; ++g) {
+            // invariant: patch of K step kb in Xs, weight group g in buffer g&1, rw = weight group g+1 (in flight)
+            const bool more = g + 1 < NG, last_row = kh == G::GPK - 1;
+            if (more) lstoreW((g + 1) & 1);                // (order: see stageW above)
+            __builtin_amdgcn_sched_barrier(0);
+            if (g + 2 < NG) gloadW(g + 2);
+            if (kh == G::GPK - 2 && kb + 1 < KB) gloadX(kb + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(g & 1, kh * G::WP);
+            lds_barrier();
+            if (more && last_row) {                        // K step change: the patch is fully consumed
+                lstoreX(kb + 1);
+                lds_barrier();
+            }
+            if (++kh == G::GPK) { kh = 0; ++kb; }
+        }
+    }
+
+    X3_STAMP(5);                                   // main loop done
+    if constexpr (SH) {
         X3_STAMP(7);                               // end of the workgroup's program
         X3_STAMP_RT(65);
     } else {
@@ -648,12 +700,19 @@ int launch_x3(const X3P& p, hipStream_t st) {
     const long pixels = (long)p.N * G::OHW;
     dim3 grid((unsigned)((pixels + G::PIX - 1) / G::PIX), (unsigned)(p.OP / 32));
     if (G::OHW < G::PIX) grid.x = (unsigned)((p.N + G::NIMG - 1) / G::NIMG);
-    g_x3_splits = (int)grid.x;
-    if (p.aff.sc) {
-        if (p.Cin > 256) return JVAE_ENOTSUP;
-        hipLaunchKernelGGL((conv5_x3_kernel<S, OW, MT, true, SH>), grid, dim3(256), G::LDS_BYTES, st, p);
+    g_x3_splits = (int)grid.x;                                 // BatchNorm partial sums: one per TILE
+    // Two consecutive tiles per workgroup (16x16x32 form, stride 1) when that still leaves two residency rounds of 512 workgroups:
+    // the second tile's prologue hides under the first one's last weight groups.  JVAE_X3_TPW=1 switches it off (A/B).
+    static int tpw_on = -1;
+    if (tpw_on < 0) { const char* e = getenv("JVAE_X3_TPW"); tpw_on = (e && e[0] == '1') ? 0 : 1; }
+    X3P q = p;
+    q.tpw = 1;
+    if (SH && S == 1 && tpw_on && grid.x % 2 == 0 && (long)grid.x * grid.y >= 2048) { q.tpw = 2; grid.x /= 2; }
+    if (q.aff.sc) {
+        if (q.Cin > 256) return JVAE_ENOTSUP;
+        hipLaunchKernelGGL((conv5_x3_kernel<S, OW, MT, true, SH>), grid, dim3(256), G::LDS_BYTES, st, q);
     } else {
-        hipLaunchKernelGGL((conv5_x3_kernel<S, OW, MT, false, SH>), grid, dim3(256), G::LDS_BYTES, st, p);
+        hipLaunchKernelGGL((conv5_x3_kernel<S, OW, MT, false, SH>), grid, dim3(256), G::LDS_BYTES, st, q);
     }
     JVAE_LAUNCH_CHECK();
     return 0;
@@ -762,7 +821,7 @@ int jvae_conv5_x3_fwd(const float* in, const float* w, int swap, int flip, const
             if (rc) return rc;
         }
     }
-    X3P p{in, (const u32x4*)ws, bias, out, N, Cin, H, W, OP, P, Cout, stats, aff ? *aff : InAff{nullptr, nullptr, 0}};
+    X3P p{in, (const u32x4*)ws, bias, out, N, Cin, H, W, OP, P, Cout, stats, aff ? *aff : InAff{nullptr, nullptr, 0}, 1};
 #ifdef JVAE_X3_STAMPS
     p.dbg = g_x3_dbg;
 #endif
