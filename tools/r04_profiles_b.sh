@@ -9,7 +9,7 @@ cp $(find gpurun_out/r04_x3_fwd/trace -name "*kernel_stats.csv") gpurun_out/r04/
 bash tools/prof_kernel.sh r04_wgrad_x3 conv5_wgrad_x3_kernel tools/wgrad_probe.py > gpurun_out/r04/prof_wg.log 2>&1
 cp gpurun_out/r04_wgrad_x3/summary.json gpurun_out/r04/r04_wgrad_x3_pmc.json
 cp $(find gpurun_out/r04_wgrad_x3/trace -name "*kernel_stats.csv") gpurun_out/r04/r04_wgrad_x3_kernel_stats.csv
-JVAE_HIP_LIB=$R/joint-vae_amd/jvae_hip/libjvae_stamps.so python tools/x3_stamps.py > gpurun_out/r04/r04_x3_stamps_raw.txt 2>&1
+JVAE_X3_TPW=1 JVAE_HIP_LIB=$R/joint-vae_amd/jvae_hip/libjvae_stamps.so python tools/x3_stamps.py > gpurun_out/r04/r04_x3_stamps_raw.txt 2>&1
 python bench.py --workload 3 --no-cpu-baseline > gpurun_out/r04/r04_bench_cfg3.json 2>/dev/null
 python bench.py --workload 5 --dtype bf16 --no-cpu-baseline > gpurun_out/r04/r04_bench_cfg5_bf16.json 2>/dev/null
 python bench.py --workload 5 --dtype f32 --no-cpu-baseline > gpurun_out/r04/r04_bench_cfg5_f32.json 2>/dev/null
