@@ -143,11 +143,13 @@ __global__ __launch_bounds__(256, 2) void conv5_x3_kernel(X3P p) {
     // of ONE image - which share their halo rows - used to sit on different XCDs and every halo row came from HBM again
     // (profiles/r02_x3_fwd_pmc.json: 188 MB read for 134 MB of input).  Workgroup w = (xcd, k) takes tile xcd * (tiles / 8) + k:
     // neighbouring tiles run on the same XCD at about the same time, the halo is an L2 hit.
-    // Two tiles per workgroup (16x16x32 form, p.tpw = 2; round 4): consecutive tiles, so that the second tile's first patch and
+    // Two tiles per workgroup (16x16x32 form, p.tpw = 2; round 4), so that the second tile's first patch and
     // first weight groups are loaded under the last weight groups of the first one and its prologue (entry, address set-up, zero
     // fill, the round trip of the first loads: 3 500 of a tile's 63 000 cycles) is paid once.
+    // Its tiles are w and w + gridDim.x, NOT 2w and 2w + 1: the workgroups that run side by side then hold neighbouring tiles in both
+    // passes and share their halo rows in L2 (with consecutive tiles per workgroup the PMC passes read 172 MB instead of 136).
     const int TPW = SH ? p.tpw : 1;
-    int bx = xcd_tile(blockIdx.x, gridDim.x) * TPW;
+    int bx = xcd_tile(blockIdx.x, gridDim.x);
     const int ntiles = gridDim.x * TPW;
     int img0 = (G::OHW >= G::PIX) ? bx / TILES_PER_IMG : bx * G::NIMG;
     int row0 = (G::OHW >= G::PIX) ? (bx % TILES_PER_IMG) * G::TH : 0;
@@ -544,7 +546,7 @@ __global__ __launch_bounds__(256, 2) void conv5_x3_kernel(X3P p) {
         for (int ti = 0; ti < TPW; ++ti) {
             has_next = ti + 1 < TPW;
             if (has_next) {                                // the next tile's coordinates and patch addresses
-                const int nb = bx + 1;
+                const int nb = bx + gridDim.x;
                 const int nimg0 = (G::OHW >= G::PIX) ? nb / TILES_PER_IMG : nb * G::NIMG;
                 const int nrow0 = (G::OHW >= G::PIX) ? (nb % TILES_PER_IMG) * G::TH : 0;
                 tile_src(nimg0, nrow0 * S - p.P, xsrcN);
@@ -582,7 +584,7 @@ __global__ __launch_bounds__(256, 2) void conv5_x3_kernel(X3P p) {
             epilogueSH();                                      // (its LDS use is red_s; the stores drain under what follows)
             if (has_next) {                                    // enter the next tile: its first patch sits in rx
                 gbase += NG;
-                ++bx;
+                bx += gridDim.x;
                 img0 = (G::OHW >= G::PIX) ? bx / TILES_PER_IMG : bx * G::NIMG;
                 row0 = (G::OHW >= G::PIX) ? (bx % TILES_PER_IMG) * G::TH : 0;
                 in_row0 = row0 * S - p.P;
@@ -701,7 +703,7 @@ int launch_x3(const X3P& p, hipStream_t st) {
     dim3 grid((unsigned)((pixels + G::PIX - 1) / G::PIX), (unsigned)(p.OP / 32));
     if (G::OHW < G::PIX) grid.x = (unsigned)((p.N + G::NIMG - 1) / G::NIMG);
     g_x3_splits = (int)grid.x;                                 // BatchNorm partial sums: one per TILE
-    // Two consecutive tiles per workgroup (16x16x32 form, stride 1) when that still leaves two residency rounds of 512 workgroups:
+    // Two tiles per workgroup (16x16x32 form, stride 1) when that still leaves two residency rounds of 512 workgroups:
     // the second tile's prologue hides under the first one's last weight groups.  JVAE_X3_TPW=1 switches it off (A/B).
     static int tpw_on = -1;
     if (tpw_on < 0) { const char* e = getenv("JVAE_X3_TPW"); tpw_on = (e && e[0] == '1') ? 0 : 1; }
