@@ -59,7 +59,7 @@ struct X3P {
     int N, Cin, H, W, OP, P, CoutReal;
     float* stats;        // optional (CoutReal, gridDim.x, 2)
     InAff aff;           // deferred BatchNorm(+ReLU) of the input (sc == nullptr: none)
-    int tpw;             // tiles per workgroup (16x16x32 form: 1 or 2 consecutive tiles; gridDim.x * tpw = number of tiles)
+    int tpw;             // tiles per workgroup (16x16x32 form: 1, or 2 = tiles w and w + gridDim.x; gridDim.x * tpw = number of tiles)
 #ifdef JVAE_X3_STAMPS
     unsigned long long* dbg;   // DIAGNOSTIC BUILD ONLY (tools/x3_stamps.py): 96 s_memtime stamps of wave 0 per workgroup
 #endif
