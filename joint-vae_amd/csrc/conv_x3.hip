@@ -22,6 +22,10 @@
 //    staged per KERNEL ROW (5 taps, 15 KB) into a double-buffered LDS area: one barrier per 60 MFMAs, two workgroups
 //    per CU (77 KB each);
 //  * accumulators, bias, BatchNorm partial sums and the coalesced NCHW epilogue are those of the fp32 kernel.
+// Default since round 4 (maps up to 32 wide): the 16x16x32 form (template argument SH) - K = 2 consecutive taps x 16 channels per
+// MFMA, weights staged per group of two tap pairs, a wave-uniform channel block per staging item (the deferred BatchNorm's
+// coefficients are scalar operands), straight-line weight groups with their read-ahead, two tiles per workgroup on the large
+// launches: see the comments at computeSH, lstoreX and the tile loop, and DESIGN.md section 4.
 #include <stdlib.h>
 #include "common.h"
 #include "jvae_internal.h"
@@ -518,7 +522,7 @@ __global__ __launch_bounds__(256, 2) void conv5_x3_kernel(X3P p) {
             Xs[pl * G::XS + rr * G::WP + (c < 4 ? c : c + G::WIN)] = u32x4{0u, 0u, 0u, 0u};
         }
     }
-    __syncthreads();                               // halo zero fill + coefficient table complete
+    __syncthreads();                               // halo zero fill complete (it overlaps nothing lstoreX writes, but orders bias_s)
     X3_STAMP(2);
     lstoreX(0);
     lstoreW(0);
