@@ -374,16 +374,22 @@ def main():
         probe.armed = True
     # per-step HIP events on the launch stream (median / min are reported beside the contract's mean over the K steps)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
+    host_marks = [0.0] * (a.steps + 1)
     t0 = time.time()
     marks[0].record()
+    host_marks[0] = t0
     for i in range(a.steps):
         losses, meas = one_step(i, meas)
         marks[i + 1].record()
+        host_marks[i + 1] = time.time()
     sync()
     dt = time.time() - t0
     if probe is not None:
         probe.armed = False
-    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps))
+    # in launch order (which step is the slow one must stay visible); sorted only for the median / min below
+    per_step_order = [marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps)]
+    per_step_host = [(host_marks[i + 1] - host_marks[i]) * 1e3 for i in range(a.steps)]
+    per_step = sorted(per_step_order)
     if dist is not None:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -406,6 +412,10 @@ def main():
                'unit': 'images/s', 'n_gpus': world,
                'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': dt / a.steps * 1e3,
                'ms_per_step_median': per_step[len(per_step) // 2], 'ms_per_step_min': per_step[0],
+               'ms_per_step_max': per_step[-1],
+               'per_step_ms': [round(t, 4) for t in per_step_order],
+               'per_step_host_enqueue_ms': [round(t, 4) for t in per_step_host],
+               'drain_ms_after_last_enqueue': round((t0 + dt - host_marks[-1]) * 1e3, 4),
                'timing': 'value / ms_per_step: wall clock over the K steps between barrier+synchronize (max over ranks); '
                          'median / min: HIP events around every step on the launch stream of rank 0',
                'higher_is_better': True,

@@ -172,6 +172,14 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
     return red[16];
 }
 
+// Activation kinds of the `relu` / `in_relu` arguments of the C ABI (include/jvae_hip.h): 0 = none, 1 = ReLU, 2 = leaky ReLU with
+// PyTorch's default negative slope - the reference's activation='leaky' is nn.LeakyReLU() (module/vae_layers/misc.py:24-27).
+// max(x, slope * x) is x for x > 0 and slope * x otherwise: the same product and the same bits as torch's select.
+#define JVAE_ACT_NONE 0
+#define JVAE_ACT_RELU 1
+#define JVAE_ACT_LEAKY 2
+#define JVAE_LEAKY_SLOPE 0.01f
+
 // a = [relu](v*s + t) on a float4 (deferred BatchNorm of a convolution input; the same fmaf as bn_coef / bn_apply_kernel,
 // so the ReLU mask BatchNorm-backward recomputes is the one applied here)
 __device__ __forceinline__ f32x4 aff4(f32x4 v, float s, float t, int relu) {

@@ -798,10 +798,11 @@ bool jvae_conv5_x3_ok(int Cin, int H, int W, int Cout, int OH, int OW, int S, in
     return jvae_conv5_fwd_ok(Cin, H, W, Cout, OH, OW, S, P);
 }
 
-// bytes of the larger of the two packed forms (kernel-row groups / tap-pair groups)
+// bytes of the largest of the packed forms (kernel-row groups / tap-pair groups / position-sorted taps of the 4-phase kernel)
 size_t jvae_conv5_x3_pack_bytes(int Cin, int Cout) {
     const size_t a = jvae_pack_bytes(JVAE_PACK_X3, Cin, Cout), b = jvae_pack_bytes(JVAE_PACK_X3S, Cin, Cout);
-    return a > b ? a : b;
+    const size_t c = jvae_pack_bytes(JVAE_PACK_T2S, Cin, Cout);      // (conv_t2_x3.hip's 32-channel K step)
+    return a > b ? (a > c ? a : c) : (b > c ? b : c);
 }
 
 static int x3s_wpack(const float* w, float* ws, int C, int O, int swap, int flip, hipStream_t st) {

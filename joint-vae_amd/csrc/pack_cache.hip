@@ -68,6 +68,7 @@ __global__ __launch_bounds__(256) void pack_refresh_kernel(PackTable t) {
         else if (kind == JVAE_PACK_X3) jvae_pack_x3_elem(en.w, (__bf16*)en.dst, i, en.C, en.O, swap, flip);
         else if (kind == JVAE_PACK_X3S) jvae_pack_x3s_elem(en.w, (__bf16*)en.dst, i, en.C, en.O, swap, flip);
         else if (kind == JVAE_PACK_SCI) jvae_pack_sci_elem(en.w, (float*)en.dst, i, en.C, en.O, swap, flip);
+        else if (kind == JVAE_PACK_T2S) jvae_pack_t2s_elem(en.w, (__bf16*)en.dst, i, en.C, en.O, swap, flip);
         else jvae_pack_b8_elem(en.w, (__bf16*)en.dst, i, en.C, en.O, swap, flip);
     }
 }

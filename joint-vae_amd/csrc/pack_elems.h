@@ -5,7 +5,7 @@
 #include "common.h"
 #include "conv_x3.h"
 
-enum JvaePackKind { JVAE_PACK_F32 = 0, JVAE_PACK_X3 = 1, JVAE_PACK_B8 = 2, JVAE_PACK_X3S = 3, JVAE_PACK_SCI = 4 };
+enum JvaePackKind { JVAE_PACK_F32 = 0, JVAE_PACK_X3 = 1, JVAE_PACK_B8 = 2, JVAE_PACK_X3S = 3, JVAE_PACK_SCI = 4, JVAE_PACK_T2S = 5 };
 
 // tap pairs per K step of the 16x16x32 split-bf16 layout: 25 taps = 12 pairs + tap 24 with an all-zero partner, + one all-zero
 // pair so that every staging group of the kernel (2 pairs) is complete
@@ -19,11 +19,12 @@ __host__ __device__ __forceinline__ long jvae_pack_elems(int kind, int C, int O)
     if (kind == JVAE_PACK_F32) return (long)C * 25 * OP;
     if (kind == JVAE_PACK_SCI) return (long)((O + 7) / 8) * C * 25 * 8;
     if (kind == JVAE_PACK_X3S) return (long)((C + 15) / 16) * JVAE_X3S_PAIRS * 4 * OP * 8;
+    if (kind == JVAE_PACK_T2S) return (long)((C + 31) / 32) * 25 * 4 * OP * 8;
     return (long)((C + 15) / 16) * 25 * 2 * OP * 8;
 }
 __host__ __device__ __forceinline__ size_t jvae_pack_bytes(int kind, int C, int O) {
     const long n = jvae_pack_elems(kind, C, O);
-    return (size_t)n * ((kind == JVAE_PACK_F32 || kind == JVAE_PACK_SCI) ? 4 : ((kind == JVAE_PACK_X3 || kind == JVAE_PACK_X3S) ? 6 : 2));
+    return (size_t)n * ((kind == JVAE_PACK_F32 || kind == JVAE_PACK_SCI) ? 4 : ((kind == JVAE_PACK_X3 || kind == JVAE_PACK_X3S || kind == JVAE_PACK_T2S) ? 6 : 2));
 }
 
 __device__ __forceinline__ float jvae_pack_src(const float* __restrict__ w, int C, int O, int c, int o, int tap, int swap, int flip) {
@@ -95,6 +96,33 @@ __device__ __forceinline__ void jvae_pack_x3s_elem(const float* __restrict__ w, 
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl)
         wp[(((((long)kb * JVAE_X3S_PAIRS + pair) * 3 + pl) * 4 + kq) * OP + o) * 8 + ci] = s[pl];
+}
+
+// Tap sequence of the 4-phase stride-2 transposed kernel's 16x16x32 form (conv_t2_x3.hip, round 5): the 25 taps sorted by the
+// patch POSITION (dh, dw) = ((kh & 1) + 2 - kh) / 2, ((kw & 1) + 2 - kw) / 2 they read - the 25 taps touch only the 3 x 3
+// neighbourhood of a small-grid pixel, so consecutive taps of the sequence share their patch fragments.  tap = kh * 5 + kw.
+__host__ __device__ __forceinline__ int jvae_t2s_tap(int t) {
+    constexpr int SEQ[25] = {0, 1, 5, 6,  2, 3, 7, 8,  4, 9,  10, 11, 15, 16,  12, 13, 17, 18,  14, 19,  20, 21,  22, 23,  24};
+    return SEQ[t];
+}
+
+// split-bf16 operand of conv_t2_x3.hip's 16x16x32 form (K index of one MFMA = 32 channels of ONE tap):
+// Wp[kb][t][plane][kq][o][ci] = plane(W[o][c = kb*32 + kq*8 + ci][tap = jvae_t2s_tap(t)])
+__device__ __forceinline__ void jvae_pack_t2s_elem(const float* __restrict__ w, __bf16* __restrict__ wp, long i,
+                                                   int C, int O, int swap, int flip) {
+    const int OP = jvae_pack_op(O);
+    const int ci = (int)(i % 8);
+    long t = i / 8;
+    const int o = (int)(t % OP); t /= OP;
+    const int kq = (int)(t % 4); t /= 4;
+    const int ts = (int)(t % 25);
+    const int kb = (int)(t / 25);
+    const float v = jvae_pack_src(w, C, O, kb * 32 + kq * 8 + ci, o, jvae_t2s_tap(ts), swap, flip);
+    __bf16 s[3];
+    x3_split(v, s[0], s[1], s[2]);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+        wp[(((((long)kb * 25 + ts) * 3 + pl) * 4 + kq) * OP + o) * 8 + ci] = s[pl];
 }
 
 // bf16 operand of conv_b8.hip / conv_t2_b8.hip: Wp[kb][tap][half][o][ci] = bf16(W[o][c = kb*16 + half*8 + ci][tap])

@@ -869,7 +869,7 @@ class ClassificationVariationalNetwork(nn.Module):
                     y = recorder.get_batch(i, 'y_true')
                 else:
                     x, y = next(loader)[:2]
-                    x, y = x.to(device), y.to(device)
+                    x, y = self._device_batch(x.to(device)), y.to(device)      # raw uint8 images: ToTensor on the device
                     _, logits, losses, measures = self.evaluate(x, batch=i, current_measures=measures)
                 preds = [self.predict_after_evaluate(logits, losses, method=m) for m in methods]
                 if recording:
@@ -1070,40 +1070,94 @@ class ClassificationVariationalNetwork(nn.Module):
         step.graph = graph
         return step
 
-    def train_model(self, trainset=None, transformer='default', data_augmentation=[], optimizer=None, epochs=50,
+    def train_model(self, trainset=None, transformer=None, data_augmentation=None, optimizer=None, epochs=50,
                     batch_size=100, test_batch_size=100, validation=4096, device=None, testset=None, oodsets=None,
                     acc_methods=None, fine_tuning=False, warmup=[0, 0], warmup_gamma=[0, 0], latent_sampling=None,
                     validation_sample_size=1024, full_test_every=10, ood_detection_every=10, train_accuracy=False,
                     save_dir=None, outputs=None, signal_handler=None, report_every=10):
-        """Training loop with the reference's signature (cvae.py:2081-2104).  `trainset` is any map-style dataset of
-        (image, int label): float tensors in [0,1] shaped like `input_shape`, or RAW uint8 images ((H,W,C) as torchvision's
-        CIFAR `.data`, or (C,H,W)), which are converted - and augmented - on the device.  The periodic accuracy / OOD
-        phases of the reference are out of scope and skipped.  `outputs.results` gets the running
-        batch-mean losses the reference prints (cvae.py:2463-2479), refreshed from the device every `report_every` batches
-        (extra keyword, default 10) so that the loop does not synchronise per batch.
+        """Training loop with the reference's signature, bookkeeping and phases (cvae.py:2081-2547).
+
+        `trainset` is a map-style dataset of (image, int label) - what utils/torch_load.get_dataset() returns (train.py:236-243
+        hands it over with `.name`, `.transformer` and, for the torchvision sets, the raw images in `.data` / `.targets`), or any
+        torch Dataset: float tensors in [0,1] shaped like `input_shape`, or RAW uint8 images ((H,W,C) or (C,H,W)), which are
+        converted - and augmented - on the device.  Named datasets (a string) are the reference's torchvision plumbing and
+        outside this build.
+
+        What the reference does and this does too (same order):
+        * `training_parameters` gets `epochs`, and - for an untrained net only - `set` (trainset.name), `transformer`
+          (trainset.transformer), `validation`, `full_test_every`, `batch_size`, `latent_sampling`, `data_augmentation`
+          (cvae.py:2108-2145: train.py:224-229 reads them back on --resume), then `validation_split_seed`, `warmup`,
+          `warmup_gamma` (element-wise max with the recorded ones, cvae.py:2196-2202);
+        * a seeded `random_split` holds `validation` samples out; training runs on the remainder (cvae.py:2164-2167);
+        * every epoch (and once more at epoch == epochs) starts with the test phase: `accuracy(testset)` every
+          `full_test_every` epochs -> history `test_accuracy / test_measures / test_loss`, `accuracy(validationset)` every
+          epoch -> `validation_accuracy / _measures / _loss`, with `record-<set>.pth` written under `save_dir/samples/{last,
+          <epoch>}` (cvae.py:2293-2382); `train_accuracy=True` adds `accuracy(trainset)` -> `train_accuracy`;
+        * the hot loop cvae.py:2424-2501 = train_step(); the final test pass of cvae.py:2528-2545.
+        OOD detection rates (`oodsets`, cvae.py:2328-2336,2513-2526: ROC / FPR tooling over the recorders) are out of scope
+        (SURVEY.md §2a): a warning says so once and the phase is skipped.
 
         data_augmentation: the reference hands the list to its dataset factory, which prepends RandomHorizontalFlip ('flip')
-        and RandomCrop(size, padding=size//8 [0 for imagenet sets], padding_mode='edge') ('crop') to the training
-        transforms (utils/torch_load.py:405-426, consumed through the loader of cvae.py:2245-2249).  Here the same two
-        transforms run on the device, one launch per batch (ops.augment_batch: flip, edge-pad crop, /255, bit-exact against
-        the torchvision chain), with per-image decisions from ops.draw_augmentation; they need the raw uint8 images.  A
-        float dataset with a non-empty `data_augmentation`, or a token other than 'flip' / 'crop', raises instead of
-        training silently un-augmented.  The batch size is clamped to `max_batch_sizes['train']` as in cvae.py:2180-2194."""
+        and RandomCrop(size, padding=size//8 [0 for imagenet sets], padding_mode='edge') ('crop') to the training transforms
+        (utils/torch_load.py:405-426) - it re-opens the dataset BY NAME for that (cvae.py:2160-2162), so train.py passes the
+        un-augmented float (ToTensor) dataset together with the list.  Here the two transforms run on the device, one launch
+        per batch (ops.augment_batch: flip, edge-pad crop, /255, bit-exact against the torchvision chain), on the raw uint8
+        images: those the dataset yields, or - for a float dataset - those it CARRIES (`.data` uint8 + `.targets` / `.labels`,
+        as torchvision's CIFAR / SVHN objects do), once two samples have shown that `dataset[i]` is exactly `data[i] / 255`
+        (i.e. its own transform is ToTensor and nothing else).  A float dataset without raw images, or a token other than
+        'flip' / 'crop', raises instead of training silently un-augmented.  `outputs.results` gets the running batch-mean
+        losses the reference prints (cvae.py:2463-2479), refreshed from the device every `report_every` batches (extra
+        keyword) so that the loop does not synchronise per batch.  The batch size is clamped to `max_batch_sizes['train']`."""
         if isinstance(trainset, str):
             raise NotImplementedError('named torchvision datasets are host-side plumbing outside this build: '
                                       'pass a torch.utils.data.Dataset')
-        optimizer = optimizer or self.optimizer
-        if not self.trained:                     # cvae.py:2121-2146: a partially trained net keeps its recorded parameters
+        if epochs:
+            self.training_parameters['epochs'] = epochs
+        set_name = None
+        if trainset is not None:                 # cvae.py:2111-2118
+            set_name = getattr(trainset, 'name', None)
+            if not set_name:
+                set_name = str(trainset).splitlines()[0].split()[-1].lower()
+            transformer = getattr(trainset, 'transformer', transformer)
+        if self.trained:                         # cvae.py:2120-2122: a partially trained net keeps its recorded parameters
+            logging.info('Network partially trained (%d epochs)', self.trained)
+        else:
+            if trainset is not None:
+                self.training_parameters.update({'set': set_name, 'transformer': transformer, 'validation': validation,
+                                                 'full_test_every': full_test_every})
+            if batch_size:
+                self.training_parameters['batch_size'] = batch_size
             if latent_sampling:
                 self._latent_samplings['train'] = latent_sampling
                 self.training_parameters['latent_sampling'] = latent_sampling
             if data_augmentation:
                 self.training_parameters['data_augmentation'] = list(data_augmentation)
+        if not self.training_parameters.get('set'):
+            if trainset is None:
+                raise AssertionError("training_parameters['set'] is empty and no trainset was given (cvae.py:2147)")
+            self.training_parameters['set'] = set_name        # a resumed job whose record lacks the key (written before round 5)
+        set_name = str(self.training_parameters['set'])
+        if trainset is None:
+            raise NotImplementedError('re-opening the recorded set {!r} by name is torchvision plumbing outside this build: '
+                                      'pass the dataset (train.py:224-226 does)'.format(set_name))
         data_augmentation = list(self.training_parameters.get('data_augmentation') or [])
+        full_test_every = self.training_parameters.get('full_test_every', 10)
         unknown = [t for t in data_augmentation if t not in ('flip', 'crop')]
         if unknown:
             raise ValueError('data_augmentation: only flip and crop exist (utils/torch_load.py:405-413), got {}'.format(unknown))
+        # cvae.py:2155-2158 asks for the key 'validation_split_seed ' (trailing blank), which never exists: the reference draws
+        # a new seed in EVERY call, a resumed one included.  Same here.
+        np.random.seed()
+        seed = int(np.random.randint(0, 2 ** 12))
+        self.training_parameters['validation_split_seed'] = seed
+        if validation >= len(trainset):          # the reference's random_split([v, n - v]) would leave an EMPTY training set
+            raise ValueError('validation={} leaves nothing of the {} training samples to train on'.format(validation, len(trainset)))
+        validationset, trainset = torch.utils.data.random_split(trainset, [validation, len(trainset) - validation],
+                                                                generator=torch.Generator().manual_seed(seed))
+        validationset.name = 'validation'
+        validation_sample_size = min(validation, validation_sample_size)
         device = device or self.device
+        optimizer = optimizer or self.optimizer
         max_batch_sizes = self.max_batch_sizes
         test_batch_size = min(max_batch_sizes['test'], test_batch_size)
         if batch_size:                           # cvae.py:2180-2194
@@ -1112,14 +1166,86 @@ class ClassificationVariationalNetwork(nn.Module):
             train_batch_size = max_batch_sizes['train']
         logging.info('Train batch size is {}'.format(train_batch_size))
         batch_size = train_batch_size
-        self.training_parameters.update({'batch_size': batch_size, 'warmup': list(warmup),
-                                         'warmup_gamma': list(warmup_gamma), 'full_test_every': full_test_every})
-        loader = torch.utils.data.DataLoader(trainset, batch_size=batch_size, shuffle=True, num_workers=0)
-        set_name = str(getattr(trainset, 'name', '') or '')
-        done = self.trained
+        self.training_parameters['batch_size'] = batch_size
+        warmup, warmup_gamma = list(warmup), list(warmup_gamma)
+        warmup_ = self.training_parameters.get('warmup', [0, 0])
+        warmup_gamma_ = self.training_parameters.get('warmup_gamma', [0, 0])
+        for _ in (0, 1):                         # cvae.py:2196-2202
+            warmup[_] = max(warmup[_], warmup_[_])
+            warmup_gamma[_] = max(warmup_gamma[_], warmup_gamma_[_])
+        self.training_parameters['warmup'] = warmup
+        self.training_parameters['warmup_gamma'] = warmup_gamma
+
+        from jvae_compat.recorders import LossRecorder
+        sets = [set_name] + (['validation'] if validation else [])
+        recorders = {s: LossRecorder(test_batch_size) for s in sets}      # tensors allocated by the first recorded batch
+        if oodsets:
+            logging.warning('OOD detection rates (%s) are outside this build (SURVEY.md 2a): phase skipped; the recorders of '
+                            'accuracy() hold the losses the reference computes them from',
+                            ','.join(str(getattr(s, 'name', s)) for s in oodsets))
+        batches = self._train_batches(trainset, batch_size, data_augmentation, set_name, device)
+        per_epoch = len(batches)
+        done_epochs = self.train_history['epochs']
+        if done_epochs == 0:
+            self.train_history = {'epochs': 0}
+        if not acc_methods:
+            acc_methods = self.predict_methods
+        if fine_tuning:
+            for p in self.parameters():
+                p.requires_grad_(True)
         sig = signal_handler
-        for epoch in range(done, epochs):
-            if sig is not None and getattr(sig, 'sig', 0) > 2:
+
+        def signalled(level):
+            return sig is not None and getattr(sig, 'sig', 0) > level
+        epoch = done_epochs
+        for epoch in range(done_epochs, epochs + 1):
+            self.train_history[epoch] = {}
+            history_checkpoint = self.train_history[epoch]
+            for s in recorders:
+                recorders[s].reset()
+            # ---- test phase (cvae.py:2302-2382)
+            full_test = bool((epoch - done_epochs) and epoch % full_test_every == 0) or epoch == epochs
+            if (full_test or not epoch) and save_dir:
+                sample_dirs = [os.path.join(save_dir, 'samples', d) for d in ('last', '{:04d}'.format(epoch))]
+                for d in sample_dirs:
+                    os.makedirs(d, exist_ok=True)
+            else:
+                sample_dirs = []
+            with torch.no_grad():
+                self.test_losses, self.test_measures = {}, {}
+                if full_test and testset is not None:
+                    test_accuracy = self.accuracy(testset, batch_size=test_batch_size, num_batch='all', method=acc_methods,
+                                                  outputs=outputs, sample_dirs=sample_dirs, update_self_testing=full_test,
+                                                  recorder=recorders[set_name], print_result='TEST' if full_test else 'test')
+                    history_checkpoint['test_accuracy'] = test_accuracy
+                    history_checkpoint['test_measures'] = dict(self.test_measures)
+                    history_checkpoint['test_loss'] = dict(self.test_losses)
+                if validation:
+                    validation_accuracy = self.accuracy(validationset, batch_size=test_batch_size, num_batch='all',
+                                                        method=acc_methods, outputs=outputs, sample_dirs=sample_dirs,
+                                                        update_self_testing=False, recorder=recorders['validation'],
+                                                        print_result='VALID' if full_test else 'valid')
+                    history_checkpoint['validation_accuracy'] = validation_accuracy
+                    history_checkpoint['validation_measures'] = dict(self.test_measures)
+                    history_checkpoint['validation_loss'] = dict(self.test_losses)
+                if signalled(3):
+                    logging.warning('Abruptly breaking training loop bc of %s', sig)
+                    break
+                if save_dir:
+                    self.save(save_dir)
+            if epoch == epochs:
+                break
+            # ---- train phase (cvae.py:2388-2501)
+            if train_accuracy:
+                with torch.no_grad():
+                    train_accuracy = self.accuracy(trainset, batch_size=test_batch_size, num_batch='all', method=acc_methods,
+                                                   update_self_testing=False, log=False, outputs=outputs, print_result='acc')
+            if signalled(3):
+                logging.warning('Abruptly breaking training loop bc of %s', sig)
+                break
+            if save_dir:
+                self.save(save_dir)
+            if signalled(2) or (full_test and signalled(1)):
                 logging.warning('Breaking training loop bc of signal %s after %d epochs', sig, epoch)
                 break
             self.encoder.prior.thaw_means(epoch)
@@ -1130,8 +1256,7 @@ class ClassificationVariationalNetwork(nn.Module):
             measures, nb = None, 0
             keys, acc = None, None          # running sums of the batch means of every loss: ONE device vector
             shown = {}
-            for i, (x, y) in enumerate(loader):
-                x, y = self._device_batch(x.to(device), data_augmentation, set_name), y.to(device)
+            for i, (x, y) in enumerate(batches):
                 losses, measures = self.train_step(x, y, batch=i, current_measures=measures,
                                                    kl_var_weighting=w_kl, gamma_weighting=w_gamma)
                 if keys is None:
@@ -1141,27 +1266,135 @@ class ClassificationVariationalNetwork(nn.Module):
                 acc += torch.stack([losses[k].detach().mean() for k in keys])
                 nb = i + 1
                 if outputs is not None and hasattr(outputs, 'results'):
-                    if i % report_every == 0 or i + 1 == len(loader):
+                    if i % report_every == 0 or i + 1 == per_epoch:
                         host = (acc / nb).tolist()                    # the only read-back of the loop: every k batches
                         shown = dict(zip(keys, host))
-                    outputs.results(i, len(loader), epoch + 1, epochs, preambule='train',
+                    outputs.results(i, per_epoch, epoch + 1, epochs, preambule='train',
                                     losses={k: shown.get(k, float('nan')) for k in self.loss_components},
-                                    metrics={k: measures[k] for k in self.metrics} if (i % report_every == 0 or i + 1 == len(loader))
+                                    metrics={k: measures[k] for k in self.metrics} if (i % report_every == 0 or i + 1 == per_epoch)
                                     else {k: float('nan') for k in self.metrics},
                                     accuracy={k: np.nan for k in self.predict_methods},
                                     time_per_i=(time.time() - t0) / (i + 1), batch_size=batch_size, end_of_epoch='\n')
             self.eval()
             mean_loss = dict(zip(keys or [], (acc / max(nb, 1)).tolist() if acc is not None else []))
-            self.train_history[epoch] = {'train_loss': mean_loss, 'train_measures': dict(measures or {}),
-                                         'lr': self.optimizer.lr}
+            if train_accuracy:
+                history_checkpoint['train_accuracy'] = train_accuracy
+            history_checkpoint['train_loss'] = mean_loss
+            history_checkpoint['train_measures'] = dict(measures or {})
             self.train_history['epochs'] += 1
+            history_checkpoint['lr'] = self.optimizer.lr
             self.trained += 1
             if fine_tuning:
                 self.training_parameters['fine_tuning'].append(epoch)
             optimizer.update_lr()
+            if signalled(3):
+                logging.warning('Abruptly breaking training loop bc of %s', sig)
+                break
             if save_dir:
                 self.save(save_dir)
+        # ---- after the loop (cvae.py:2503-2545): a last test pass over the whole test set, then save
+        for s in recorders:
+            recorders[s].reset()
+        sample_dirs = []
+        if save_dir:
+            sample_dirs = [os.path.join(save_dir, 'samples', d) for d in ('last', '{:04d}'.format(epoch + 1))]
+            for d in sample_dirs:
+                os.makedirs(d, exist_ok=True)
+        if testset is not None and not signalled(1):
+            with torch.no_grad():
+                self.accuracy(testset, batch_size=test_batch_size, method=acc_methods, recorder=recorders[set_name],
+                              sample_dirs=sample_dirs, outputs=outputs, print_result='TEST')
+        if signalled(3):
+            logging.warning('Skipping saving because of %s', sig)
+        elif save_dir:
+            self.save(save_dir)
         return self.train_history
+
+    def _train_batches(self, trainset, batch_size, data_augmentation, set_name, device):
+        """The training loader of cvae.py:2245-2249 (batch_size, shuffle=True, num_workers=0, no drop_last) as a re-iterable of
+        DEVICE batches (x float32 (n, *input_shape), y int64).  Three sources:
+        * a dataset that yields uint8 images: collated by the DataLoader, converted / augmented by the input-pipeline kernel;
+        * a float dataset, no augmentation asked: collated by the DataLoader, passed through;
+        * a float dataset + `data_augmentation`: the raw uint8 images the dataset object carries (`.data`, `.targets` or
+          `.labels`; behind a `random_split` Subset: its `.dataset` and `.indices`) are gathered per batch by the SAME
+          DataLoader machinery run over the sample indices - the shuffling consumes the global generator exactly as the
+          reference's loader does - and augmented on the device.  Accepted only if the dataset's own transform is ToTensor and
+          nothing else: its first and last samples must equal `data[i] / 255` bit for bit, and its target_transform (held-out
+          classes: utils/torch_load.py:338-343) is applied to the gathered labels."""
+        model = self
+
+        class Batches:
+            def __init__(self, loader, convert):
+                self.loader, self.convert = loader, convert
+
+            def __len__(self):
+                return len(self.loader)
+
+            def __iter__(self):
+                for item in self.loader:
+                    yield self.convert(item)
+        probe = trainset[0][0] if len(trainset) else None
+        is_raw = torch.is_tensor(probe) and probe.dtype == torch.uint8
+        if is_raw or not data_augmentation or probe is None:
+            loader = torch.utils.data.DataLoader(trainset, batch_size=batch_size, shuffle=True, num_workers=0)
+            return Batches(loader, lambda b: (model._device_batch(b[0].to(device), data_augmentation, set_name), b[1].to(device)))
+        base, indices = trainset, None
+        while isinstance(base, torch.utils.data.Subset):
+            idx = torch.as_tensor(base.indices, dtype=torch.int64)
+            indices = idx if indices is None else idx[indices]
+            base = base.dataset
+        data = getattr(base, 'data', None)
+        labels = getattr(base, 'targets', None)
+        if labels is None:
+            labels = getattr(base, 'labels', None)
+        why = None
+        if data is None or labels is None:
+            why = 'the dataset carries no raw images (.data and .targets / .labels)'
+        else:
+            data = torch.as_tensor(np.asarray(data) if not torch.is_tensor(data) else data)
+            labels = torch.as_tensor(np.asarray(labels) if not torch.is_tensor(labels) else labels).to(torch.int64)
+            C, H, W = self.input_shape
+            if data.dtype != torch.uint8:
+                why = 'its .data is {} (uint8 expected)'.format(data.dtype)
+            elif data.dim() == 3 and C == 1 and tuple(data.shape[1:]) == (H, W):
+                data = data.unsqueeze(1)
+            elif data.dim() != 4 or tuple(data.shape[1:]) not in ((H, W, C), (C, H, W)):
+                why = 'its .data is shaped {} (input_shape {})'.format(tuple(data.shape), tuple(self.input_shape))
+        if why is None:
+            n_base = len(base)
+            if len(data) != n_base or len(labels) != n_base:
+                why = '.data / .targets hold {} / {} entries for {} samples'.format(len(data), len(labels), n_base)
+        if why is None:
+            nhwc = tuple(data.shape[1:]) == (H, W, C) and not (C == H == W)
+            for i in {0, n_base - 1}:
+                xi = base[i][0]
+                raw = data[i].permute(2, 0, 1) if nhwc else data[i]
+                if not torch.is_tensor(xi) or tuple(xi.shape) != (C, H, W) or not torch.equal(
+                        xi.to(torch.float32), raw.to(torch.float32).div(255)):
+                    why = 'sample {} of the dataset is not its raw image / 255: its own transform is more than ToTensor'.format(i)
+                    break
+        if why is not None:
+            raise ValueError('data_augmentation={} needs the raw uint8 images (the reference augments PIL images before '
+                             'ToTensor, utils/torch_load.py:405-426); this dataset yields {} and {}'.format(
+                                 list(data_augmentation), getattr(probe, 'dtype', type(probe)), why))
+        target_transform = getattr(base, 'target_transform', None)
+
+        class Indices(torch.utils.data.Dataset):
+            def __len__(self):
+                return len(trainset)
+
+            def __getitem__(self, i):
+                return i
+
+        def gather(idx):
+            if indices is not None:
+                idx = indices[idx]
+            y = labels[idx]
+            if target_transform is not None:
+                y = torch.tensor([int(target_transform(int(v))) for v in y.tolist()], dtype=torch.int64)
+            return (model._device_batch(data[idx].to(device), data_augmentation, set_name), y.to(device))
+        loader = torch.utils.data.DataLoader(Indices(), batch_size=batch_size, shuffle=True, num_workers=0)
+        return Batches(loader, gather)
 
     def _device_batch(self, x, data_augmentation=(), set_name=''):
         """Collated training batch -> the float32 (N, *input_shape) tensor the step takes.  Raw uint8 images go through the

@@ -631,8 +631,9 @@ def test_train_model_loop_saves_and_resumes(tmp_path):
     out = Out()
     m0 = net.encoder.prior.mean.detach().clone()
     hist = net.train_model(data, epochs=2, batch_size=32, warmup=[0, 1], save_dir=str(tmp_path), outputs=out,
-                           report_every=2, device=DEV)
-    assert hist['epochs'] == 2 and net.trained == 2 and set(hist) == {'epochs', 0, 1}
+                           report_every=2, validation=0, device=DEV)
+    # cvae.py:2293-2296: the loop runs to epoch == epochs, whose entry holds the closing test / validation results only
+    assert hist['epochs'] == 2 and net.trained == 2 and set(hist) == {'epochs', 0, 1, 2} and hist[2] == {}
     assert set(hist[0]) == {'train_loss', 'train_measures', 'lr'}
     assert set(hist[0]['train_loss']) >= {'total', 'cross_x', 'kl', 'zdist', 'var_kl', 'wmse'}
     assert all(np.isfinite(v) for v in hist[1]['train_loss'].values())
@@ -645,13 +646,13 @@ def test_train_model_loop_saves_and_resumes(tmp_path):
     # freeze_means=1: the dictionary does not move in epoch 0 and does from epoch 1 on (priors.py:105-106,134-140)
     assert not torch.equal(net.encoder.prior.mean.detach(), m0)
     on_disk = json.load(open(os.path.join(tmp_path, 'history.json')))
-    assert on_disk['epochs'] == 2 and set(on_disk) == {'epochs', '0', '1'}
+    assert on_disk['epochs'] == 2 and set(on_disk) == {'epochs', '0', '1', '2'}
     again = Net.load(str(tmp_path), device=DEV)
     assert again.trained == 2 and again.train_history['epochs'] == 2
     for (k, p), (_, q) in zip(net.state_dict().items(), again.state_dict().items()):
         assert torch.equal(p, q), k
-    hist2 = again.train_model(data, epochs=3, batch_size=32, warmup=[0, 1], save_dir=str(tmp_path), device=DEV)
-    assert hist2['epochs'] == 3 and set(hist2) == {'epochs', 0, 1, 2} and again.trained == 3
+    hist2 = again.train_model(data, epochs=3, batch_size=32, warmup=[0, 1], save_dir=str(tmp_path), validation=0, device=DEV)
+    assert hist2['epochs'] == 3 and set(hist2) == {'epochs', 0, 1, 2, 3} and again.trained == 3
     assert all(np.isfinite(v) for v in hist2[2]['train_loss'].values())
 
 
@@ -670,7 +671,7 @@ def test_train_model_epoch_with_a_ragged_last_batch(tmp_path):
         def results(self, i, per_epoch, epoch, epochs, **k):
             seen.append((i, per_epoch, k.get('batch_size')))
     w0 = {k: v.detach().clone() for k, v in net.state_dict().items() if v.dtype.is_floating_point}
-    hist = net.train_model(data, epochs=1, batch_size=512, save_dir=str(tmp_path), outputs=Out(), report_every=1, device=DEV)
+    hist = net.train_model(data, epochs=1, batch_size=512, save_dir=str(tmp_path), outputs=Out(), report_every=1, validation=0, device=DEV)
     torch.cuda.synchronize()
     assert hist['epochs'] == 1 and net.trained == 1
     assert all(np.isfinite(v) for v in hist[0]['train_loss'].values()), hist[0]['train_loss']
@@ -733,8 +734,9 @@ def test_train_model_augments_on_the_device_bit_exact(monkeypatch):
         return real_step(x, y, **k)
     monkeypatch.setattr(ops, 'draw_augmentation', draw)
     monkeypatch.setattr(net, 'train_step', step)
-    hist = net.train_model(data, epochs=1, batch_size=32, data_augmentation=['flip', 'crop'], device=DEV)
+    hist = net.train_model(data, epochs=1, batch_size=32, data_augmentation=['flip', 'crop'], validation=0, device=DEV)
     assert hist['epochs'] == 1 and net.training_parameters['data_augmentation'] == ['flip', 'crop']
+    data.order.pop(0)                                      # train_model's look at what the dataset yields (uint8 or float)
     assert [b[0].shape[0] for b in batches] == [32, 32, 19] and len(draws) == 3 and sorted(data.order) == list(range(83))
     at, flipped, shifted = 0, 0, 0
     for (xb, yb), (flip, dy, dx) in zip(batches, draws):
@@ -751,7 +753,8 @@ def test_train_model_augments_on_the_device_bit_exact(monkeypatch):
     net2 = Net(**dict(get_case('c2_n8')['net'])).to(DEV)
     step2 = net2.train_step
     monkeypatch.setattr(net2, 'train_step', lambda x, y, **k: (batches.append(x.detach().cpu().numpy().copy()), step2(x, y, **k))[1])
-    net2.train_model(data, epochs=1, batch_size=64, device=DEV)
+    net2.train_model(data, epochs=1, batch_size=64, validation=0, device=DEV)
+    data.order.pop(0)
     assert np.array_equal(batches[0], data.data[data.order[:64]].transpose(0, 3, 1, 2).astype(np.float32) / np.float32(255))
     # 'crop' on an imagenet set pads by 0 (utils/torch_load.py:410): flips only
     batches.clear(); draws.clear(); data.order.clear()
@@ -759,7 +762,8 @@ def test_train_model_augments_on_the_device_bit_exact(monkeypatch):
     net3 = Net(**dict(get_case('c2_n8')['net'])).to(DEV)
     step3 = net3.train_step
     monkeypatch.setattr(net3, 'train_step', lambda x, y, **k: (batches.append(x.detach().cpu().numpy().copy()), step3(x, y, **k))[1])
-    net3.train_model(data, epochs=1, batch_size=83, data_augmentation=['flip', 'crop'], device=DEV)
+    net3.train_model(data, epochs=1, batch_size=83, data_augmentation=['flip', 'crop'], validation=0, device=DEV)
+    data.order.pop(0)
     flip, dy, dx = draws[0]
     assert dy is None and dx is None and np.array_equal(batches[0], augment(data.data[data.order], flip, None, None, 0))
 
@@ -772,17 +776,183 @@ def test_train_model_refuses_what_it_cannot_honour_and_clamps_the_batch(monkeypa
     net = Net(**dict(get_case('c2_n8')['net'])).to(DEV)
     floats = torch.utils.data.TensorDataset(torch.rand(24, 3, 32, 32), torch.randint(0, 10, (24,)))
     with pytest.raises(ValueError, match='uint8'):
-        net.train_model(floats, epochs=1, batch_size=8, data_augmentation=['flip'], device=DEV)
+        net.train_model(floats, epochs=1, batch_size=8, data_augmentation=['flip'], validation=0, device=DEV)
     net = Net(**dict(get_case('c2_n8')['net'])).to(DEV)
     with pytest.raises(ValueError, match='rotate'):
-        net.train_model(_RawImages(8), epochs=1, batch_size=8, data_augmentation=['rotate'], device=DEV)
+        net.train_model(_RawImages(8), epochs=1, batch_size=8, data_augmentation=['rotate'], validation=0, device=DEV)
     net = Net(**dict(get_case('c2_n8')['net'])).to(DEV)
     monkeypatch.setattr(Net, 'max_batch_sizes', property(lambda self: {'train': 8, 'test': 4}))
     sizes = []
     real_step = net.train_step
     monkeypatch.setattr(net, 'train_step', lambda x, y, **k: (sizes.append(x.shape[0]), real_step(x, y, **k))[1])
-    net.train_model(floats, epochs=1, batch_size=512, device=DEV)
+    net.train_model(floats, epochs=1, batch_size=512, validation=0, device=DEV)
     assert sizes == [8, 8, 8] and net.training_parameters['batch_size'] == 8
+
+
+class _CifarLike(torch.utils.data.Dataset):
+    """What utils/torch_load.get_dataset('cifar10', transformer='default') hands to train.py:236-243: a torchvision-CIFAR-shaped
+    object - raw images in `.data` (uint8 NHWC) / `.targets` (list), `__getitem__` -> (ToTensor(image), label) - with the
+    attributes the reference's factory adds (`.name .transformer .same_size .classes .heldout`, torch_load.py:489-497)."""
+    target_transform = None
+
+    def __init__(self, n, name='cifar10', seed=0, classes=10):
+        rng = np.random.default_rng(seed)
+        self.data = rng.integers(0, 256, size=(n, 32, 32, 3), dtype=np.uint8)
+        self.targets = [int(t) for t in rng.integers(0, classes, size=n)]
+        self.name, self.transformer, self.same_size = name, 'default', ['svhn']
+        self.classes, self.heldout = [str(i) for i in range(classes)], []
+
+    def __len__(self):
+        return len(self.data)
+
+    def __getitem__(self, i):
+        return torch.from_numpy(self.data[i]).permute(2, 0, 1).to(torch.float32).div(255), self.targets[i]
+
+
+def _keep_job(src, name, with_tensors):
+    """JVAE_KEEP_JOB_DIR (set by tools/gpu_job.sh): the job directory a test's train_model() wrote is copied there, so that
+    oracle/check_dropin_job.py can hand it to the REFERENCE's load() in the build container."""
+    keep = os.environ.get('JVAE_KEEP_JOB_DIR')
+    if not keep:
+        return
+    import shutil
+    dst = os.path.join(keep, name)
+    shutil.rmtree(dst, ignore_errors=True)
+    os.makedirs(dst)
+    for f in os.listdir(src):
+        if f.endswith('.json') or (with_tensors and f.endswith('.pth')):
+            shutil.copy(os.path.join(src, f), dst)
+
+
+def test_train_model_as_train_py_drives_it(tmp_path, monkeypatch, caplog):
+    """the call of train.py:333-351 - a FLOAT (ToTensor) CIFAR-shaped dataset object that carries its raw
+    images, data_augmentation=['flip', 'crop'], a test set, OOD sets, a validation hold-out - through the drop-in.
+    Bookkeeping of cvae.py:2108-2167 (what train.py:224-229 reads back on --resume), the seeded split (the held-out samples
+    are never trained on), augmentation of the carried raw images bit-exact against the oracle, the test / validation phases
+    of cvae.py:2293-2382 with their history entries and record files, one warning for the OOD phase."""
+    import json
+    import logging
+    from cvae import ClassificationVariationalNetwork as Net
+    from jvae_hip import ops
+    from oracle.augment_oracle import augment
+    torch.manual_seed(5)
+    net = Net(**dict(get_case('c2_n8')['net'])).to(DEV)
+    trainset, testset, ood = _CifarLike(600, seed=21), _CifarLike(130, seed=22), _CifarLike(40, name='svhn', seed=23)
+    index_of = {trainset.data[i].tobytes(): i for i in range(len(trainset))}
+    raw, seen_y = [], []
+    real_aug, real_step = ops.augment_batch, net.train_step
+
+    def aug(x, flip, dy, dx, **k):
+        out = real_aug(x, flip, dy, dx, **k)
+        raw.append((x.cpu().numpy().copy(), flip.cpu().numpy().copy(), dy.cpu().numpy().copy(), dx.cpu().numpy().copy(),
+                    dict(k), out.cpu().numpy().copy()))
+        return out
+    monkeypatch.setattr(ops, 'augment_batch', aug)
+    monkeypatch.setattr(net, 'train_step', lambda x, y, **k: (seen_y.append(y.cpu().numpy().copy()), real_step(x, y, **k))[1])
+
+    class Out:
+        rows = []
+
+        def results(self, i, per_epoch, epoch, epochs, **k):
+            self.rows.append((k.get('preambule'), i, per_epoch))
+
+    class Sig:
+        sig = 0
+    save_dir = str(tmp_path / 'job')
+    with caplog.at_level(logging.WARNING):
+        hist = net.train_model(trainset, transformer=trainset.transformer, epochs=2, batch_size=64, test_batch_size=50,
+                               full_test_every=1, ood_detection_every=1, validation=88, device=DEV, testset=testset,
+                               oodsets=[ood], data_augmentation=['flip', 'crop'], fine_tuning=False, warmup=[0, 0],
+                               warmup_gamma=[0, 0], validation_sample_size=64, save_dir=save_dir, outputs=Out(),
+                               signal_handler=Sig())
+    assert sum('OOD' in r.getMessage() for r in caplog.records) == 1
+    tp = net.training_parameters
+    assert (tp['set'], tp['transformer'], tp['validation'], tp['full_test_every']) == ('cifar10', 'default', 88, 1)
+    assert tp['data_augmentation'] == ['flip', 'crop'] and tp['epochs'] == 2 and tp['batch_size'] == 64
+    assert 0 <= tp['validation_split_seed'] < 2 ** 12 and tp['warmup'] == [0, 0]
+    # the split: 512 of the 600 samples per epoch, the SAME 512 in both epochs, each once; labels travel with their images
+    per_epoch = [raw[:8], raw[8:]]
+    assert len(raw) == 16 and all(sum(b[0].shape[0] for b in ep) == 512 for ep in per_epoch)
+    trained_on = []
+    at = 0
+    for ep in per_epoch:
+        ids = []
+        for xb, flip, dy, dx, kw, out in ep:
+            assert xb.dtype == np.uint8 and xb.shape[1:] == (32, 32, 3) and kw.get('pad') == 4 and kw.get('nhwc')
+            idx = [index_of[im.tobytes()] for im in xb]
+            assert np.array_equal(out, augment(trainset.data[idx], flip, dy, dx, 4))            # bit-exact input pipeline
+            assert np.array_equal(seen_y[at], np.asarray(trainset.targets)[idx])
+            at += 1
+            ids += idx
+        assert len(set(ids)) == 512
+        trained_on.append(set(ids))
+    assert trained_on[0] == trained_on[1]
+    held_out = set(range(600)) - trained_on[0]
+    split = torch.utils.data.random_split(range(600), [88, 512], generator=torch.Generator().manual_seed(tp['validation_split_seed']))
+    assert held_out == set(split[0]) and len(held_out) == 88                                    # cvae.py:2164-2167
+    # phases and history (cvae.py:2293-2382,2481-2501)
+    assert hist['epochs'] == 2 and set(hist) == {'epochs', 0, 1, 2}
+    assert set(hist[0]) == {'validation_accuracy', 'validation_measures', 'validation_loss', 'train_loss', 'train_measures', 'lr'}
+    for e in (1, 2):
+        assert {'test_accuracy', 'test_measures', 'test_loss', 'validation_accuracy'} <= set(hist[e])
+        assert set(hist[e]['test_accuracy']) == set(net.predict_methods)
+        assert all(0. <= v <= 1. for v in hist[e]['test_accuracy'].values())
+        assert np.isfinite(hist[e]['test_loss']['total']) and np.isfinite(hist[e]['validation_loss']['total'])
+    assert 'train_loss' in hist[1] and 'train_loss' not in hist[2]
+    assert net.testing[2][net.predict_methods[0]]['n'] == 130
+    pre = [r[0] for r in Out.rows]
+    assert pre.count('train') == 16 and 'TEST' in pre and ('VALID' in pre or 'valid' in pre)
+    for d in ('last', '0001', '0002'):
+        for s in ('cifar10', 'validation'):
+            assert os.path.exists(os.path.join(save_dir, 'samples', d, 'record-{}.pth'.format(s))), (d, s)
+    from jvae_compat.recorders import LossRecorder
+    rec = LossRecorder.load(os.path.join(save_dir, 'samples', 'last', 'record-cifar10.pth'))
+    assert rec.recorded_samples == 130 and np.array_equal(rec['y_true'].cpu().numpy(), np.asarray(testset.targets))
+    # what train.py:224-229 reads on --resume, from the files
+    on_disk = json.load(open(os.path.join(save_dir, 'train_params.json')))
+    for k in ('set', 'transformer', 'validation', 'data_augmentation', 'latent_sampling'):
+        assert on_disk[k] == tp[k], k
+    again = Net.load(save_dir, device=DEV)
+    assert again.trained == 2 and again.training_parameters['set'] == 'cifar10' and again.training_parameters['validation'] == 88
+    _keep_job(save_dir, 'cifar_conv32', with_tensors=False)
+    # a float dataset WITHOUT raw images, or one whose own transform is more than ToTensor, still raises
+    net = Net(**dict(get_case('c2_n8')['net'])).to(DEV)
+    class Inverted(_CifarLike):
+        def __getitem__(self, i):
+            x, y = super().__getitem__(i)
+            return 1 - x, y
+    bad = Inverted(64, seed=3)
+    with pytest.raises(ValueError, match='more than ToTensor'):
+        net.train_model(bad, epochs=1, batch_size=8, data_augmentation=['flip'], validation=0, device=DEV)
+
+
+def test_train_model_job_of_a_small_model_for_the_reference_to_load(tmp_path):
+    """A complete job directory (JSON files + state.pth + optimizer.pth) written by the drop-in's train_model() for a model
+    small enough to commit: oracle/check_dropin_job.py loads it with the REFERENCE's own load() (cvae.py:2677-2857) in the
+    build container.  Here: it is written, and the drop-in resumes from it."""
+    from cvae import ClassificationVariationalNetwork as Net
+    kw = dict(input_shape=(1, 8, 8), num_labels=4, type='cvae', features=None, upsampler=None, encoder=[24], decoder=[24],
+              classifier=[], batch_norm=False, latent_dim=6, latent_sampling=1, test_latent_sampling=2, sigma={'value': 0.5},
+              gamma=0., beta=1., output_activation='sigmoid',
+              prior=dict(distribution='gaussian', init_mean=0., learned_means=True, var_dim='diag', freeze_means=0),
+              optimizer=dict(optim_type='adam', lr=1e-3, weight_decay=3e-5, grad_clipping=100, lr_decay=0.1))
+    torch.manual_seed(2)
+    net = Net(**kw).to(DEV)
+    g = torch.Generator().manual_seed(0)
+    data = torch.utils.data.TensorDataset(torch.rand(80, 1, 8, 8, generator=g), torch.randint(0, 4, (80,), generator=g))
+    data.name, data.transformer = 'toy8', 'simple'
+    test = torch.utils.data.TensorDataset(torch.rand(20, 1, 8, 8, generator=g), torch.randint(0, 4, (20,), generator=g))
+    test.name = 'toy8'
+    save_dir = str(tmp_path / 'job')
+    hist = net.train_model(data, epochs=2, batch_size=16, test_batch_size=10, validation=16, testset=test, full_test_every=1,
+                           save_dir=save_dir, device=DEV)
+    assert hist['epochs'] == 2 and net.training_parameters['set'] == 'toy8' and net.training_parameters['transformer'] == 'simple'
+    for f in ('params.json', 'train_params.json', 'test.json', 'ood.json', 'history.json', 'state.pth', 'optimizer.pth'):
+        assert os.path.exists(os.path.join(save_dir, f)), f
+    again = Net.load(save_dir, device=DEV)
+    # (load() fast-forwards the restored learning rate by `trained` epochs once more, as the reference's does: ckpt_ref_e2)
+    assert again.trained == 2 and again.optimizer.lr == pytest.approx(net.optimizer.lr * 0.9 ** 2)
+    _keep_job(save_dir, 'toy8_mlp', with_tensors=True)
 
 
 def test_encoder_value_error_dumps_model_and_batch(tmp_path, monkeypatch):
