@@ -65,7 +65,7 @@ def build_model(device, workload=2, test_latent_sampling=1):
     return net
 
 
-def dominant_kernel_roofline(device, reps=20, in_step_ms=None):
+def dominant_kernel_roofline(device, reps=20, in_step_ms=None, where='the timed steps'):
     """Largest layer of the step (imager.15: ConvTranspose2d 32->32 5x5 on 1024x32x32x32, 53.69 GFLOP fwd).
 
     `achieved` = algorithmic FLOPs of one launch / its average duration INSIDE the timed steps (`in_step_ms`: one HIP-event
@@ -102,7 +102,7 @@ def dominant_kernel_roofline(device, reps=20, in_step_ms=None):
     sec, measured = alone, 'standalone: %d back-to-back launches outside the step' % reps
     if in_step_ms:
         sec = sum(in_step_ms) / len(in_step_ms) * 1e-3
-        measured = 'in the timed steps: %d HIP-event pairs (one per step) around the launch, on its launch stream' % len(in_step_ms)
+        measured = 'inside %s: %d HIP-event pairs (one per step) around the launch, on its launch stream' % (where, len(in_step_ms))
     traffic, traffic_source = None, None
     for name in (('r04_x3_fwd_pmc.json', 'r03_x3_fwd_pmc.json') if x3 else ('r01_dominant_kernel_pmc.json',)):
         pmc = os.path.join(REPO, 'profiles', name)
@@ -295,8 +295,11 @@ def main():
     ap.add_argument('--batch', type=int, default=None, help='diagnostics only: per-GPU batch (the metric is defined at 512)')
     ap.add_argument('--sync-bn', action='store_true', help='BatchNorm statistics over all ranks (default: per rank)')
     ap.add_argument('--graph', action='store_true',
-                    help='replay the step as a captured HIP graph (ClassificationVariationalNetwork.graph_train_step: one host call per '
-                         'step, three when data parallel) instead of the eager loop: the same kernels, for hosts with few cores per GPU')
+                    help='(default since round 5) replay the step as a captured HIP graph - ClassificationVariationalNetwork.graph_train_step: '
+                         'one host call per step, three when data parallel; the same kernels as the eager loop')
+    ap.add_argument('--eager', action='store_true',
+                    help='time the eager loop (train_step: ~180 launches per step enqueued from Python, ~3 ms of host time per step) '
+                         'instead of the graph replay')
     ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'], help='bf16: the mixed-precision mode of BASELINE configs[4]')
     ap.add_argument('--workload', default='2', choices=[str(k) for k in sorted(WORKLOADS)] + ['eval'],
                     help="diagnostics: other BASELINE configs; 'eval' = the label-free evaluation pass (SURVEY.md §8f-1): config 2, "
@@ -304,6 +307,11 @@ def main():
     a = ap.parse_args()
     eval_mode = a.workload == 'eval'
     a.workload = 2 if eval_mode else int(a.workload)
+    # What is timed (round 5): the captured step.  The eager loop needs ~3.0 ms of host time per 3.6 ms step and may run at most one
+    # step ahead of the GPU (the NaN flag of the previous update is read before every backward, as the reference does), so any
+    # host hiccup of a few ms lands in the wall clock: the driver's r04 line read mean 3.87 / median 3.67 ms for that reason.
+    # The replay needs 0.4 ms of host time per step.  --eager times the loop of train_step() calls instead.
+    a.graph = not a.eager and not eval_mode
     fh = _watchdog(900)
     if a.batch is None:
         a.batch = 256 if a.workload == 5 else BATCH_PER_GPU
@@ -363,14 +371,16 @@ def main():
     for i in range(a.warmup):
         _, meas = one_step(i, meas)
     probe = None
-    if a.workload == 2 and a.dtype == 'f32' and not eval_mode and not a.graph and os.environ.get('JVAE_BENCH_NO_PROBES') != '1':
-        # the dominant kernel (imager.15 forward: ConvT 32->32 5x5 s1 on the 2N x 32 x 32 x 32 decoder activation) timed INSIDE the
-        # timed steps: one HIP-event pair per step around that launch, on the stream it is launched on
+    want_probe = a.workload == 2 and a.dtype == 'f32' and not eval_mode and os.environ.get('JVAE_BENCH_NO_PROBES') != '1'
+    if want_probe:
+        # the dominant kernel (imager.15 forward: ConvT 32->32 5x5 s1 on the 2N x 32 x 32 x 32 decoder activation) timed INSIDE
+        # running steps: one HIP-event pair per step around that launch, on the stream it is launched on.  Eager timing: inside the
+        # timed steps; graph replay (no events inside a captured graph): inside eager steps run right after the timed region.
         from jvae_hip import ops as _ops
         probe = _ops.FWD_AFF_PROBE = _ops.LaunchProbe(lambda sp, N, H: sp.transposed and sp.s == 1 and sp.cin == 32 and sp.cout == 32
                                                       and H == 32 and N == 2 * a.batch)
     sync()
-    if probe is not None:
+    if probe is not None and not a.graph:
         probe.armed = True
     # per-step HIP events on the launch stream (median / min are reported beside the contract's mean over the K steps)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
@@ -384,6 +394,19 @@ def main():
         host_marks[i + 1] = time.time()
     sync()
     dt = time.time() - t0
+    probe_steps = 0
+    if probe is not None and a.graph:
+        # the instrumented EAGER steps behind the timed replay (same model, same batch, same kernels in the same order)
+        losses = meas = None
+        m2 = None
+        for i in range(3):
+            _, m2 = net.train_step(x, y, batch=i, current_measures=m2)
+        torch.cuda.synchronize()
+        probe.armed = True
+        probe_steps = max(10, min(a.steps, 40))
+        for i in range(probe_steps):
+            losses, m2 = net.train_step(x, y, batch=3 + i, current_measures=m2)
+        torch.cuda.synchronize()
     if probe is not None:
         probe.armed = False
     # in launch order (which step is the slow one must stay visible); sorted only for the median / min below
@@ -395,6 +418,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
     value = world * a.batch * a.steps / dt
+    final_loss = float(losses['total'].detach().mean())
     replicas = None
     if dist is not None and not eval_mode:
         # data-parallel replicas must hold bit-identical parameters after the timed steps: exact integer checksum of the
@@ -424,7 +448,9 @@ def main():
                                        'N=512 images x L=128 latent draws per step, eval-mode BatchNorm, fp32'
                                        if eval_mode else WORKLOADS[a.workload][0]),
                           'global_batch': world * a.batch, 'parallelism': f'dp{world}',
-                          'launch': 'HIP graph replay' if (a.graph and not eval_mode) else 'eager',
+                          'launch': ('HIP graph replay (ClassificationVariationalNetwork.graph_train_step: the whole step captured once, '
+                                     'one host call per step' + (', two graphs with the gradient all-reduce between them' if world > 1 else '') +
+                                     '; --eager times the loop of train_step() calls)') if (a.graph and not eval_mode) else 'eager',
                           'bn_statistics': 'synchronised over ranks' if (a.sync_bn and world > 1) else 'per-rank (local)',
                           'arithmetic': ('fp32 operands, products and accumulation everywhere; the stride-1 and 4-phase 5x5 layers '
                                          'accumulate each fp32 product from 6 bf16 MFMA products of exactly 3-way split operands (dropped terms < 2^-24 of '
@@ -433,7 +459,7 @@ def main():
                                          if (a.dtype == 'f32' and os.environ.get('JVAE_X3', '1') != '0') else
                                          ('fp32 MFMA in every layer' if a.dtype == 'f32' else
                                           'bf16 activations / MFMA operands, fp32 accumulation, statistics, losses, optimiser'))},
-               'final_loss': float(losses['total'].detach().mean())}
+               'final_loss': final_loss}
         if replicas is not None:
             out['replicas_identical'] = len(set(replicas)) == 1
             out['replica_param_checksums'] = replicas
@@ -444,7 +470,9 @@ def main():
             out['step_throughput_vs_f32_mfma_peak'] = value / world * WORKLOADS[a.workload][1] / (MFMA_F32_PEAK if a.dtype == 'f32' else MFMA_BF16_PEAK)
         # the roofline probes and the CPU baseline belong to the headline config (JVAE_BENCH_NO_PROBES=1: kernel traces of the step alone)
         if a.workload == 2 and a.dtype == 'f32' and not eval_mode and os.environ.get('JVAE_BENCH_NO_PROBES') != '1':
-            out['roofline'] = dominant_kernel_roofline(device, in_step_ms=probe.times_ms() if probe is not None else None)
+            out['roofline'] = dominant_kernel_roofline(device, in_step_ms=probe.times_ms() if probe is not None else None,
+                                                       where=('%d eager train_step() calls run right after the timed graph-replay region (events cannot be '
+                                                              'recorded inside a captured graph)' % probe_steps) if a.graph else 'the timed steps')
             out['roofline_wgrad'] = wgrad_kernel_roofline(device)
             out['roofline_hbm'] = bn_backward_hbm(device)
         if world == 1 and not a.no_cpu_baseline and a.workload == 2 and a.dtype == 'f32' and not eval_mode:

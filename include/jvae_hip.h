@@ -106,7 +106,10 @@ int jvae_channel_sum_f32(const float* t, float* out, int N, int C, int P, int ac
 /* ---- BatchNorm2d (+ fused ReLU) -------------------------------------------------------------------
  * x,y,dx,dy: (N,C,P) with P = H*W.  training != 0: batch statistics (biased variance in the forward,
  * unbiased into running_var, momentum update, num_batches_tracked += 1), else running statistics.
- * relu != 0 fuses the following nn.ReLU (conv.py:214-220).  Backward recomputes the ReLU mask from x. */
+ * `relu` (here and as `in_relu` of the convolutions below) names the activation that follows the BatchNorm in the reference's stacks
+ * (conv.py:214-220, misc.py:24-27), fused into these kernels: 0 none, 1 nn.ReLU, 2 nn.LeakyReLU() - negative slope 0.01, the
+ * reference's activation='leaky' (round 5); any other non-zero value means ReLU.  Backward recomputes the mask from x.  The bf16
+ * ("b8") entry points know 0 and 1 only. */
 size_t jvae_bn_workspace_bytes(int C);
 /* Host-only (no GPU work): launch plan of the BatchNorm kernels - nsplit image parts for the reduction kernels, nchunk for the
  * apply kernels - and the image range [nb, ne) of part j out of `parts` (trailing parts may be EMPTY, nb == ne, never
@@ -255,7 +258,7 @@ int jvae_conv2d_wgrad_aff_b8(const void* x, const void* dy, float* dw, float* db
 int jvae_relu_fwd_b8(const void* x, void* y, long units, void* stream);                /* units of 8 bf16 */
 int jvae_relu_bwd_b8(const void* dy, const void* y, void* dx, long units, void* stream);
 
-/* ---- activations (kind 0 identity, 1 ReLU, 2 sigmoid); backward takes the forward OUTPUT ---------- */
+/* ---- activations (kind 0 identity, 1 ReLU, 2 sigmoid, 3 leaky ReLU with slope 0.01); backward takes the forward OUTPUT ---------- */
 int jvae_act_fwd_f32(const float* x, float* y, long n, int kind, void* stream);
 int jvae_act_bwd_f32(const float* dy, const float* y, float* dx, long n, int kind, void* stream);
 

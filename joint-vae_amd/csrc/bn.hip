@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
             const long off = pi(i);
             f32x4 v = *reinterpret_cast<const f32x4*>(x + off);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { const float t = fmaf(v[e], sc, sh); v[e] = relu ? fmaxf(t, 0.f) : t; }
+            for (int e = 0; e < 4; ++e) { const float t = fmaf(v[e], sc, sh); v[e] = jvae_act(t, relu); }
             *reinterpret_cast<f32x4*>(y + off) = v;
         }
     } else {
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
             const long n = nb + i / P, q = i % P;
             const long off = (n * C + c) * (long)P + q;
             const float t = fmaf(x[off], sc, sh);
-            y[off] = relu ? fmaxf(t, 0.f) : t;
+            y[off] = jvae_act(t, relu);
         }
     }
 }
@@ -207,10 +207,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
                                                             float* __restrict__ partial, int N, int C, int P, int nsplit,
-                                                            int relu) {
+                                                            int relu, int rev) {
     __shared__ float red[17];
-    const int c = blockIdx.x, s = (relu & 2) ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.y;
-    relu &= 1;
+    const int c = blockIdx.x, s = rev ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.y;    // rev: walk the image parts downwards
+    const float neg = relu == JVAE_ACT_LEAKY ? JVAE_LEAKY_SLOPE : 0.f;       // gradient factor where the pre-activation is <= 0
     const float mu = mean[c], is = invstd[c];
     const float g_ = gamma ? gamma[c] : 1.f, b_ = beta ? beta[c] : 0.f;
     float sc, sh;
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float g = gv[e];
-                if (relu && !(fmaf(xv[e], sc, sh) > 0.f)) g = 0.f;
+                if (relu && !(fmaf(xv[e], sc, sh) > 0.f)) g *= neg;
                 s1 += g; s2 += g * ((xv[e] - mu) * is);
             }
         }
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
             const long idx = (n * C + c) * (long)P + q;
             const float xv = x[idx];
             float g = dy[idx];
-            if (relu && !(fmaf(xv, sc, sh) > 0.f)) g = 0.f;
+            if (relu && !(fmaf(xv, sc, sh) > 0.f)) g *= neg;
             s1 += g; s2 += g * ((xv - mu) * is);
         }
     }
@@ -260,10 +260,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ partial, float* __restrict__ dx,
                                                            float* dgamma, float* dbeta, int accumulate,
                                                            int N, int C, int P, int nsplit, int nchunk, int relu,
-                                                           const float* __restrict__ gsums, int count_mult) {
+                                                           const float* __restrict__ gsums, int count_mult, int rev) {
     __shared__ float ms[2];
-    const int c = blockIdx.x, j = (relu & 2) ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.y;
-    relu &= 1;
+    const int c = blockIdx.x, j = rev ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.y;
+    const float neg = relu == JVAE_ACT_LEAKY ? JVAE_LEAKY_SLOPE : 0.f;
     if (threadIdx.x == 0) {
         double s1 = 0., s2 = 0.;
         for (int s = 0; s < nsplit; ++s) {
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float g = gv[e];
-                if (relu && !(fmaf(xv[e], sc, sh) > 0.f)) g = 0.f;
+                if (relu && !(fmaf(xv[e], sc, sh) > 0.f)) g *= neg;
                 gv[e] = k * (g - m1 - ((xv[e] - mu) * is) * m2);
             }
             *reinterpret_cast<f32x4*>(dx + off) = gv;
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
             const long idx = (n * C + c) * (long)P + q;
             const float xv = x[idx];
             float g = dy[idx];
-            if (relu && !(fmaf(xv, sc, sh) > 0.f)) g = 0.f;
+            if (relu && !(fmaf(xv, sc, sh) > 0.f)) g *= neg;
             dx[idx] = k * (g - m1 - ((xv - mu) * is) * m2);
         }
     }
@@ -402,7 +402,7 @@ static int bn_fwd_impl(const float* x, const float* gamma, const float* beta,
     }
     const int nc = pick_chunk(N, C, P);
     hipLaunchKernelGGL(bn_apply_kernel, dim3(C, nc), dim3(256), 0, st, x, partial, gamma, beta, running_mean, running_var,
-                       num_batches_tracked, save_mean, save_invstd, y, N, C, P, ns, nc, momentum, eps, training, relu,
+                       num_batches_tracked, save_mean, save_invstd, y, N, C, P, ns, nc, momentum, eps, training, jvae_act_kind(relu),
                        ext ? 1 : 0, ext_pivot, count_mult > 0 ? count_mult : 1);
     JVAE_LAUNCH_CHECK();
     return 0;
@@ -477,14 +477,14 @@ int jvae_bn_bwd_f32(const float* dy, const float* x, const float* gamma, const f
     // that the producing dgrad kernel wrote last - and the apply pass walks them upwards, i.e. starts on what the reduction
     // read last: 113-118 us instead of 120-124 for the 134 MB activation (two 268 MB sweeps), about 1 % of the step.
     // JVAE_BN_ORDER (bit 0: reduce downwards, bit 1: apply downwards; default 1) is the A/B switch; 0 and 3 measure alike.
-    static int order = -1;
-    if (order < 0) { const char* e = getenv("JVAE_BN_ORDER"); order = e ? atoi(e) : 1; }
+    static const int order = [] { const char* e = getenv("JVAE_BN_ORDER"); return e ? atoi(e) : 1; }();     // (thread-safe static init)
+    relu = jvae_act_kind(relu);
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C, ns), dim3(256), 0, st, dy, x, gamma, beta, save_mean, save_invstd,
-                       partial, N, C, P, ns, relu | ((order & 1) ? 2 : 0));
+                       partial, N, C, P, ns, relu, order & 1);
     JVAE_LAUNCH_CHECK();
     const int nc = pick_chunk(N, C, P);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(C, nc), dim3(256), 0, st, dy, x, gamma, beta, save_mean, save_invstd,
-                       partial, dx, dgamma, dbeta, accumulate, N, C, P, ns, nc, relu | ((order & 2) ? 2 : 0), (const float*)nullptr, 1);
+                       partial, dx, dgamma, dbeta, accumulate, N, C, P, ns, nc, relu, (const float*)nullptr, 1, (order >> 1) & 1);
     JVAE_LAUNCH_CHECK();
     return 0;
 }
@@ -533,7 +533,7 @@ int jvae_bn_bwd_sums_f32(const float* dy, const float* x, const float* gamma, co
     const int ns = N > 0 ? pick_split(N, C, P) : 1;
     if (N > 0) {
         hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C, ns), dim3(256), 0, st, dy, x, gamma, beta, save_mean, save_invstd,
-                           (float*)ws, N, C, P, ns, relu);
+                           (float*)ws, N, C, P, ns, jvae_act_kind(relu), 0);
         JVAE_LAUNCH_CHECK();
     } else {
         hipError_t e = hipMemsetAsync(ws, 0, sizeof(float) * 2 * (size_t)C, st);
@@ -556,7 +556,7 @@ int jvae_bn_bwd_sync_f32(const float* dy, const float* x, const float* gamma, co
     if (N == 0) return 0;
     const int nc = pick_chunk(N, C, P);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(C, nc), dim3(256), 0, (hipStream_t)stream, dy, x, gamma, beta, save_mean,
-                       save_invstd, local_sums, dx, dgamma, dbeta, accumulate, N, C, P, 1, nc, relu, global_sums, world);
+                       save_invstd, local_sums, dx, dgamma, dbeta, accumulate, N, C, P, 1, nc, jvae_act_kind(relu), global_sums, world, 0);
     JVAE_LAUNCH_CHECK();
     return 0;
 }

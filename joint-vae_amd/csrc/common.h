@@ -179,12 +179,29 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 #define JVAE_ACT_RELU 1
 #define JVAE_ACT_LEAKY 2
 #define JVAE_LEAKY_SLOPE 0.01f
+__host__ __device__ __forceinline__ int jvae_act_kind(int relu) { return relu == JVAE_ACT_LEAKY ? JVAE_ACT_LEAKY : (relu ? JVAE_ACT_RELU : JVAE_ACT_NONE); }
+__device__ __forceinline__ float jvae_act(float t, int kind) {
+    return kind == JVAE_ACT_RELU ? fmaxf(t, 0.f) : (kind == JVAE_ACT_LEAKY ? fmaxf(t, JVAE_LEAKY_SLOPE * t) : t);
+}
 
 // a = [relu](v*s + t) on a float4 (deferred BatchNorm of a convolution input; the same fmaf as bn_coef / bn_apply_kernel,
 // so the ReLU mask BatchNorm-backward recomputes is the one applied here)
 __device__ __forceinline__ f32x4 aff4(f32x4 v, float s, float t, int relu) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) { const float x = fmaf(v[j], s, t); v[j] = relu ? fmaxf(x, 0.f) : x; }
+    return v;
+}
+// ... with leaky ReLU instead (the AFF = 2 instantiations of the convolution kernels: the ReLU ones keep their code)
+__device__ __forceinline__ f32x4 aff4_leaky(f32x4 v, float s, float t) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const float x = fmaf(v[j], s, t); v[j] = fmaxf(x, JVAE_LEAKY_SLOPE * x); }
+    return v;
+}
+
+// ... with the activation kind at run time (the leaky-ReLU instantiations of kernels whose two operand sides may differ)
+__device__ __forceinline__ f32x4 aff4_kind(f32x4 v, float s, float t, int kind) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = jvae_act(fmaf(v[j], s, t), kind);
     return v;
 }
 

@@ -56,7 +56,7 @@ struct FwdGeom {
     static constexpr int WS = CC * 25 * WCOLS;
 };
 
-template <int S, int OW, int MT, int NT, int CC, bool AFF>
+template <int S, int OW, int MT, int NT, int CC, int AFF>      // AFF: 0 plain input, 1 deferred BatchNorm (+ReLU by flag), 2 ... + leaky ReLU
 __global__ __launch_bounds__(256, 2) void conv5_fwd_kernel(FwdP p) {
     using G = FwdGeom<S, OW, MT, NT, CC>;
     __shared__ __attribute__((aligned(16))) float lds[G::XS + G::WS];
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256, 2) void conv5_fwd_kernel(FwdP p) {
                 const int lr = t % G::ROWS; t /= G::ROWS;
                 const int c = t % CC, im = t / CC;
                 *reinterpret_cast<f32x4*>(&Xs[(im * CC + c) * G::CH + lr * G::WP + 4 + x4 * 4]) =
-                    AFF ? aff4(rx[k], rsc[AFF ? k : 0], rsh[AFF ? k : 0], p.aff.relu) : rx[k];
+                    AFF == 2 ? aff4_leaky(rx[k], rsc[AFF ? k : 0], rsh[AFF ? k : 0]) : (AFF ? aff4(rx[k], rsc[AFF ? k : 0], rsh[AFF ? k : 0], p.aff.relu) : rx[k]);
             }
         }
 #pragma unroll
@@ -268,8 +268,9 @@ int launch_fwd(const FwdP& p, hipStream_t st) {
     dim3 grid((unsigned)((pixels + G::PIX - 1) / G::PIX), (unsigned)(p.Cout / G::WCOLS));
     if (G::OHW < G::PIX) grid.x = (unsigned)((p.N + G::NIMG - 1) / G::NIMG);
     g_last_splits = (int)grid.x;
-    if (p.aff.sc) hipLaunchKernelGGL((conv5_fwd_kernel<S, OW, MT, NT, CC, true>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((conv5_fwd_kernel<S, OW, MT, NT, CC, false>), grid, dim3(256), 0, st, p);
+    if (p.aff.sc && p.aff.relu == JVAE_ACT_LEAKY) hipLaunchKernelGGL((conv5_fwd_kernel<S, OW, MT, NT, CC, 2>), grid, dim3(256), 0, st, p);
+    else if (p.aff.sc) hipLaunchKernelGGL((conv5_fwd_kernel<S, OW, MT, NT, CC, 1>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((conv5_fwd_kernel<S, OW, MT, NT, CC, 0>), grid, dim3(256), 0, st, p);
     JVAE_LAUNCH_CHECK();
     return 0;
 }

@@ -4,8 +4,8 @@
 // With 3 output channels a 32-wide MFMA row/column tile would be 90 % padding, so this layer runs as a
 // register-blocked direct convolution instead: one thread owns 4 horizontally adjacent output pixels x CO
 // channels (4*CO accumulators); per (input channel, kernel row) it reads 12 patch values with three aligned
-// ds_read_b128 and 5*CO weights (wave-uniform LDS broadcast) and issues 20*CO FMAs.  A 256-thread workgroup
-// covers 1024 pixels (32 rows of a 32-wide image, 16 rows of a 64-wide one); input channels are staged 8 at a
+// ds_read_b128, takes its 5*CO weights as scalar operands and issues 20*CO FMAs.  A 256-thread workgroup
+// covers 1024 pixels (32 rows of a 32-wide image, 16 rows of a 64-wide one); input channels are staged 4 at a
 // time, next chunk prefetched into registers under the FMAs.
 #include <stdlib.h>
 #include "common.h"
@@ -24,110 +24,7 @@ struct SmP {
     InAff aff;           // deferred BatchNorm(+ReLU) of the input
 };
 
-template <int OW, int CO, int CC>
-__global__ __launch_bounds__(256) void conv5_smallco_kernel(SmP p) {
-    constexpr int OH = OW;
-    constexpr int TH = 1024 / OW;                  // rows per workgroup
-    constexpr int ROWS = TH + 4;
-    constexpr int WP = OW + 8;                     // data at col 4 (16-byte aligned), halo 2 each side (P <= 4)
-    constexpr int CH = ROWS * WP;
-    constexpr int XS = CC * CH;
-    constexpr int WL = CC * 5 * 5 * 4;             // [c][kh][kw][co padded to 4]
-    __shared__ __attribute__((aligned(16))) float lds[XS + WL];
-    float* Xs = lds;
-    float* Wl = lds + XS;
-
-    const int tid = threadIdx.x;
-    constexpr int TPI = OH / TH;                   // tiles per image
-    const int n = blockIdx.x / TPI, row0 = (blockIdx.x % TPI) * TH;
-    constexpr int XQ = OW / 4;
-    const int r = tid / XQ, xq = tid % XQ;         // this thread: row r, pixels 4*xq .. 4*xq+3
-
-    for (int i = tid; i < XS / 4; i += 256) reinterpret_cast<f32x4*>(Xs)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    float acc[CO][4];
-#pragma unroll
-    for (int o = 0; o < CO; ++o)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[o][j] = 0.f;
-
-    constexpr int W4 = OW / 4;
-    constexpr int XUNITS = CC * ROWS * W4;
-    constexpr int XU = (XUNITS + 255) / 256;
-    f32x4 rx[XU];
-    float rsc[XU], rsh[XU];         // deferred-BatchNorm coefficients, applied when the units are written to LDS
-    const int in_row0 = row0 - p.P;
-    auto gload = [&](int c0) {
-#pragma unroll
-        for (int k = 0; k < XU; ++k) {
-            const int u = tid + k * 256;
-            const int x4 = u % W4;
-            const int t = u / W4;
-            const int lr = t % ROWS, c = t / ROWS;
-            const int ir = in_row0 + lr, ch = c0 + c;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            float sc = 0.f, sh = 0.f;
-            if (u < XUNITS && ir >= 0 && ir < OH && ch < p.Cin) {
-                v = *reinterpret_cast<const f32x4*>(p.in + (((long)n * p.Cin + ch) * OH + ir) * OW + x4 * 4);
-                if (p.aff.sc) { sc = p.aff.sc[ch]; sh = p.aff.sh[ch]; }
-            }
-            rx[k] = v; rsc[k] = sc; rsh[k] = sh;
-        }
-    };
-    gload(0);
-    for (int c0 = 0; c0 < p.Cin; c0 += CC) {
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < XU; ++k) {
-            const int u = tid + k * 256;
-            if (u < XUNITS) {
-                const int x4 = u % W4;
-                const int t = u / W4;
-                const int lr = t % ROWS, c = t / ROWS;
-                *reinterpret_cast<f32x4*>(&Xs[c * CH + lr * WP + 4 + x4 * 4]) =
-                    p.aff.sc ? aff4(rx[k], rsc[k], rsh[k], p.aff.relu) : rx[k];
-            }
-        }
-        for (int i = tid; i < CC * 25 * 4; i += 256) {           // Wl[c][tap][co]
-            const int co = i & 3, tap = (i >> 2) % 25, c = i / 100;
-            float v = 0.f;
-            if (co < CO && c0 + c < p.Cin) v = p.w[((long)co * p.Cin + c0 + c) * 25 + tap];
-            Wl[i] = v;
-        }
-        __syncthreads();
-        if (c0 + CC < p.Cin) gload(c0 + CC);
-#pragma unroll 2
-        for (int c = 0; c < CC; ++c) {
-#pragma unroll
-            for (int kh = 0; kh < 5; ++kh) {
-                // 12 consecutive patch values starting at lds col 4*xq (input col 4*xq - 4)
-                const float* row = &Xs[c * CH + (r + kh) * WP + 4 * xq];
-                const f32x4 v0 = *reinterpret_cast<const f32x4*>(row);
-                const f32x4 v1 = *reinterpret_cast<const f32x4*>(row + 4);
-                const f32x4 v2 = *reinterpret_cast<const f32x4*>(row + 8);
-                const float in12[12] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3], v2[0], v2[1], v2[2], v2[3]};
-#pragma unroll
-                for (int kw = 0; kw < 5; ++kw) {
-                    const f32x4 wv = *reinterpret_cast<const f32x4*>(&Wl[((c * 5 + kh) * 5 + kw) * 4]);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float xv = in12[j + kw + 4 - 2];   // lds col = x + kw - P + 4 relative to 4*xq, P == 2
-#pragma unroll
-                        for (int o = 0; o < CO; ++o) acc[o][j] = fmaf(wv[o], xv, acc[o][j]);
-                    }
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int o = 0; o < CO; ++o) {
-        const float b = p.bias ? p.bias[o] : 0.f;
-        f32x4 v = {acc[o][0] + b, acc[o][1] + b, acc[o][2] + b, acc[o][3] + b};
-        *reinterpret_cast<f32x4*>(p.out + (((long)n * CO + o) * OH + row0 + r) * OW + 4 * xq) = v;
-    }
-}
-
-// Round 4 form (default; JVAE_SMALLCO_V2=0 selects the kernel above for an A/B).  What the first form was bound by: per
+// Round 4 form (the first form - weights as wave-uniform LDS broadcasts - left the tree in round 5).  What that one was bound by: per
 // (input channel, kernel row) a wave issued 3 + 5 ds_read_b128 - 3 for its 12 patch values, 5 for the 5 x CO weights, read as
 // wave-uniform LDS broadcasts - for 60 FMAs: 4 SIMDs x 8 reads x 4 LDS cycles = 128 LDS cycles per 120 FMA cycles.  The LDS,
 // not the vector ALU, set the pace (107 us for 5.03 GFLOP at N = 1024: 47 TFLOP/s of 157).  Here the weights never touch the
@@ -136,7 +33,7 @@ __global__ __launch_bounds__(256) void conv5_smallco_kernel(SmP p) {
 // then serves 3 reads per 60 FMAs.  CC = 4 input channels per stage (23 KB): four workgroups per CU, so the 1024 workgroups
 // of the 32 x 32 head (one image each) are all resident at once - the first form ran 768 at a time, a second round for the
 // last third.
-template <int OW, int CO, int CC>
+template <int OW, int CO, int CC, bool LEAKY = false>
 __global__ __launch_bounds__(256, 4) void conv5_smallco2_kernel(SmP p) {
     constexpr int OH = OW;
     constexpr int TH = 1024 / OW;                  // rows per workgroup
@@ -201,7 +98,7 @@ __global__ __launch_bounds__(256, 4) void conv5_smallco2_kernel(SmP p) {
                 const int lr = t % ROWS, c = t / ROWS;
                 const int ir = in_row0 + lr, ch = c0 + c;
                 f32x4 v = rx[k];                   // padding rows / missing channels hold zeros and stay zeros
-                if (p.aff.sc && ir >= 0 && ir < OH && ch < p.Cin) v = aff4(v, ctab[ch], ctab[256 + ch], p.aff.relu);
+                if (p.aff.sc && ir >= 0 && ir < OH && ch < p.Cin) v = LEAKY ? aff4_leaky(v, ctab[ch], ctab[256 + ch]) : aff4(v, ctab[ch], ctab[256 + ch], p.aff.relu);
                 *reinterpret_cast<f32x4*>(&Xs[c * CH + lr * WP + 4 + x4 * 4]) = v;
             }
         }
@@ -363,26 +260,17 @@ __global__ __launch_bounds__(256, 4) void conv5_smallci_kernel(SciP p) {
 template <int OW>
 int launch_sm(const SmP& p, int CO, hipStream_t st) {
     dim3 grid((unsigned)(p.N * (OW * OW / 1024)));
-    static int v2 = -1;
-    if (v2 < 0) { const char* e = getenv("JVAE_SMALLCO_V2"); v2 = e ? atoi(e) : 1; }
-    if (v2) {
-        switch (CO) {
-            case 1: hipLaunchKernelGGL((conv5_smallco2_kernel<OW, 1, 4>), grid, dim3(256), 0, st, p); break;
-            case 2: hipLaunchKernelGGL((conv5_smallco2_kernel<OW, 2, 4>), grid, dim3(256), 0, st, p); break;
-            case 3: hipLaunchKernelGGL((conv5_smallco2_kernel<OW, 3, 4>), grid, dim3(256), 0, st, p); break;
-            case 4: hipLaunchKernelGGL((conv5_smallco2_kernel<OW, 4, 4>), grid, dim3(256), 0, st, p); break;
-            default: return JVAE_ENOTSUP;
-        }
-        JVAE_LAUNCH_CHECK();
-        return 0;
-    }
+    const bool leaky = p.aff.sc && p.aff.relu == JVAE_ACT_LEAKY;
+#define SM_CASE(CO_) \
+    case CO_: \
+        if (leaky) hipLaunchKernelGGL((conv5_smallco2_kernel<OW, CO_, 4, true>), grid, dim3(256), 0, st, p); \
+        else hipLaunchKernelGGL((conv5_smallco2_kernel<OW, CO_, 4, false>), grid, dim3(256), 0, st, p); \
+        break;
     switch (CO) {
-        case 1: hipLaunchKernelGGL((conv5_smallco_kernel<OW, 1, 8>), grid, dim3(256), 0, st, p); break;
-        case 2: hipLaunchKernelGGL((conv5_smallco_kernel<OW, 2, 8>), grid, dim3(256), 0, st, p); break;
-        case 3: hipLaunchKernelGGL((conv5_smallco_kernel<OW, 3, 8>), grid, dim3(256), 0, st, p); break;
-        case 4: hipLaunchKernelGGL((conv5_smallco_kernel<OW, 4, 8>), grid, dim3(256), 0, st, p); break;
+        SM_CASE(1) SM_CASE(2) SM_CASE(3) SM_CASE(4)
         default: return JVAE_ENOTSUP;
     }
+#undef SM_CASE
     JVAE_LAUNCH_CHECK();
     return 0;
 }

@@ -46,7 +46,7 @@ struct T2Geom {
 
 // NT = 1: 64 accumulator registers; <= 128 VGPRs keeps 4 workgroups per CU resident (measured: 134 VGPRs = 3 per CU
 // costs 15 %)
-template <int WS, int NT, int CC, bool AFF>
+template <int WS, int NT, int CC, int AFF>      // AFF: 0 plain input, 1 deferred BatchNorm (+ReLU by flag), 2 ... + leaky ReLU
 __global__ __launch_bounds__(256, NT == 1 ? 4 : 2) void convt2_kernel(T2P p) {
     using G = T2Geom<WS, NT, CC>;
     __shared__ __attribute__((aligned(16))) float lds[G::XS + G::WSZ];
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 4 : 2) void convt2_kernel(T2P p) {
                 const int lr = t % G::ROWS; t /= G::ROWS;
                 const int c = t % CC, i2 = t / CC;
                 *reinterpret_cast<f32x4*>(&Xs[(i2 * CC + c) * G::CH + lr * G::WP + 4 + x4 * 4]) =
-                    AFF ? aff4(rx[k], rsc[AFF ? k : 0], rsh[AFF ? k : 0], p.aff.relu) : rx[k];
+                    AFF == 2 ? aff4_leaky(rx[k], rsc[AFF ? k : 0], rsh[AFF ? k : 0]) : (AFF ? aff4(rx[k], rsc[AFF ? k : 0], rsh[AFF ? k : 0], p.aff.relu) : rx[k]);
             }
         }
 #pragma unroll
@@ -226,8 +226,9 @@ int launch_t2(const T2P& p, hipStream_t st) {
     dim3 grid(G::HSWS >= G::PIX ? (unsigned)((long)p.N * G::HSWS / G::PIX) : (unsigned)((p.N + G::NIMG - 1) / G::NIMG),
               (unsigned)(p.O / G::WCOLS));
     g_t2_splits = (int)grid.x;
-    if (p.aff.sc) hipLaunchKernelGGL((convt2_kernel<WS, NT, 4, true>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((convt2_kernel<WS, NT, 4, false>), grid, dim3(256), 0, st, p);
+    if (p.aff.sc && p.aff.relu == JVAE_ACT_LEAKY) hipLaunchKernelGGL((convt2_kernel<WS, NT, 4, 2>), grid, dim3(256), 0, st, p);
+    else if (p.aff.sc) hipLaunchKernelGGL((convt2_kernel<WS, NT, 4, 1>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((convt2_kernel<WS, NT, 4, 0>), grid, dim3(256), 0, st, p);
     JVAE_LAUNCH_CHECK();
     return 0;
 }

@@ -364,7 +364,7 @@ __global__ __launch_bounds__(256, 2) void convt2s_x3_kernel(T2X3P p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     u32x4* Xs = reinterpret_cast<u32x4*>(lds_raw);            // [3 planes][XS]
     u32x4* Ws = Xs + 3 * G::XS;                                // [2 buffers][WGS]
-    __shared__ float bias_s[32];
+    __shared__ __attribute__((aligned(16))) float bias_s[32];
     __shared__ float red_s[4 * 32 * 2];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -529,28 +529,27 @@ __global__ __launch_bounds__(256, 2) void convt2s_x3_kernel(T2X3P p) {
     int gbase = 0;                                             // weight groups of the earlier K steps (buffer parity)
     for (int kb = 0; kb < KB; ++kb) {
         const bool nextk = kb + 1 < KB;
-        // Fragments are SINGLE-buffered: the six products of a tap are ordered so that every plane's registers die as early as
-        // possible - weight planes lo, mid, hi after products 0, 3, 5, patch planes hi, mid, lo after products 2, 4, 5 - and the next
-        // tap's (next position's) plane is read into them right behind its last use, 2 - 5 products (130 - 320 matrix-pipe cycles)
-        // ahead of its first one.  (The order inside a tap is free: the accumulators hold the sums of all earlier taps anyway.)
-        u32x4 fa[3][2], fb[3][NPT];                            // [plane hi | mid | lo][channel tile | pixel tile]
-        auto fragA = [&](int buf, int tl, int pl) {
+        // Fragment registers: the six products of a tap are ordered so that every plane dies as early as possible (weight planes
+        // lo, mid, hi after products 0, 3, 5, patch planes hi, mid, lo after 2, 4, 5); see the read-ahead rules at the products.
+        u32x4 fa[2][3][2], fb[3][NPT];                         // [tap parity][plane hi | mid | lo][channel tile] | [plane][pixel tile]
+        auto fragA = [&](int buf, int tl, int pl, int par) {
             const u32x4* Wb = Ws + buf * G::WGS + kq * 32 + l15;
 #pragma unroll
-            for (int ct = 0; ct < 2; ++ct) fa[pl][ct] = Wb[((tl * 3 + pl) * 4) * 32 + ct * 16];
+            for (int ct = 0; ct < 2; ++ct) fa[par][pl][ct] = Wb[((tl * 3 + pl) * 4) * 32 + ct * 16];
         };
         auto fragB = [&](int off, int pl) {
 #pragma unroll
             for (int pt = 0; pt < NPT; ++pt) fb[pl][pt] = Xs[pl * G::XS + pixoff[pt] + off];
         };
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) { fragA(gbase & 1, 0, pl); fragB(T::dh(0) * G::WP + T::dw(0), pl); }
+        for (int pl = 0; pl < 3; ++pl) { fragA(gbase & 1, 0, pl, 0); fragB(T::dh(0) * G::WP + T::dw(0), pl); }
         auto tapstep = [&](auto t_c) {
             constexpr int t = decltype(t_c)::value;
             constexpr int g = T::group(t), tl = t - T::gstart(g);
             constexpr bool first = tl == 0, last = t + 1 == T::gstart(g + 1);
             constexpr bool newpos = t + 1 < 25 && T::pos(t + 1 < 25 ? t + 1 : t) != T::pos(t);
             constexpr int noff_h = T::dh(t + 1 < 25 ? t + 1 : t), noff_w = T::dw(t + 1 < 25 ? t + 1 : t);
+            constexpr int par = t & 1;
             const int buf = (gbase + g) & 1;
             if constexpr (first) {
                 // staging of the NEXT weight group behind this group's first fragment reads: buffer (gg + 1) & 1 was last read in
@@ -571,7 +570,11 @@ __global__ __launch_bounds__(256, 2) void convt2s_x3_kernel(T2X3P p) {
                 if constexpr (g == T::NG - 1) { if (nextk) gloadX(kb + 1); }
             }
             constexpr int ph = T::phase(t);
-            // (weight plane, patch plane) of the six products; planes 0 = hi, 1 = mid, 2 = lo
+            // (weight plane, patch plane) of the six products; planes 0 = hi, 1 = mid, 2 = lo.  The patch planes die after products
+            // 2 / 4 / 5 (hi, mid, lo) and a new POSITION's plane is read into the dead registers right there, 3-5 products ahead of
+            // its first use; the next tap's weight planes go into the other register set behind products 0 (lo, mid) and 1 (hi) -
+            // 4 or more products (16 MFMAs = 256+ matrix-pipe cycles) ahead: the lo plane's old registers are dead by then, the mid and
+            // hi planes cost 16 registers.  (The order inside a tap is free: the accumulators hold the sums of all earlier taps.)
             constexpr int WPL[6] = {2, 1, 0, 1, 0, 0}, XPL[6] = {0, 0, 0, 1, 1, 2};
 #pragma unroll
             for (int q = 0; q < 6; ++q) {
@@ -580,18 +583,15 @@ __global__ __launch_bounds__(256, 2) void convt2s_x3_kernel(T2X3P p) {
                 for (int pt = 0; pt < NPT; ++pt)
 #pragma unroll
                     for (int ct = 0; ct < 2; ++ct)
-                        acc[ph][pt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[WPL[q]][ct]),
+                        acc[ph][pt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[par][WPL[q]][ct]),
                                                                                   __builtin_bit_cast(bf16x8, fb[XPL[q]][pt]),
                                                                                   acc[ph][pt][ct], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                // read-ahead into the registers that just died (same group: the weight buffer is valid; the patch does not change
-                // inside a K step, so its read-ahead may also cross the group's closing barrier)
-                if constexpr (!last) {
-                    if (q == 0) fragA(buf, tl + 1, 2);
-                    if (q == 3) fragA(buf, tl + 1, 1);
-                    if (q == 5) fragA(buf, tl + 1, 0);
+                if constexpr (!last) {                 // (same group: its weight buffer is valid)
+                    if (q == 0) { fragA(buf, tl + 1, 2, par ^ 1); fragA(buf, tl + 1, 1, par ^ 1); }
+                    if (q == 1) fragA(buf, tl + 1, 0, par ^ 1);
                 }
-                if constexpr (newpos) {
+                if constexpr (newpos) {                // (the patch does not change inside a K step: also across the closing barrier)
                     if (q == 2) fragB(noff_h * G::WP + noff_w, 0);
                     if (q == 4) fragB(noff_h * G::WP + noff_w, 1);
                     if (q == 5) fragB(noff_h * G::WP + noff_w, 2);
@@ -602,7 +602,7 @@ __global__ __launch_bounds__(256, 2) void convt2s_x3_kernel(T2X3P p) {
                 lds_barrier();
                 if constexpr (t + 1 < 25) {                                // first tap of the next group (its buffer is complete now)
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) fragA(buf ^ 1, 0, pl);
+                    for (int pl = 0; pl < 3; ++pl) fragA(buf ^ 1, 0, pl, par ^ 1);
                 }
             }
         };
@@ -614,31 +614,16 @@ __global__ __launch_bounds__(256, 2) void convt2s_x3_kernel(T2X3P p) {
         }
     }
 
-    // ---- epilogue: lane holds pixel l15 of each 16-pixel tile, channels ct*16 + kq*4 + e, the four output phases
+    // ---- epilogue: lane holds pixel l15 of each 16-pixel tile, channels ct*16 + kq*4 + e, the four output phases.
+    // The BatchNorm sums (pivot = bias) are taken from the bias-free accumulators first (registers only); then the bias goes INTO the
+    // accumulators, four channels at a time, and the two column phases of a row are stored as 8-byte pairs.  Round 5: the first
+    // version added the bias while forming each pair - `make_float2(acc0 + b, acc1 + b)` became `v_pk_add_f32 ... op_sel:[0,1]`
+    // (one bias register broadcast to both halves) two instructions in front of the `global_store_dwordx2` of its result - and,
+    // timing-dependent, lanes 48-63 of the low half reached memory WITHOUT the bias (exactly -bias[c] on 16 outputs of channel
+    // 13 / 29, mostly in a process's first launch: tools/t2_err_probe.py; profiles/NOTES.md).
     constexpr int HB = 2 * G::HS, WB = 2 * WS;
-    float bv[2][4];
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) bv[ct][e] = bias_s[ct * 16 + kq * 4 + e];
-#pragma unroll
-    for (int pt = 0; pt < NPT; ++pt) {
-        const int pix = (wave * NPT + pt) * 16 + l15;
-        const int im = pix / (G::TH * WS), rem = pix % (G::TH * WS);
-        const int n = img0 + im;
-        if (n >= p.N) continue;
-        float* const dst = p.out + (((long)n * p.O + o0 + kq * 4) * HB + 2 * (row0 + rem / WS)) * WB + 2 * (rem % WS);
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int r = 0; r < 2; ++r)
-                    *reinterpret_cast<float2*>(dst + ((long)(ct * 16 + e) * HB + r) * WB) =
-                        make_float2(acc[r * 2][pt][ct][e] + bv[ct][e], acc[r * 2 + 1][pt][ct][e] + bv[ct][e]);
-    }
-    if (p.stats) {                                             // BatchNorm partial sums of the tile (pivot = bias): after the stores
-        float sv[16];                                          // [sum | sum of squares][channel tile][register]
+    float sv[16];                                              // [sum | sum of squares][channel tile][register]
+    if (p.stats) {
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
@@ -654,6 +639,38 @@ __global__ __launch_bounds__(256, 2) void convt2s_x3_kernel(T2X3P p) {
                 sv[ct * 4 + e] = s1;
                 sv[8 + ct * 4 + e] = s2;
             }
+    }
+    {
+        f32x4 bv[2];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) bv[ct] = *reinterpret_cast<const f32x4*>(&bias_s[ct * 16 + kq * 4]);
+        // 32 idle cycles between the arrival of these two broadcast reads and their first use (see the note above)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7" : "+v"(bv[0]), "+v"(bv[1]) :: "memory");
+#pragma unroll
+        for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+            for (int pt = 0; pt < NPT; ++pt)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) acc[ph][pt][ct] += bv[ct];
+    }
+    __builtin_amdgcn_sched_barrier(0);                         // every biased value exists before the first store is formed
+#pragma unroll
+    for (int pt = 0; pt < NPT; ++pt) {
+        const int pix = (wave * NPT + pt) * 16 + l15;
+        const int im = pix / (G::TH * WS), rem = pix % (G::TH * WS);
+        const int n = img0 + im;
+        if (n >= p.N) continue;
+        float* const dst = p.out + (((long)n * p.O + o0 + kq * 4) * HB + 2 * (row0 + rem / WS)) * WB + 2 * (rem % WS);
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+                    *reinterpret_cast<float2*>(dst + ((long)(ct * 16 + e) * HB + r) * WB) =
+                        make_float2(acc[r * 2][pt][ct][e], acc[r * 2 + 1][pt][ct][e]);
+    }
+    if (p.stats) {                                             // ... reduced after the stores have been issued (they drain meanwhile)
         {   // lane l15 of every 16-lane row receives the row total of sv[l15]
             const float tot = row_reduce16(sv);
             const int j = l15 & 7, ch = (j >> 2) * 16 + kq * 4 + (j & 3);

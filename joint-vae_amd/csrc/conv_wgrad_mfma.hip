@@ -49,7 +49,7 @@ struct WgGeom {
     static constexpr int NBT = (NTILE + 3) / 4;               // per wave
 };
 
-template <int S, int WS, int CB, bool PF, bool AFF>
+template <int S, int WS, int CB, bool PF, int AFF>      // AFF: 0 plain operands, 1 deferred BatchNorm (+ReLU by flag), 2 ... with a leaky ReLU on a side
 __global__ __launch_bounds__(256, 2) void conv5_wgrad_kernel(WgP p) {
     using G = WgGeom<S, WS, CB>;
     __shared__ __attribute__((aligned(16))) float lds[G::QS + G::PSZ];
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_kernel(WgP p) {
                 f32x4 v = rq[k];
                 if (AFF && p.aff_q.sc) {
                     const int ir = in_row0 + lr;
-                    if (ir >= 0 && ir < HB && c < cb_here) v = aff4(v, coef[2 * c], coef[2 * c + 1], p.aff_q.relu);
+                    if (ir >= 0 && ir < HB && c < cb_here) v = AFF == 2 ? aff4_kind(v, coef[2 * c], coef[2 * c + 1], p.aff_q.relu) : aff4(v, coef[2 * c], coef[2 * c + 1], p.aff_q.relu);
                 }
                 *reinterpret_cast<f32x4*>(&Qs[c * G::CH + lr * G::WP + 4 + x4 * 4]) = v;
             }
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_kernel(WgP p) {
             if (u < PUNITS) {
                 const int p4 = u % (G::TPIX / 4), a = u / (G::TPIX / 4);
                 f32x4 v = rp[k];
-                if (AFF && p.aff_p.sc && a0 + a < p.Ca) v = aff4(v, coef[2 * (CB + a)], coef[2 * (CB + a) + 1], p.aff_p.relu);
+                if (AFF && p.aff_p.sc && a0 + a < p.Ca) v = AFF == 2 ? aff4_kind(v, coef[2 * (CB + a)], coef[2 * (CB + a) + 1], p.aff_p.relu) : aff4(v, coef[2 * (CB + a)], coef[2 * (CB + a) + 1], p.aff_p.relu);
                 float* d = &Pt[a * G::PPITCH + p4 * 4];
                 d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
             }
@@ -259,8 +259,10 @@ int launch_wg(const WgP& p, hipStream_t st) {
     static_assert((G::QS + G::PSZ) * 4 + 8 * (CB + 32) <= 64 * 1024, "static LDS budget");
     dim3 grid(p.G, (p.Ca + 31) / 32, (p.Cb + CB - 1) / CB);
     // two instantiations: the deferred-BatchNorm transform costs registers / LDS only where it is used
-    if (p.aff_p.sc || p.aff_q.sc) hipLaunchKernelGGL((conv5_wgrad_kernel<S, WS, CB, PF, true>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((conv5_wgrad_kernel<S, WS, CB, PF, false>), grid, dim3(256), 0, st, p);
+    const bool leaky = (p.aff_p.sc && p.aff_p.relu == JVAE_ACT_LEAKY) || (p.aff_q.sc && p.aff_q.relu == JVAE_ACT_LEAKY);
+    if (leaky) hipLaunchKernelGGL((conv5_wgrad_kernel<S, WS, CB, PF, 2>), grid, dim3(256), 0, st, p);
+    else if (p.aff_p.sc || p.aff_q.sc) hipLaunchKernelGGL((conv5_wgrad_kernel<S, WS, CB, PF, 1>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((conv5_wgrad_kernel<S, WS, CB, PF, 0>), grid, dim3(256), 0, st, p);
     JVAE_LAUNCH_CHECK();
     return 0;
 }

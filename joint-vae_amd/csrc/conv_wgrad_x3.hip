@@ -91,7 +91,7 @@ __device__ __forceinline__ bf16x8 tr_pair(const unsigned char* base, int off) {
 
 // SH16: the products run on v_mfma_f32_16x16x32_bf16 (K step = 32 pixels, a 32 x 32 tile = 2 x 2 blocks of 16 x 16) instead of
 // v_mfma_f32_32x32x16_bf16: the same LDS image, the same reads and MFMA cycles per FLOP; the chip holds a higher clock under
-// the 16x16x32 shape (MI355X_MICROARCH.md, DVFS give-back item 7).  JVAE_WGRAD_SH16=0 selects the 32x32x16 form (A/B).
+// the 16x16x32 shape (MI355X_MICROARCH.md, DVFS give-back item 7).  (The 32x32x16 form of this kernel left the tree in round 5.)
 // NPL = 1: the operands are bf16 "B8" tensors (conv_b8.hip: 16-byte units of 8 channels per pixel - exactly the units of the
 // LDS image): no split, ONE plane, one MFMA per product; everything else (LDS image, transposed reads, read-ahead, slabs) is
 // shared with the split-bf16 form.  This is the weight-gradient kernel of the bf16 mode (BASELINE configs[4]).
@@ -108,7 +108,7 @@ __device__ __forceinline__ bf16x8 tr_pair(const unsigned char* base, int off) {
 // (lane, tap) folded into the tile's byte offset; the second 16-channel block is that offset ^ 32.  Keyed on the column, not
 // the slot index, the swizzle needs no padded row pitch (round 2's one-plane version padded it to 16 slots, which the three
 // planes of the split form cannot afford within 80 KB).
-template <int S, int WS, int MODE, bool AFF, bool SH16, int NPL = 3>
+template <int S, int WS, int MODE, int AFF, bool SH16, int NPL = 3>     // AFF: 0 plain operands, 1 deferred BatchNorm (+ReLU by flag), 2 ... with a leaky ReLU (fp32 form only)
 __global__ __launch_bounds__(256, 2) void conv5_wgrad_x3_kernel(WgX3P p) {
     using G = WgX3Geom<S, WS, MODE, NPL>;
     constexpr bool SWZ = SH16 && MODE == 0 && S == 1 && WS >= 16;
@@ -310,13 +310,15 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_x3_kernel(WgX3P p) {
             if constexpr (REGC) {
                 if (aff) {
                     f32x2 a{fmaf(v[0], creg[ci], creg[8 + ci]), fmaf(v[1], creg[ci], creg[8 + ci])};
-                    if (relu) { a[0] = fmaxf(a[0], 0.f); a[1] = fmaxf(a[1], 0.f); }
+                    if constexpr (AFF == 2) { a[0] = jvae_act(a[0], relu); a[1] = jvae_act(a[1], relu); }
+                    else if (relu) { a[0] = fmaxf(a[0], 0.f); a[1] = fmaxf(a[1], 0.f); }
                     v = (live && ci < nch) ? a : f32x2{0.f, 0.f};         // padding rows / missing channels stay exact zeros
                 }
             } else if (AFF && aff && live && ci < nch) {
                 v[0] = fmaf(v[0], sc[ci], sh[ci]);
                 v[1] = fmaf(v[1], sc[ci], sh[ci]);
-                if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); }
+                if constexpr (AFF == 2) { v[0] = jvae_act(v[0], relu); v[1] = jvae_act(v[1], relu); }
+                else if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); }
             }
             vv[ci] = v;
         }
@@ -589,54 +591,50 @@ int launch_wgx3(const WgX3P& p, hipStream_t st) {
     dim3 grid(p.G, (p.Ca + 31) / 32, (p.Cb + 8 * G::NCBQ - 1) / (8 * G::NCBQ));
     if (MODE == 1 || MODE == 3) grid.z = 1;
     const bool aff = p.aff_p.sc || p.aff_q.sc;
+    const bool leaky = (p.aff_p.sc && p.aff_p.relu == JVAE_ACT_LEAKY) || (p.aff_q.sc && p.aff_q.relu == JVAE_ACT_LEAKY);
+    // the stride-2 forms keep ONE register set of (scale, shift) for the side that carries a deferred BatchNorm
+    if (S == 2 && p.aff_p.sc && p.aff_q.sc) return JVAE_ENOTSUP;
     if constexpr (NPL == 1) {
+        if (leaky) return JVAE_ENOTSUP;            // the bf16 one-plane form has ReLU only (cvae.set_compute_dtype refuses 'leaky')
         static bool attr1 = false;
         if (!attr1) {
-            const void* fns[2] = {reinterpret_cast<const void*>(&conv5_wgrad_x3_kernel<S, WS, MODE, false, true, 1>),
-                                  reinterpret_cast<const void*>(&conv5_wgrad_x3_kernel<S, WS, MODE, true, true, 1>)};
+            const void* fns[2] = {reinterpret_cast<const void*>(&conv5_wgrad_x3_kernel<S, WS, MODE, 0, true, 1>),
+                                  reinterpret_cast<const void*>(&conv5_wgrad_x3_kernel<S, WS, MODE, 1, true, 1>)};
             for (const void* f : fns) {
                 hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
                 if (e != hipSuccess) return (int)e;
             }
             attr1 = true;
         }
-        if (aff) hipLaunchKernelGGL((conv5_wgrad_x3_kernel<S, WS, MODE, true, true, 1>), grid, dim3(256), G::LDS_BYTES, st, p);
-        else hipLaunchKernelGGL((conv5_wgrad_x3_kernel<S, WS, MODE, false, true, 1>), grid, dim3(256), G::LDS_BYTES, st, p);
+        if (aff) hipLaunchKernelGGL((conv5_wgrad_x3_kernel<S, WS, MODE, 1, true, 1>), grid, dim3(256), G::LDS_BYTES, st, p);
+        else hipLaunchKernelGGL((conv5_wgrad_x3_kernel<S, WS, MODE, 0, true, 1>), grid, dim3(256), G::LDS_BYTES, st, p);
         JVAE_LAUNCH_CHECK();
         return 0;
     } else {
+    // (the 32x32x16 MFMA shape of this kernel and its JVAE_WGRAD_SH16 switch left the tree in round 5: the 16x16x32 shape has been
+    // the default since round 2 and the other was never part of a test)
     static bool attr_set = false;
     if (!attr_set) {
-        const void* fns[4] = {reinterpret_cast<const void*>(&conv5_wgrad_x3_kernel<S, WS, MODE, false, false>),
-                              reinterpret_cast<const void*>(&conv5_wgrad_x3_kernel<S, WS, MODE, true, false>),
-                              reinterpret_cast<const void*>(&conv5_wgrad_x3_kernel<S, WS, MODE, false, true>),
-                              reinterpret_cast<const void*>(&conv5_wgrad_x3_kernel<S, WS, MODE, true, true>)};
+        const void* fns[3] = {reinterpret_cast<const void*>(&conv5_wgrad_x3_kernel<S, WS, MODE, 0, true>),
+                              reinterpret_cast<const void*>(&conv5_wgrad_x3_kernel<S, WS, MODE, 1, true>),
+                              reinterpret_cast<const void*>(&conv5_wgrad_x3_kernel<S, WS, MODE, 2, true>)};
         for (const void* f : fns) {
             hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
             if (e != hipSuccess) return (int)e;
         }
         attr_set = true;
     }
-    static int sh16 = -1;
-    if (sh16 < 0) { const char* e = getenv("JVAE_WGRAD_SH16"); sh16 = (e && e[0] == '0') ? 0 : 1; }
-    if (sh16) {
-        if (aff) hipLaunchKernelGGL((conv5_wgrad_x3_kernel<S, WS, MODE, true, true>), grid, dim3(256), G::LDS_BYTES, st, p);
-        else hipLaunchKernelGGL((conv5_wgrad_x3_kernel<S, WS, MODE, false, true>), grid, dim3(256), G::LDS_BYTES, st, p);
-    } else {
-        if (aff) hipLaunchKernelGGL((conv5_wgrad_x3_kernel<S, WS, MODE, true, false>), grid, dim3(256), G::LDS_BYTES, st, p);
-        else hipLaunchKernelGGL((conv5_wgrad_x3_kernel<S, WS, MODE, false, false>), grid, dim3(256), G::LDS_BYTES, st, p);
-    }
+    if (leaky) hipLaunchKernelGGL((conv5_wgrad_x3_kernel<S, WS, MODE, 2, true>), grid, dim3(256), G::LDS_BYTES, st, p);
+    else if (aff) hipLaunchKernelGGL((conv5_wgrad_x3_kernel<S, WS, MODE, 1, true>), grid, dim3(256), G::LDS_BYTES, st, p);
+    else hipLaunchKernelGGL((conv5_wgrad_x3_kernel<S, WS, MODE, 0, true>), grid, dim3(256), G::LDS_BYTES, st, p);
     JVAE_LAUNCH_CHECK();
     return 0;
     }
 }
 
-// JVAE_WGRAD_M3=0: the 3-channel layers on the 8-channel x 4-tap tiles of MODE 1 (A/B switch)
-inline int x3_mode(int S, int Cb) {
-    static int m3 = -1;
-    if (m3 < 0) { const char* e = getenv("JVAE_WGRAD_M3"); m3 = (e && e[0] == '0') ? 0 : 1; }
-    return Cb <= 4 && m3 ? 3 : (Cb <= 8 ? 1 : (S == 2 ? 2 : 0));
-}
+// column tiles by the width of the unfolded side: <= 4 channels (the 3-channel image layers): 4 channels x 8 taps (MODE 3; its
+// predecessor - MODE 1 for these layers too - and the JVAE_WGRAD_M3 switch left the tree in round 5), <= 8: 8 channels x 4 taps
+inline int x3_mode(int S, int Cb) { return Cb <= 4 ? 3 : (Cb <= 8 ? 1 : (S == 2 ? 2 : 0)); }
 
 int slab_count_x3(int N, int Ca, int Cb, int S) {
     const int mode = x3_mode(S, Cb);

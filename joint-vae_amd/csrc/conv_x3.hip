@@ -128,7 +128,7 @@ struct X3Geom {
 template <bool SH, int NPT> struct X3Acc { f32x16 t[NPT]; };
 template <int NPT> struct X3Acc<true, NPT> { f32x4 t[NPT][2]; };        // [16-pixel tile][16-channel tile]
 
-template <int S, int OW, int MT, bool AFF, bool SH = false>
+template <int S, int OW, int MT, int AFF, bool SH = false>      // AFF: 0 plain input, 1 deferred BatchNorm (+ReLU by flag), 2 ... + leaky ReLU
 __global__ __launch_bounds__(256, 2) void conv5_x3_kernel(X3P p) {
     using G = X3Geom<S, OW, MT, SH>;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256, 2) void conv5_x3_kernel(X3P p) {
         typedef const __attribute__((address_space(4))) float* const_f32_p;
         float csc[8], csh[8];
         const float relu_lo = p.aff.relu ? 0.f : -__builtin_inff();
-        if constexpr (AFF) {
+        if constexpr (AFF != 0) {
             const const_f32_p gsc = (const_f32_p)(unsigned long long)p.aff.sc, gsh = (const_f32_p)(unsigned long long)p.aff.sh;
 #pragma unroll
             for (int ci = 0; ci < 8; ++ci) {
@@ -287,8 +287,11 @@ __global__ __launch_bounds__(256, 2) void conv5_x3_kernel(X3P p) {
                 for (int ci = 0; ci < 8; ++ci) {
                     const bool keep = live && kb * 16 + h * 8 + ci < p.Cin;
                     f32x2 v = rx[k][ci];                                   // (a stand-in value where !keep: replaced below)
-                    if constexpr (AFF) {                                   // ReLU as max(., lo) with lo = 0 or -inf: no select
+                    if constexpr (AFF == 1) {                              // ReLU as max(., lo) with lo = 0 or -inf: no select
                         v = f32x2{fmaxf(fmaf(v[0], csc[ci], csh[ci]), relu_lo), fmaxf(fmaf(v[1], csc[ci], csh[ci]), relu_lo)};
+                    } else if constexpr (AFF == 2) {                       // leaky ReLU: max(a, 0.01 a)
+                        const float a0 = fmaf(v[0], csc[ci], csh[ci]), a1 = fmaf(v[1], csc[ci], csh[ci]);
+                        v = f32x2{fmaxf(a0, JVAE_LEAKY_SLOPE * a0), fmaxf(a1, JVAE_LEAKY_SLOPE * a1)};
                     }
                     vv[ci] = keep ? v : f32x2{0.f, 0.f};                   // padding rows / missing channels stay exact zeros
                 }
@@ -695,10 +698,13 @@ int launch_x3(const X3P& p, hipStream_t st) {
     static_assert(G::LDS_BYTES + 2048 <= (S == 1 ? 80 : 160) * 1024, "workgroups per CU vs the 160 KB LDS");
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_x3_kernel<S, OW, MT, false, SH>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_x3_kernel<S, OW, MT, 0, SH>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
         if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_x3_kernel<S, OW, MT, true, SH>),
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_x3_kernel<S, OW, MT, 1, SH>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_x3_kernel<S, OW, MT, 2, SH>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
@@ -716,9 +722,10 @@ int launch_x3(const X3P& p, hipStream_t st) {
     if (SH && S == 1 && tpw_on && grid.x % 2 == 0 && (long)grid.x * grid.y >= 2048) { q.tpw = 2; grid.x /= 2; }
     if (q.aff.sc) {
         if (q.Cin > 256) return JVAE_ENOTSUP;
-        hipLaunchKernelGGL((conv5_x3_kernel<S, OW, MT, true, SH>), grid, dim3(256), G::LDS_BYTES, st, q);
+        if (q.aff.relu == JVAE_ACT_LEAKY) hipLaunchKernelGGL((conv5_x3_kernel<S, OW, MT, 2, SH>), grid, dim3(256), G::LDS_BYTES, st, q);
+        else hipLaunchKernelGGL((conv5_x3_kernel<S, OW, MT, 1, SH>), grid, dim3(256), G::LDS_BYTES, st, q);
     } else {
-        hipLaunchKernelGGL((conv5_x3_kernel<S, OW, MT, false, SH>), grid, dim3(256), G::LDS_BYTES, st, q);
+        hipLaunchKernelGGL((conv5_x3_kernel<S, OW, MT, 0, SH>), grid, dim3(256), G::LDS_BYTES, st, q);
     }
     JVAE_LAUNCH_CHECK();
     return 0;

@@ -133,20 +133,20 @@ __global__ __launch_bounds__(256) void xent_bwd_kernel(const float* __restrict__
     for (int c = lane; c < C; c += 64) glogits[(long)r * C + c] = gv * (__expf(row[c] - mx) * inv - (c == t ? 1.f : 0.f));
 }
 
-// kind: 0 identity, 1 relu, 2 sigmoid
+// kind: 0 identity, 1 relu, 2 sigmoid, 3 leaky relu (negative slope 0.01: nn.LeakyReLU(), module/vae_layers/misc.py:24-27)
 __global__ __launch_bounds__(256) void act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long n, int kind) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const float v = x[i];
-        y[i] = kind == 1 ? fmaxf(v, 0.f) : (kind == 2 ? 1.f / (1.f + __expf(-v)) : v);
+        y[i] = kind == 1 ? fmaxf(v, 0.f) : (kind == 2 ? 1.f / (1.f + __expf(-v)) : (kind == 3 ? fmaxf(v, JVAE_LEAKY_SLOPE * v) : v));
     }
 }
 
-// uses the OUTPUT y: relu -> [y > 0], sigmoid -> y (1 - y)
+// uses the OUTPUT y: relu -> [y > 0], sigmoid -> y (1 - y), leaky relu -> [y > 0] + 0.01 [y <= 0] (the sign of y is that of x)
 __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                       float* __restrict__ dx, long n, int kind) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const float g = dy[i], v = y[i];
-        dx[i] = kind == 1 ? (v > 0.f ? g : 0.f) : (kind == 2 ? g * v * (1.f - v) : g);
+        dx[i] = kind == 1 ? (v > 0.f ? g : 0.f) : (kind == 2 ? g * v * (1.f - v) : (kind == 3 ? (v > 0.f ? g : JVAE_LEAKY_SLOPE * g) : g));
     }
 }
 
@@ -453,7 +453,7 @@ int jvae_xent_bwd_f32(const float* logits, const long long* y, const float* g_ce
 }
 
 int jvae_act_fwd_f32(const float* x, float* y, long n, int kind, void* stream) {
-    if (!x || !y || n < 0 || kind < 0 || kind > 2) return JVAE_EINVAL;
+    if (!x || !y || n < 0 || kind < 0 || kind > 3) return JVAE_EINVAL;
     if (n == 0) return 0;
     hipLaunchKernelGGL(act_fwd_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, x, y, n, kind);
     JVAE_LAUNCH_CHECK();
@@ -461,7 +461,7 @@ int jvae_act_fwd_f32(const float* x, float* y, long n, int kind, void* stream) {
 }
 
 int jvae_act_bwd_f32(const float* dy, const float* y, float* dx, long n, int kind, void* stream) {
-    if (!dy || !y || !dx || n < 0 || kind < 0 || kind > 2) return JVAE_EINVAL;
+    if (!dy || !y || !dx || n < 0 || kind < 0 || kind > 3) return JVAE_EINVAL;
     if (n == 0) return 0;
     hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, dy, y, dx, n, kind);
     JVAE_LAUNCH_CHECK();

@@ -386,6 +386,8 @@ class ClassificationVariationalNetwork(nn.Module):
         from module.vae_layers.conv import HipConvStack
         if dtype not in ('fp32', 'bf16'):
             raise ValueError(dtype)
+        if dtype == 'bf16' and self.activation == 'leaky':
+            raise NotImplementedError("the bf16 mode has ReLU kernels only: activation='leaky' (config.ini:113) trains in fp32")
         for m in self.modules():
             if isinstance(m, HipConvStack):
                 m.compute_dtype = dtype

@@ -10,11 +10,13 @@ import torch
 
 from . import lib as L
 
-RELU, SIGMOID, IDENT = 1, 2, 0
+RELU, SIGMOID, IDENT, LEAKY = 1, 2, 0, 3          # jvae_act_* kinds (LEAKY: nn.LeakyReLU(), negative slope 0.01)
+# the `relu` / `in_relu` argument of the BatchNorm and convolution entry points: 0 none, 1 ReLU, 2 leaky ReLU (jvae_hip.h)
+BN_ACT = {IDENT: 0, RELU: 1, LEAKY: 2}
 OVERLAP_WGRAD = True          # weight-gradient kernels on a second HIP stream (see _Conv.backward)
 LAST_WGRAD_ON_MAIN = __import__('os').environ.get('JVAE_LAST_WGRAD_MAIN', '1') != '0'     # A/B switch, see _Conv.backward
 WGRAD_FORK_BEFORE_DGRAD = __import__('os').environ.get('JVAE_WGRAD_FORK_EARLY', '1') != '0'   # A/B switch, see _Conv.backward
-ACT_KIND = {'relu': RELU, 'sigmoid': SIGMOID, 'linear': IDENT, None: IDENT}
+ACT_KIND = {'relu': RELU, 'sigmoid': SIGMOID, 'linear': IDENT, 'leaky': LEAKY, None: IDENT}
 
 
 def _c(t):
@@ -107,8 +109,8 @@ class _Linear(torch.autograd.Function):
         else:
             gemm(R, O, I, x2, (I, 1, 0), w, (1, I, 0), y, (O, 1, 0), bias=b, bias_mode=1 if b is not None else 0,
                  flags=2 if act == RELU else 0)
-        if act == SIGMOID:
-            L.check(L.load().jvae_act_fwd_f32(L.ptr(y), L.ptr(y), y.numel(), SIGMOID, L.stream_ptr()), 'act_fwd')
+        if act in (SIGMOID, LEAKY):           # (ReLU rides in the product's epilogue; these two are a pass of their own, in place)
+            L.check(L.load().jvae_act_fwd_f32(L.ptr(y), L.ptr(y), y.numel(), act, L.stream_ptr()), 'act_fwd')
         ctx.save_for_backward(x2, w, y if act != IDENT else None)
         ctx.act = act
         ctx.has_bias = b is not None

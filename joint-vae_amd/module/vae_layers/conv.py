@@ -194,8 +194,8 @@ class HipConvStack(nn.Sequential):
         while i < len(mods):
             m = mods[i]
             if isinstance(m, HipBatchNorm2d) and i + 1 < len(mods) and type(mods[i + 1]) in ACT_OF_MODULE \
-                    and ACT_OF_MODULE[type(mods[i + 1])] in (ops.RELU, ops.IDENT):
-                relu = ACT_OF_MODULE[type(mods[i + 1])] == ops.RELU
+                    and ACT_OF_MODULE[type(mods[i + 1])] in ops.BN_ACT:
+                relu = ops.BN_ACT[ACT_OF_MODULE[type(mods[i + 1])]]      # 0 none, 1 ReLU, 2 leaky ReLU: fused into the BatchNorm kernels
                 nxt = mods[i + 2] if i + 2 < len(mods) else None
                 if self.defer_batchnorm and isinstance(nxt, (HipConv2d, HipConvTranspose2d)) \
                         and not (m.training and m.sync_world > 1) \
@@ -225,15 +225,14 @@ class HipConvStack(nn.Sequential):
 
     def _forward_b8(self, x):
         mods = list(self)
+        if any(type(m).__name__ == 'HipLeakyReLU' for m in mods):
+            raise NotImplementedError("the bf16 mode (no counterpart in the reference) has ReLU kernels only: activation='leaky' needs fp32")
         convs = [k for k, m in enumerate(mods) if isinstance(m, (HipConv2d, HipConvTranspose2d))]
         i = 0
         ext = None
         aff = None           # (scale, shift, relu) of a BatchNorm deferred into the next bf16 convolution
         channels = x.shape[1]
-        tape = getattr(self, '_debug_tape', None)    # diagnostics only (tests/diagnostics/b8_stack_oracle_diag.py): (index, fp32 copy)
         while i < len(mods):
-            if tape is not None and i > 0:
-                tape.append((i - 1, (ops_b8.unpack(x.detach(), channels) if ops_b8.is_b8(x) else x.detach()).clone(), aff))
             m = mods[i]
             b8 = ops_b8.is_b8(x)
             if isinstance(m, (HipConv2d, HipConvTranspose2d)):

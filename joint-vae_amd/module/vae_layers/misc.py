@@ -26,15 +26,22 @@ class HipIdentity(nn.Identity):
         return ops.act(x, ops.IDENT)
 
 
-class _Unsupported(nn.Module):
-    def __init__(self, *a, **k):
-        raise NotImplementedError('leaky ReLU is outside the native-kernel contract of this build '
-                                  '(relu / sigmoid / linear are supported)')
+class HipLeakyReLU(nn.LeakyReLU):
+    """nn.LeakyReLU() as the reference builds it for activation='leaky' (misc.py:24-27, conv.py:218-219: no arguments, i.e. negative
+    slope 0.01).  The kernels carry that slope as a constant; another one is refused."""
+
+    def __init__(self, negative_slope=0.01, inplace=False):
+        if negative_slope != 0.01:
+            raise NotImplementedError('leaky ReLU kernels are built for negative_slope = 0.01 (nn.LeakyReLU default)')
+        super().__init__(negative_slope, inplace)
+
+    def forward(self, x):
+        return ops.act(x, ops.LEAKY)
 
 
-activation_layers = {'linear': HipIdentity, 'sigmoid': HipSigmoid, 'relu': HipReLU, 'leaky': _Unsupported}
+activation_layers = {'linear': HipIdentity, 'sigmoid': HipSigmoid, 'relu': HipReLU, 'leaky': HipLeakyReLU}
 
-ACT_OF_MODULE = {HipReLU: ops.RELU, HipSigmoid: ops.SIGMOID, HipIdentity: ops.IDENT}
+ACT_OF_MODULE = {HipReLU: ops.RELU, HipSigmoid: ops.SIGMOID, HipIdentity: ops.IDENT, HipLeakyReLU: ops.LEAKY}
 
 
 def _no_activation(a):

@@ -41,6 +41,10 @@ CASES = {
     'c2_n8_tilted': dict(net=_conv(10, prior=dict(distribution='tilted', init_mean=0., learned_means=True,
                                                    tau=5., freeze_means=0)),
                          N=8, kl_var_weighting=1.0, gamma_weighting=1.0),
+    # activation='leaky' (nn.LeakyReLU(), slope 0.01) with the tilted prior: the shipped conv32 / deconv32 recipe of config.ini:96-115
+    'c2_n8_leaky': dict(net=_conv(10, activation='leaky', prior=dict(distribution='tilted', init_mean=0., learned_means=True,
+                                                                      tau=5., freeze_means=0)),
+                        N=8, kl_var_weighting=1.0, gamma_weighting=1.0),
     'c2_n8_uniform': dict(net=_conv(10, prior=dict(distribution='uniform', init_mean=0., learned_means=True,
                                                     tau=3., freeze_means=0)),
                           N=8, kl_var_weighting=0.5, gamma_weighting=1.0),

@@ -115,8 +115,8 @@ def make_spec(input_shape, num_labels, type='cvae', features=None, upsampler=Non
               classifier=(), batch_norm=False, latent_dim=32, latent_sampling=1, test_latent_sampling=None,
               sigma=None, gamma=0., beta=1., output_activation='linear', activation='relu', prior=None,
               optimizer=None, **_):
-    assert type == 'cvae' and activation == 'relu'
-    sp = dict(input_shape=tuple(input_shape), C=num_labels, K=latent_dim, L=latent_sampling,
+    assert type == 'cvae' and activation in ('relu', 'leaky')         # cvae.py:46-49: 'leaky' = nn.LeakyReLU() (slope 0.01)
+    sp = dict(act=activation, input_shape=tuple(input_shape), C=num_labels, K=latent_dim, L=latent_sampling,
               beta=beta, gamma=gamma, out_act=output_activation,
               enc=list(encoder), dec=list(decoder), clf=list(classifier) if gamma else [],
               prior=dict(prior or {}), opt=dict(optimizer or {}), sigma=dict(sigma or {'value': 1}))
@@ -330,7 +330,7 @@ def _bn_from(stat_src, x, rm, rv, gamma, beta, training, momentum, eps):
     return xh * gamma.view(1, -1, 1, 1) + beta.view(1, -1, 1, 1)
 
 
-def run_stack(P, prefix, layers, bn, x, last_act, training=True, momentum=0.1, eps=1e-5):
+def run_stack(P, prefix, layers, bn, x, last_act, training=True, momentum=0.1, eps=1e-5, hidden_act='relu'):
     """conv.py:186-230: (de)conv -> [BatchNorm2d] -> ReLU; the LAST activation is `last_act` for upsamplers."""
     i = 0
     b8 = False                       # bf16 emulation: x is a tensor the product holds in bf16
@@ -365,7 +365,7 @@ def run_stack(P, prefix, layers, bn, x, last_act, training=True, momentum=0.1, e
             if training:
                 P[f'{prefix}.{i}.num_batches_tracked'] += 1
             i += 1
-        act = 'relu' if (last_act is None or li < len(layers) - 1) else last_act
+        act = hidden_act if (last_act is None or li < len(layers) - 1) else last_act
         x = _act(x, act)
         if b8:
             x = _StoredBF16.apply(x)                     # the normalised activation is stored (or becomes an operand) in bf16
@@ -375,7 +375,7 @@ def run_stack(P, prefix, layers, bn, x, last_act, training=True, momentum=0.1, e
 
 
 def _act(x, name):
-    return {'relu': torch.relu, 'linear': lambda t: t, 'sigmoid': torch.sigmoid}[name](x)
+    return {'relu': torch.relu, 'linear': lambda t: t, 'sigmoid': torch.sigmoid, 'leaky': F.leaky_relu}[name](x)
 
 
 def prior_T(sp, P):
@@ -488,27 +488,27 @@ def evaluate(sp, P, x, y, eps, kl_var_weighting=1.0, gamma_weighting=1.0, with_b
     K, L = sp['K'], sp['L']
     D = int(np.prod(sp['input_shape']))
     if sp['features']:
-        t = run_stack(P, 'features', sp['features'], sp['bn_e'], x, None, training)
+        t = run_stack(P, 'features', sp['features'], sp['bn_e'], x, None, training, hidden_act=sp.get('act', 'relu'))
     else:
         t = x
     u = t.reshape(N, -1)
     for j in range(len(sp['enc'])):
-        u = torch.relu(F.linear(u, P[f'encoder.dense_projs.{2 * j}.weight'], P[f'encoder.dense_projs.{2 * j}.bias']))
+        u = _act(F.linear(u, P[f'encoder.dense_projs.{2 * j}.weight'], P[f'encoder.dense_projs.{2 * j}.bias']), sp.get('act', 'relu'))
     mu = F.linear(u, P['encoder.dense_mean.weight'], P['encoder.dense_mean.bias'])
     log_var = torch.clip(F.linear(u, P['encoder.dense_log_var.weight'], P['encoder.dense_log_var.bias']), -20, 20)
     z = mu + torch.exp(0.5 * log_var) * eps * float(sp['sampled'])       # layers.py:243, eps[0] == 0
     h = z
     for j in range(len(sp['dec'])):
-        h = torch.relu(F.linear(h, P[f'decoder.{2 * j}.weight'], P[f'decoder.{2 * j}.bias']))
+        h = _act(F.linear(h, P[f'decoder.{2 * j}.weight'], P[f'decoder.{2 * j}.bias']), sp.get('act', 'relu'))
     if sp['imager']:
-        xr = run_stack(P, 'imager', sp['imager'], sp['bn_d'], h.reshape(-1, *sp['imager_in']), sp['out_act'], training)
+        xr = run_stack(P, 'imager', sp['imager'], sp['bn_d'], h.reshape(-1, *sp['imager_in']), sp['out_act'], training, hidden_act=sp.get('act', 'relu'))
     else:
         xr = _act(F.linear(h, P['imager.0.weight'], P['imager.0.bias']), sp['out_act'])
     x_reco = xr.reshape(L + 1, N, *sp['input_shape'])
     c = z
     nclf = len(sp['clf'])
     for j in range(nclf):
-        c = torch.relu(F.linear(c, P[f'classifier.{2 * j}.weight'], P[f'classifier.{2 * j}.bias']))
+        c = _act(F.linear(c, P[f'classifier.{2 * j}.weight'], P[f'classifier.{2 * j}.bias']), sp.get('act', 'relu'))
     logits = F.linear(c, P[f'classifier.{2 * nclf}.weight'], P[f'classifier.{2 * nclf}.bias'])
 
     wmse_s, wmse, mse, log_sigma, sigma_reported = recon_terms(sp, P, u, x, x_reco, L, N, training)
@@ -561,25 +561,25 @@ def evaluate_all_classes(sp, P, x, eps):
     K, C = sp['K'], sp['C']
     L = eps.shape[0] - 1
     D = int(np.prod(sp['input_shape']))
-    t = run_stack(P, 'features', sp['features'], sp['bn_e'], x, None, False) if sp['features'] else x
+    t = run_stack(P, 'features', sp['features'], sp['bn_e'], x, None, False, hidden_act=sp.get('act', 'relu')) if sp['features'] else x
     u = t.reshape(N, -1)
     for j in range(len(sp['enc'])):
-        u = torch.relu(F.linear(u, P[f'encoder.dense_projs.{2 * j}.weight'], P[f'encoder.dense_projs.{2 * j}.bias']))
+        u = _act(F.linear(u, P[f'encoder.dense_projs.{2 * j}.weight'], P[f'encoder.dense_projs.{2 * j}.bias']), sp.get('act', 'relu'))
     mu = F.linear(u, P['encoder.dense_mean.weight'], P['encoder.dense_mean.bias'])
     log_var = torch.clip(F.linear(u, P['encoder.dense_log_var.weight'], P['encoder.dense_log_var.bias']), -20, 20)
     z = mu + torch.exp(0.5 * log_var) * eps * float(sp['sampled'])
     h = z
     for j in range(len(sp['dec'])):
-        h = torch.relu(F.linear(h, P[f'decoder.{2 * j}.weight'], P[f'decoder.{2 * j}.bias']))
+        h = _act(F.linear(h, P[f'decoder.{2 * j}.weight'], P[f'decoder.{2 * j}.bias']), sp.get('act', 'relu'))
     if sp['imager']:
-        xr = run_stack(P, 'imager', sp['imager'], sp['bn_d'], h.reshape(-1, *sp['imager_in']), sp['out_act'], False)
+        xr = run_stack(P, 'imager', sp['imager'], sp['bn_d'], h.reshape(-1, *sp['imager_in']), sp['out_act'], False, hidden_act=sp.get('act', 'relu'))
     else:
         xr = _act(F.linear(h, P['imager.0.weight'], P['imager.0.bias']), sp['out_act'])
     x_reco = xr.reshape(L + 1, N, *sp['input_shape'])
     c = z
     nclf = len(sp['clf'])
     for j in range(nclf):
-        c = torch.relu(F.linear(c, P[f'classifier.{2 * j}.weight'], P[f'classifier.{2 * j}.bias']))
+        c = _act(F.linear(c, P[f'classifier.{2 * j}.weight'], P[f'classifier.{2 * j}.bias']), sp.get('act', 'relu'))
     logits = F.linear(c, P[f'classifier.{2 * nclf}.weight'], P[f'classifier.{2 * nclf}.bias'])
 
     wmse_s, wmse, mse, log_sigma, sigma_reported = recon_terms(sp, P, u, x, x_reco, L, N, False)

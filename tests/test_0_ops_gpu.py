@@ -242,7 +242,8 @@ def test_split_bf16_wgrad_is_fp32_accurate(cin, cout, s, tr, H, N):
 # ((parts-1)*ceil(N/parts) >= N) - the ragged last batches the reference never drops (cvae.py:2245-2249)
 @pytest.mark.parametrize('N,C,P,relu', [(8, 32, 1024, True), (5, 3, 1024, False), (16, 200, 4, True), (2, 64, 63, True),
                                         (98, 32, 1024, True), (672, 32, 1024, True), (42, 3, 4096, False),
-                                        (49, 32, 1024, True), (37, 64, 256, True), (74, 3, 1023, False)])
+                                        (49, 32, 1024, True), (37, 64, 256, True), (74, 3, 1023, False),
+                                        (8, 32, 1024, 2), (37, 64, 255, 2)])          # 2: leaky ReLU (misc.py:24-27)
 def test_batchnorm_train(N, C, P, relu):
     from jvae_hip import ops
     g = torch.Generator().manual_seed(N + C + P)
@@ -253,7 +254,8 @@ def test_batchnorm_train(N, C, P, relu):
     xr, gr, br = (t.clone().requires_grad_(True) for t in (x, gamma, beta))
     rmr, rvr = rm.clone(), rv.clone()
     pre = F.batch_norm(xr, rmr, rvr, gr, br, True, 0.1, 1e-5)
-    yr = torch.relu(pre) if relu else pre
+    act = {0: lambda t: t, 1: torch.relu, 2: F.leaky_relu}[int(relu)]
+    yr = act(pre)
     gy = torch.randn(yr.shape, generator=g)
     xd, gd, bd = (t.to(DEV).requires_grad_(True) for t in (x, gamma, beta))
     rmd, rvd = rm.to(DEV), rv.to(DEV)
@@ -269,14 +271,14 @@ def test_batchnorm_train(N, C, P, relu):
         mask = yd.detach().cpu() > 0
         flipped = mask != (pre.detach() > 0)
         assert int(flipped.sum()) <= 8 and (not bool(flipped.any()) or float(pre.detach()[flipped].abs().max()) < 2e-5)
-    pre.backward(gy * mask)
+    pre.backward(gy * (mask if relu != 2 else torch.where(mask, 1., 0.01)))
     yd.backward(gy.to(DEV))
     assert rel(xd.grad, xr.grad) < 1e-4
     assert rel(gd.grad, gr.grad) < 1e-4 and rel(bd.grad, br.grad) < 1e-4
     # eval mode uses the running statistics
     ye = ops.batchnorm_act(xd.detach(), gd.detach(), bd.detach(), rmd, rvd, nbt, False, relu)
     yer = F.batch_norm(x, rmr, rvr, gamma, beta, False, 0.1, 1e-5)
-    assert rel(ye, torch.relu(yer) if relu else yer) < 1e-5
+    assert rel(ye, act(yer)) < 1e-5
 
 
 @pytest.mark.parametrize('N,C,P', [(49, 32, 1024), (98, 64, 256), (5, 3, 1023)])
@@ -288,7 +290,7 @@ def test_channel_sum_ragged_partitions(N, C, P):
     assert rel(out, t.double().sum((0, 2)).float()) < 1e-5
 
 
-@pytest.mark.parametrize('act', [0, 1, 2])
+@pytest.mark.parametrize('act', [0, 1, 2, 3])
 def test_linear(act):
     from jvae_hip import ops
     g = torch.Generator().manual_seed(act)
@@ -297,7 +299,7 @@ def test_linear(act):
     b = torch.randn(64, generator=g)
     xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
     yr = F.linear(xr, wr, br)
-    yr = [lambda t: t, torch.relu, torch.sigmoid][act](yr)
+    yr = [lambda t: t, torch.relu, torch.sigmoid, F.leaky_relu][act](yr)
     gy = torch.randn(yr.shape, generator=g)
     yr.backward(gy)
     xd, wd, bd = (t.to(DEV).requires_grad_(True) for t in (x, w, b))
@@ -317,7 +319,7 @@ AFF_CONVS = [(32, 32, 5, 2, 2, 0, False, 32), (32, 64, 5, 1, 2, 0, False, 16), (
 
 
 @pytest.mark.parametrize('cin,cout,k,s,p,op,tr,H', AFF_CONVS)
-@pytest.mark.parametrize('relu', [True, False])
+@pytest.mark.parametrize('relu', [True, False, 2])
 def test_conv_with_deferred_batchnorm_input(cin, cout, k, s, p, op, tr, H, relu):
     """conv(x*scale + shift [relu]) with the per-channel transform applied inside the kernels (forward and weight
     gradient) against PyTorch on the explicitly transformed input; dgrad is w.r.t. the transformed input."""
@@ -331,7 +333,7 @@ def test_conv_with_deferred_batchnorm_input(cin, cout, k, s, p, op, tr, H, relu)
     w = (torch.randn(wshape, generator=g) / math.sqrt(cin * k * k)).requires_grad_(True)
     b = torch.randn(cout, generator=g)
     a = x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
-    a = torch.relu(a) if relu else a
+    a = {0: lambda t: t, 1: torch.relu, 2: F.leaky_relu}[int(relu)](a)            # 2: leaky ReLU (slope 0.01)
     yr = F.conv_transpose2d(a, w, b, stride=s, padding=p, output_padding=op) if tr else F.conv2d(a, w, b, stride=s, padding=p)
     gy = torch.randn(yr.shape, generator=g)
     yr.backward(gy)
@@ -711,7 +713,11 @@ def test_dropout_kernel_and_module():
 
 
 @pytest.mark.parametrize('cin,cout,H,N,tr', [(32, 32, 16, 5, True), (64, 64, 8, 3, True), (24, 32, 8, 1, True),
-                                             (64, 32, 32, 2, True), (32, 32, 32, 3, False), (64, 64, 16, 2, False)])
+                                             (64, 32, 32, 2, True), (32, 32, 32, 3, False), (64, 64, 16, 2, False),
+                                             # round 5: several tiles per workgroup (4 at 2048 tiles; 2 at 514, the last one half
+                                             # empty), 32 -> 64 channels (two K-step-free output blocks), 48 channels (a partial K step)
+                                             (32, 32, 16, 1024, True), (64, 64, 8, 1027, True), (32, 64, 16, 4, True),
+                                             (48, 32, 8, 5, False)])
 def test_split_bf16_stride2_transposed_conv(cin, cout, H, N, tr):
     """conv_t2_x3.hip: ConvTranspose2d(5, stride 2, padding 2, output_padding 1) forward (tr) and the dgrad of
     Conv2d(5, stride 2, padding 2) on the bf16 matrix cores with 3-way operand splitting, against an fp64 reference
@@ -744,7 +750,10 @@ def test_split_bf16_stride2_transposed_conv(cin, cout, H, N, tr):
 
 @pytest.mark.parametrize('N,cin,cout,H,s,tr', [(256, 32, 32, 32, 1, True), (256, 64, 32, 16, 1, True), (128, 64, 64, 8, 1, True),
                                                (128, 32, 64, 16, 1, False), (8, 32, 768, 32, 1, False),
-                                               (128, 32, 32, 32, 2, False), (256, 64, 64, 8, 2, True)])
+                                               (128, 32, 32, 32, 2, False), (256, 64, 64, 8, 2, True),
+                                               # several tiles per workgroup: conv5_x3_kernel takes two from 2048 workgroups on
+                                               # (ADVICE r4), the round-5 4-phase kernel up to four while 512 workgroups remain
+                                               (256, 32, 64, 32, 1, False), (1024, 32, 32, 16, 2, True), (512, 64, 64, 8, 2, True)])
 def test_conv_kernels_are_run_to_run_deterministic(N, cin, cout, H, s, tr):
     """Every launch of the same convolution on the same data gives the same BITS - forward with and without the deferred
     BatchNorm (with its BatchNorm sums), dgrad, weight gradient with the deferred BatchNorm, in fp32 and (5x5 bf16 kernels) on

@@ -4,5 +4,5 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [REPO, os.path.join(REPO, 'joint-vae_amd')]
 from jvae_hip import ops
 ops.OVERLAP_WGRAD = False
-sys.argv = ['bench.py', '--no-cpu-baseline'] + sys.argv[1:]
+sys.argv = ['bench.py', '--no-cpu-baseline', '--eager'] + sys.argv[1:]
 runpy.run_path(os.path.join(REPO, 'bench.py'), run_name='__main__')
