@@ -104,7 +104,7 @@ def dominant_kernel_roofline(device, reps=20, in_step_ms=None, where='the timed 
         sec = sum(in_step_ms) / len(in_step_ms) * 1e-3
         measured = 'inside %s: %d HIP-event pairs (one per step) around the launch, on its launch stream' % (where, len(in_step_ms))
     traffic, traffic_source = None, None
-    for name in (('r04_x3_fwd_pmc.json', 'r03_x3_fwd_pmc.json') if x3 else ('r01_dominant_kernel_pmc.json',)):
+    for name in (('r05_x3_fwd_pmc.json', 'r04_x3_fwd_pmc.json') if x3 else ('r01_dominant_kernel_pmc.json',)):
         pmc = os.path.join(REPO, 'profiles', name)
         if os.path.exists(pmc):       # HBM bytes per launch from separate rocprofv3 --pmc passes of THIS kernel (not of this run)
             d = json.load(open(pmc))
@@ -114,9 +114,7 @@ def dominant_kernel_roofline(device, reps=20, in_step_ms=None, where='the timed 
     peak = MFMA_BF16_PEAK / X3_PRODUCTS if x3 else MFMA_F32_PEAK
     out = {'bound': 'mfma',
            'kernel': ('conv5_x3_kernel<1,32,2,aff,%s>: imager.15 forward (ConvT 32->32 5x5 s1, 1024x32x32x32), fp32 operands split exactly '
-                      'into 3 bf16 terms, 6 %s per fp32 product tile' % (('16x16x32', 'v_mfma_f32_16x16x32_bf16 (K = 2 taps x 16 channels)')
-                                                                         if os.environ.get('JVAE_X3_SH16', '1') != '0' else
-                                                                         ('32x32x16', 'v_mfma_f32_32x32x16_bf16')) if x3 else
+                      'into 3 bf16 terms, 6 %s per fp32 product tile' % ('16x16x32', 'v_mfma_f32_16x16x32_bf16 (K = 2 taps x 16 channels)') if x3 else
                       'conv5_fwd_kernel<1,32,4,1,8,aff>: imager.15 forward (ConvT 32->32 5x5 s1, 1024x32x32x32)'),
            'achieved': flops / sec / 1e12, 'peak': peak / 1e12, 'unit': 'TFLOP/s', 'frac': flops / sec / peak,
            'traffic': traffic, 'traffic_source': traffic_source, 'launch_ms': sec * 1e3, 'measured': measured,
@@ -136,7 +134,7 @@ def wgrad_kernel_roofline(device, reps=20):
     """The second MFMA-bound family of the step: the weight gradient of the same layer (imager.15, 53.69 GFLOP) on
     conv5_wgrad_x3_kernel + its slab fold, launched through the C ABI as the step launches it (deferred BatchNorm on the layer
     input, accumulation into an existing gradient), timed with HIP events on the launch stream.  Same peak definition as
-    `roofline`; HBM traffic from profiles/r04_wgrad_x3_pmc.json (committed rocprofv3 --pmc passes, not this run)."""
+    `roofline`; HBM traffic from profiles/r05_wgrad_x3_pmc.json (committed rocprofv3 --pmc passes, not this run)."""
     from jvae_hip import ops
     N, C, H = 2 * BATCH_PER_GPU, 32, 32
     spec = ops.ConvSpec(C, C, 5, 1, 2, 0, transposed=True)
@@ -157,11 +155,13 @@ def wgrad_kernel_roofline(device, reps=20):
     flops = 2.0 * N * H * H * C * C * 25
     peak = MFMA_BF16_PEAK / X3_PRODUCTS
     traffic, src = None, None
-    pmc = os.path.join(REPO, 'profiles', 'r04_wgrad_x3_pmc.json')
-    if os.path.exists(pmc):
-        d = json.load(open(pmc))
-        traffic = ((d.get('hbm_read_bytes') or 0) + (d.get('hbm_write_bytes') or 0)) or None
-        src = 'profiles/r04_wgrad_x3_pmc.json (committed file, not this run)'
+    for name in ('r05_wgrad_x3_pmc.json', 'r04_wgrad_x3_pmc.json'):
+        pmc = os.path.join(REPO, 'profiles', name)
+        if os.path.exists(pmc):
+            d = json.load(open(pmc))
+            traffic = ((d.get('hbm_read_bytes') or 0) + (d.get('hbm_write_bytes') or 0)) or None
+            src = 'profiles/%s (committed file, not this run)' % name
+            break
     return {'bound': 'mfma', 'kernel': 'conv5_wgrad_x3_kernel<1,32,0,aff,16x16x32> + wgrad_reduce4_kernel: imager.15 weight gradient '
                                        '(1024x32x32x32 activations), both operands split exactly into 3 bf16 terms',
             'achieved': flops / sec / 1e12, 'peak': peak / 1e12, 'unit': 'TFLOP/s', 'frac': flops / sec / peak,
@@ -203,12 +203,15 @@ def bn_backward_hbm(device, reps=20):
     out = {'bound': 'hbm', 'kernel': 'bn_bwd_reduce_kernel + bn_bwd_apply_kernel: BatchNorm+ReLU backward of imager.16 (1024x32x32x32 fp32), alone',
            'achieved': nbytes / sec / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s', 'frac': nbytes / sec / HBM_PEAK,
            'launch_ms': sec * 1e3, 'algorithmic_bytes': nbytes}
-    prof = os.path.join(REPO, 'profiles', 'r04_bench_kernel_stats.json')
-    if os.path.exists(prof):          # the same family inside the step (two streams share the CUs): committed rocprofv3 summary
+    for name in ('r05_bench_kernel_stats.json', 'r04_bench_kernel_stats.json'):
+        prof = os.path.join(REPO, 'profiles', name)
+        if not os.path.exists(prof):
+            continue                  # the same family inside the step (two streams share the CUs): committed rocprofv3 summary
         d = json.load(open(prof))
         if d.get('bn_bwd_ms_per_step'):
             out['in_step'] = {'ms_per_step': d['bn_bwd_ms_per_step'], 'achieved': 20.0 * 135.7e6 * 4 / 4 / (d['bn_bwd_ms_per_step'] * 1e-3) / 1e9,
-                              'unit': 'GB/s', 'source': 'profiles/r04_bench_kernel_stats.json (rocprofv3 --kernel-trace of bench.py)'}
+                              'unit': 'GB/s', 'source': 'profiles/%s (rocprofv3 --kernel-trace of bench.py)' % name}
+        break
     return out
 
 

@@ -34,7 +34,7 @@ int jvae_conv5_x3_set_shape16(int on);
 bool jvae_conv5_x3_enabled();
 int jvae_conv5_x3_wpack(const float* w, float* ws, int C, int O, int swap, int flip, hipStream_t st);
 // conv_t2_x3.hip: the 4-phase stride-2 transposed convolution in the same arithmetic (w = raw weight, [c][o][tap])
-bool jvae_convt2_x3_ok(int C, int WS, int O);
+bool jvae_convt2_x3_ok(int N, int C, int WS, int O);
 int jvae_convt2_x3(const float* in, const float* w, const float* bias, float* out, int N, int C, int WS, int O, float* ws,
                    hipStream_t st, float* stats = nullptr, int* nsplit = nullptr, const InAff* aff = nullptr);
 int jvae_conv5_x3_fwd(const float* in, const float* w, int swap, int flip, const float* bias, float* out,

@@ -33,7 +33,7 @@ inline const float* packed_f32(const float* w, float* ws, int C, int O, int swap
 }
 inline int run_t2(const ConvGeom& g, const float* small, const float* w, const float* bias, float* big, float* ws,
                   hipStream_t st) {
-    if (jvae_convt2_x3_ok(g.Cs, g.Ws, g.Cb)) return jvae_convt2_x3(small, w, bias, big, g.N, g.Cs, g.Ws, g.Cb, ws, st);
+    if (jvae_convt2_x3_ok(g.N, g.Cs, g.Ws, g.Cb)) return jvae_convt2_x3(small, w, bias, big, g.N, g.Cs, g.Ws, g.Cb, ws, st);
     const float* wp = packed_f32(w, ws, g.Cs, g.Cb, 1, 0, st);
     if (!wp) return JVAE_EINVAL;
     return jvae_convt2(small, wp, bias, big, g.N, g.Cs, g.Ws, g.Cb, st);
@@ -116,7 +116,7 @@ int jvae_conv_fwd(const ConvGeom& g, int transposed, const float* x, const float
     if (fold_bwd_fast_s1(g) && ws_bytes >= 4 * jvae_conv5_pack_floats(g.Cs, g.Cb))
         return jvae_conv5_fwd(x, w, 1, 1, bias, y, g.N, g.Cs, g.Hs, g.Ws, g.Cb, g.Wb, 1, 4 - g.P, ws, st, stats, nsplit, aff);
     if (fold_bwd_fast_s2(g) && ws_bytes >= 4 * jvae_conv5_pack_floats(g.Cs, g.Cb)) {
-        if (jvae_convt2_x3_ok(g.Cs, g.Ws, g.Cb))
+        if (jvae_convt2_x3_ok(g.N, g.Cs, g.Ws, g.Cb))
             return jvae_convt2_x3(x, w, bias, y, g.N, g.Cs, g.Ws, g.Cb, ws, st, stats, nsplit, aff);
         const float* wp = packed_f32(w, ws, g.Cs, g.Cb, 1, 0, st);
         if (!wp) return JVAE_EINVAL;

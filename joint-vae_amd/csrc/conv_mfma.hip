@@ -330,8 +330,7 @@ int jvae_conv5_fwd(const float* in, const float* w, int swap, int flip, const fl
     // <= 4 input channels: vector ALUs (conv_smallco.hip) - for the DGRAD role only (no bias, no BatchNorm sums: the image head's
     // dgrad, 68 -> 56 us).  The first layer's FORWARD gains 3 us there (47 -> 44) and stays on this kernel: another summation order
     // moves its outputs by 1e-7, which at the small-batch goldens flips single ReLU units further up (b2_n8_vib: one unit of
-    // features.13, global gradient norm 3e-4 off instead of 2e-6; tests/diagnostics/vib_grad_diag.py).  JVAE_SMALLCI=2 sends the
-    // forward there too (A/B).
+    // features.13, global gradient norm 3e-4 off instead of 2e-6; tests/diagnostics/vib_grad_diag.py).
     if (!aff && jvae_conv5_smallci_ok(Cin, H, W, Cout, OW, S, P, !bias && !stats))
         return jvae_conv5_smallci(in, w, swap, flip, bias, out, N, Cin, W, Cout, ws, st, stats, nsplit);
     {   // packed weights: the step's cache slot (refreshed once per step, pack_cache.hip) or this call's workspace

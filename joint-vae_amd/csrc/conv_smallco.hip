@@ -292,9 +292,9 @@ int jvae_conv5_smallco(const float* in, const float* w, const float* bias, float
 
 // Forward-type 5x5 stride-1 'same' convolution with <= 4 input channels (conv_mfma.hip hands these over): swap / flip as there.
 bool jvae_conv5_smallci_ok(int Cin, int H, int W, int Cout, int OW, int S, int P, bool dgrad_role) {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("JVAE_SMALLCI"); on = e ? atoi(e) : 1; }      // 0: off, 1: dgrad role only, 2: forward too
-    if (!(on == 2 || (on == 1 && dgrad_role))) return false;
+    // the dgrad role only (the image head's 3 -> 32 dgrad): for the first layer's FORWARD the kernel's summation order moves a
+    // ReLU unit of a small-batch golden to the other branch for 3 us (profiles/NOTES.md, round 4); the JVAE_SMALLCI switch is gone
+    if (!dgrad_role) return false;
     return Cin >= 1 && Cin <= 4 && Cout >= 8 && S == 1 && P == 2 && H == W && OW == W && (W == 32 || W == 64);
 }
 

@@ -94,16 +94,12 @@ struct X3P {
 //             (7 groups per K step: 12 pairs + tap 24 with an all-zero partner; pack_elems.h JVAE_PACK_X3S).  Same output tile
 //             per wave, same patch image, same LDS reads per MFMA cycle; 4 % more MFMA cycles (the empty half pair).  The chip
 //             holds a higher clock on this shape (MI355X_MICROARCH.md, DVFS give-back item 7).
-//             STRIDE 2 in this form (round 4; E1 / E3 forward, D2 / D4 dgrad of conv32 / deconv32): 64 output pixels per
-//             workgroup (one 16-pixel tile per wave), the patch columns stored DE-INTERLEAVED - even padded columns in the first
-//             WPH units of a row, odd ones in the second - so that the 16 pixels of a tile read 16 CONSECUTIVE units for every
-//             tap (2 units apart they would hit each bank twice): 11 rows x 40 units x 16 channels x 3 planes = 42 KB + 24 KB of
-//             weights, two workgroups per CU (the 32x32x16 form needed 73 + 30 KB: one per CU, slower than the fp32 kernel).
+//             (A stride-2 variant of this form on a de-interleaved 64-pixel patch was built in round 4, never beat the fp32 kernel and
+//             left the tree in round 5: profiles/NOTES.md.)
 template <int S, int OW, int MT, bool SH = false>
 struct X3Geom {
-    static constexpr bool DI = SH && S == 2;                   // de-interleaved patch columns
     static constexpr int OH = OW;
-    static constexpr int PIX = DI ? 64 : MT * 128;
+    static constexpr int PIX = MT * 128;
     static constexpr int OHW = OH * OW;
     static constexpr int NIMG = PIX >= OHW ? PIX / OHW : 1;
     static constexpr int TH = PIX >= OHW ? OH : PIX / OW;
@@ -111,10 +107,7 @@ struct X3Geom {
     static constexpr int WIN = OW * S;
     static constexpr int WP0 = (OW - 1) * S + 9;
     static constexpr int WP1 = WIN + 4;
-    // DI: padded column pc = x + 4 sits in half pc & 1 at index pc >> 1; a tile reads indices c + 1 + (kw >> 1) <= OW + 2.  A
-    // 16-pixel tile of an 8-wide map spans two output rows = 2 * WP units apart: WP = 4 (mod 8) puts them on the other banks.
-    static constexpr int WPH = OW == 8 ? 14 : (OW + 3 + 3) / 4 * 4;
-    static constexpr int WP = DI ? 2 * WPH : (WP0 > WP1 ? WP0 : WP1);          // units per patch row
+    static constexpr int WP = WP0 > WP1 ? WP0 : WP1;           // units per patch row
     static constexpr int CH = ROWS * WP;                       // units per 8-channel block per image
     static constexpr int XS = NIMG * 2 * CH;                   // patch units of one plane (16 channels)
     static constexpr int WGS = SH ? 2 * 3 * 4 * 32             // weight units of one group: 2 pairs x 3 planes x 4 lane groups
@@ -172,10 +165,7 @@ __global__ __launch_bounds__(256, 2) void conv5_x3_kernel(X3P p) {
         const int pix = (wave * NPT + mt) * TPX + (SH ? l15 : l31);
         const int im = pix / (G::TH * OW), rem = pix % (G::TH * OW);
         const int r = rem / OW, c = rem % OW;
-        if constexpr (G::DI)             // de-interleaved columns: tap kw of output column c is index c + 1 + (kw >> 1) of half kw & 1
-            pixoff[mt] = im * (2 * G::CH) + (kq & 1) * G::CH + (r * S) * G::WP + c;
-        else
-            pixoff[mt] = im * (2 * G::CH) + (SH ? (kq & 1) : half) * G::CH + (r * S) * G::WP + c * S + 4 - p.P;
+        pixoff[mt] = im * (2 * G::CH) + (SH ? (kq & 1) : half) * G::CH + (r * S) * G::WP + c * S + 4 - p.P;
     }
 
     // two accumulator sets: the three small partial products are summed apart from the three large ones (added in
@@ -305,13 +295,12 @@ __global__ __launch_bounds__(256, 2) void conv5_x3_kernel(X3P p) {
                         x3_split2(f32x2{vv[2 * cp][j], vv[2 * cp + 1][j]}, hh, mm, ll);
                         s[j][0][cp] = hh; s[j][1][cp] = mm; s[j][2][cp] = ll;
                     }
-                // (DI: input column 2*xp + j is padded column 2*xp + 4 + j = index xp + 2 of half j)
-                const int base = (im * 2 + h) * G::CH + lr * G::WP + (G::DI ? xp + 2 : 4 + 2 * xp);
+                const int base = (im * 2 + h) * G::CH + lr * G::WP + 4 + 2 * xp;
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
-                        Xs[pl * G::XS + base + j * (G::DI ? G::WPH : 1)] = s[j][pl];
+                        Xs[pl * G::XS + base + j] = s[j][pl];
             }
         }
     };
@@ -375,7 +364,7 @@ __global__ __launch_bounds__(256, 2) void conv5_x3_kernel(X3P p) {
         u32x4 fa[2][3][2], fb[2][3][TPH];
         auto tapoff = [&](int t) {                               // LDS unit offset of tap t relative to the lane's pixel
             const int kh = t / 5, kw = t - 5 * kh;
-            return G::DI ? kh * G::WP + (kw & 1) * G::WPH + 1 + (kw >> 1) : kh * G::WP + kw;
+            return kh * G::WP + kw;
         };
         auto offs = [&](int pq) {                                // ... of THIS lane's tap of pair pq (tap 25: tap 24 again)
             const int ta = 4 * gi + 2 * pq;
@@ -515,9 +504,7 @@ __global__ __launch_bounds__(256, 2) void conv5_x3_kernel(X3P p) {
     // every other cell - out-of-image rows, missing images and channels included - is rewritten by lstoreX at every K step.
     // Issued behind the first global loads (they fly meanwhile).  Round 4: the whole 46 KB image used to be cleared, in front
     // of the loads: 2 200 of a workgroup's 73 500 cycles (tools/x3_stamps.py).
-    if constexpr (G::DI) {
-        for (int i = tid; i < 3 * G::XS; i += 256) Xs[i] = u32x4{0u, 0u, 0u, 0u};     // (de-interleaved image: all of it)
-    } else {
+    {
         constexpr int HALO = G::WP - G::WIN, NROW = 3 * G::NIMG * 2 * G::ROWS;
         for (int i = tid; i < NROW * HALO; i += 256) {
             const int r = i / HALO, c = i % HALO;
@@ -693,9 +680,7 @@ thread_local int g_x3_splits = 0;
 template <int S, int OW, int MT, bool SH = false>
 int launch_x3(const X3P& p, hipStream_t st) {
     using G = X3Geom<S, OW, MT, SH>;
-    // stride 1: two workgroups per CU; stride 2 (the patch is 4x the output pixels): ONE 4-wave workgroup per CU (see
-    // jvae_conv5_x3_ok)
-    static_assert(G::LDS_BYTES + 2048 <= (S == 1 ? 80 : 160) * 1024, "workgroups per CU vs the 160 KB LDS");
+    static_assert(S == 1 && G::LDS_BYTES + 2048 <= 80 * 1024, "two workgroups per CU");
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_x3_kernel<S, OW, MT, 0, SH>),
@@ -714,12 +699,10 @@ int launch_x3(const X3P& p, hipStream_t st) {
     if (G::OHW < G::PIX) grid.x = (unsigned)((p.N + G::NIMG - 1) / G::NIMG);
     g_x3_splits = (int)grid.x;                                 // BatchNorm partial sums: one per TILE
     // Two tiles per workgroup (16x16x32 form, stride 1) when that still leaves two residency rounds of 512 workgroups:
-    // the second tile's prologue hides under the first one's last weight groups.  JVAE_X3_TPW=1 switches it off (A/B).
-    static int tpw_on = -1;
-    if (tpw_on < 0) { const char* e = getenv("JVAE_X3_TPW"); tpw_on = (e && e[0] == '1') ? 0 : 1; }
+    // the second tile's prologue hides under the first one's last weight groups.
     X3P q = p;
     q.tpw = 1;
-    if (SH && S == 1 && tpw_on && grid.x % 2 == 0 && (long)grid.x * grid.y >= 2048) { q.tpw = 2; grid.x /= 2; }
+    if (SH && grid.x % 2 == 0 && (long)grid.x * grid.y >= 2048) { q.tpw = 2; grid.x /= 2; }
     if (q.aff.sc) {
         if (q.Cin > 256) return JVAE_ENOTSUP;
         if (q.aff.relu == JVAE_ACT_LEAKY) hipLaunchKernelGGL((conv5_x3_kernel<S, OW, MT, 2, SH>), grid, dim3(256), G::LDS_BYTES, st, q);
@@ -738,7 +721,7 @@ static unsigned long long* g_x3_dbg = nullptr;
 extern "C" void jvae_x3_set_stamp_buffer(void* buf) { g_x3_dbg = (unsigned long long*)buf; }     // diagnostic build only
 #endif
 static int g_x3 = -1;        // JVAE_X3=0: keep every layer on the fp32 matrix-core kernels (A/B switch)
-static int g_x3_sh16 = -1;   // JVAE_X3_SH16=0: the 32x32x16 MFMA shape in the stride-1 forward-type kernel (A/B switch)
+static int g_x3_sh16 = 1;    // jvae_conv2d_set_split_shape16(0): the 32x32x16 MFMA shape also for maps up to 32 wide (tests run both)
 
 // Layers the split kernel takes over from conv_mfma.hip: stride 1, at least one full K step of input channels.
 static void x3_init() {
@@ -757,10 +740,7 @@ bool jvae_conv5_x3_enabled() {
     return g_x3 != 0;
 }
 
-static bool x3_sh16() {
-    if (g_x3_sh16 < 0) { const char* e = getenv("JVAE_X3_SH16"); g_x3_sh16 = (e && e[0] == '0') ? 0 : 1; }
-    return g_x3_sh16 != 0;
-}
+static bool x3_sh16() { return g_x3_sh16 != 0; }
 
 // MFMA shape of the stride-1 forward-type kernel: 1 = v_mfma_f32_16x16x32_bf16 (K = 2 taps x 16 channels), 0 = 32x32x16.
 // Returns the previous setting.
@@ -784,22 +764,9 @@ bool jvae_conv5_x3_ok(int Cin, int H, int W, int Cout, int OH, int OW, int S, in
     x3_init();
     if (!g_x3) return false;
     if (Cin < 16 || Cin > 256) return false;
-    if (S == 2) {
-        // Stride-2 forward-type layers (E1 / E3 forward, D2 / D4 dgrad of conv32 / deconv32) stay on the fp32 matrix-core kernel:
-        // both split-bf16 forms were built and measured SLOWER.  Round 3, 32x32x16 form (128-pixel tile, 73 KB patch + 30 KB
-        // weights, ONE workgroup per CU): E1 forward 96.7 vs 70.7 us, the step 4.00 vs 3.84 ms.  Round 4, 16x16x32 form on a
-        // de-interleaved 64-pixel patch, two workgroups per CU (X3Geom::DI; parity-green, tests/test_0_ops_gpu.py with
-        // JVAE_X3_S2=1): E1 forward 95.7 vs 70.9 us, E3 forward 85.8 vs 70.7, D2 dgrad 134 vs 117, D4 dgrad 133 vs 112
-        // (profiles/r04_conv_s2_x3_ab.txt).  With one 16-pixel tile per wave a weight group (2 tap pairs) feeds only 24 MFMAs
-        // = 384 matrix-pipe cycles per wave between two barriers - a quarter of the stride-1 kernel's - against ~650 cycles of
-        // weight store + load issue + barrier per group (tools/x3_stamps.py), and 9 ds_read_b128 per 12 MFMAs keep the LDS 75 %
-        // busy.  More pixels per workgroup need the 73 KB patch again, more channels 48 KB of weights: neither fits two
-        // workgroups per CU.  JVAE_X3_S2=1 selects the round-4 form (A/B switch).
-        static int s2 = -1;
-        if (s2 < 0) { const char* e = getenv("JVAE_X3_S2"); s2 = (e && e[0] == '1') ? 1 : 0; }
-        if (!s2 || !x3_sh16() || P != 2 || (OW != 8 && OW != 16 && OW != 32)) return false;
-        return jvae_conv5_fwd_ok(Cin, H, W, Cout, OH, OW, S, P);
-    }
+    // Stride-2 forward-type layers (E1 / E3 forward, D2 / D4 dgrad of conv32 / deconv32) stay on the fp32 matrix-core kernel: their
+    // patch is 4x the output pixels, and both split-bf16 forms built for them (round 3: 128-pixel tile, one workgroup per CU; round 4:
+    // 16x16x32 on a de-interleaved 64-pixel patch, two per CU) measured at best at parity with it (profiles/NOTES.md).
     if (S != 1) return false;
     if (OW != 8 && OW != 16 && OW != 32 && OW != 64) return false;
     return jvae_conv5_fwd_ok(Cin, H, W, Cout, OH, OW, S, P);
@@ -824,7 +791,7 @@ int jvae_conv5_x3_fwd(const float* in, const float* w, int swap, int flip, const
                       int N, int Cin, int H, int W, int Cout, int OW, int S, int P, float* ws, hipStream_t st,
                       float* stats, int* nsplit, const InAff* aff) {
     const int OP = (Cout + 31) / 32 * 32;
-    const bool sh = (S == 2 || OW <= 32) && x3_sh16();      // 64-wide stride-1 maps (config 5 in fp32) keep the 32x32x16 form
+    const bool sh = OW <= 32 && x3_sh16();                  // 64-wide maps (config 5 in fp32) keep the 32x32x16 form
     {   // split weights: the step's cache slot (refreshed once per step, pack_cache.hip) or this call's workspace
         bool fresh = true;
         const int kind = sh ? JVAE_PACK_X3S : JVAE_PACK_X3;
@@ -840,14 +807,7 @@ int jvae_conv5_x3_fwd(const float* in, const float* w, int swap, int flip, const
     p.dbg = g_x3_dbg;
 #endif
     struct Fin { int* n; ~Fin() { if (n) *n = g_x3_splits; } } fin{nsplit};
-    if (S == 2) {
-        switch (OW) {
-            case 8: return launch_x3<2, 8, 1, true>(p, st);
-            case 16: return launch_x3<2, 16, 1, true>(p, st);
-            case 32: return launch_x3<2, 32, 1, true>(p, st);
-        }
-        return JVAE_ENOTSUP;
-    }
+    if (S != 1) return JVAE_ENOTSUP;
     if (sh) {
         switch (OW) {
             case 8: return launch_x3<1, 8, 1, true>(p, st);
@@ -855,7 +815,6 @@ int jvae_conv5_x3_fwd(const float* in, const float* w, int swap, int flip, const
             case 32: return launch_x3<1, 32, 2, true>(p, st);
         }
     }
-    if (S != 1) return JVAE_ENOTSUP;
     switch (OW) {
         case 8: return launch_x3<1, 8, 1>(p, st);
         case 16: return launch_x3<1, 16, 2>(p, st);

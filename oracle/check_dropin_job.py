@@ -19,9 +19,31 @@ sys.path.insert(0, REPO)
 from oracle.gen_golden import import_reference      # noqa: E402
 
 
+def cpu_copy(d):
+    """The job was written on the GPU box: its state.pth / optimizer.pth hold CUDA tensors, and the reference's load() reads
+    optimizer.pth without a map_location (cvae.py:2845) - in this GPU-less container the two files are re-saved with their tensors
+    on the CPU, in a temporary copy of the directory; nothing else is touched."""
+    import shutil
+    import tempfile
+    import torch
+    t = tempfile.mkdtemp(prefix='dropin_job_')
+    dst = os.path.join(t, os.path.basename(d))
+    shutil.copytree(d, dst)
+    for f in ('state.pth', 'optimizer.pth'):
+        fp = os.path.join(dst, f)
+        if os.path.exists(fp):
+            torch.save(torch.load(fp, map_location='cpu'), fp)
+    return dst
+
+
 def check(Net, d):
     d = os.path.abspath(d)
+    shown = d
     has_state = os.path.exists(os.path.join(d, 'state.pth'))
+    if has_state:
+        import torch
+        if not torch.cuda.is_available():
+            d = cpu_copy(d)
     net = Net.load(d, load_state=has_state)
     tp = net.training_parameters
     # train.py:224-229
@@ -57,7 +79,7 @@ def check(Net, d):
         net.optimizer.clip(net.parameters())
         net.optimizer.step()
     print('OK  {}: reference load(load_state={}) -> set={!r} transformer={!r} validation={} data_augmentation={} latent_sampling={} '
-          'trained={} history keys={} lr={:.3e}{}'.format(os.path.relpath(d, REPO), has_state, dataset, transformer, validation,
+          'trained={} history keys={} lr={:.3e}{}'.format(os.path.relpath(shown, REPO), has_state, dataset, transformer, validation,
                                                          data_augmentation, latent_sampling, net.trained, sorted(map(str, net.train_history)),
                                                          net.optimizer.lr, '' if n_state is None else ' state tensors={} + one reference step'.format(n_state)))
 

@@ -1,6 +1,6 @@
 """GPU box: how far do the per-sample losses of config 2 at N = 512 move when the batch is permuted (BatchNorm partial sums are
-taken per tile in fp32, so a permutation changes their rounding) - test_full_batch_properties (2) - with the round-5 4-phase
-kernel and with the first one (JVAE_T2_V1=1), and for three permutations."""
+taken per tile in fp32, so a permutation changes their rounding) - test_full_batch_properties (2) - for three permutations
+(round 5: the same spread with the first 4-phase kernel and with the present one, profiles/NOTES.md)."""
 import os, sys, torch
 REPO = os.environ.get('GRAFT_REPO_ROOT', os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path[:0] = [REPO, os.path.join(REPO, 'joint-vae_amd')]
@@ -20,4 +20,4 @@ for s in range(3):
         a, b = l2[k].double(), l1[k][perm].double()
         d = (a - b).abs()
         out.append('%s max|d| %.3g (rel to max %.2e, median rel %.1e)' % (k, float(d.max()), float(d.max() / b.abs().max()), float((d / b.abs()).median())))
-    print('T2_V1=%s perm %d:' % (os.environ.get('JVAE_T2_V1', '0'), s), '; '.join(out))
+    print('perm %d:' % s, '; '.join(out))

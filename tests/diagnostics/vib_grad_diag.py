@@ -20,4 +20,3 @@ for n_, p in net.named_parameters():
     d = mine - ref
     nz = np.abs(d) > 1e-4 * np.abs(ref).max()
     print(f'{n_:28s} |ref| {np.linalg.norm(ref):10.4f} rel L2 {np.linalg.norm(d)/max(np.linalg.norm(ref),1e-30):.2e}  norm ratio-1 {np.linalg.norm(mine)/max(np.linalg.norm(ref),1e-30)-1:+.2e}  elems off {int(nz.sum())}/{d.size}')
-print('SMALLCI', os.environ.get('JVAE_SMALLCI', '1'))

@@ -143,13 +143,20 @@ def test_point_input_transposed_conv_weight_gradient(N):
 
 @pytest.mark.parametrize('cin,cout,tr,H,N', [(32, 32, True, 32, 6), (32, 64, False, 16, 9), (64, 32, True, 16, 5),
                                              (64, 64, True, 8, 7), (48, 40, False, 16, 3), (128, 64, False, 64, 1),
-                                             (17, 33, False, 8, 1), (16, 3, True, 32, 2), (250, 32, False, 8, 3)])
-def test_split_bf16_conv_is_fp32_accurate(cin, cout, tr, H, N):
+                                             (17, 33, False, 8, 1), (16, 3, True, 32, 2), (250, 32, False, 8, 3),
+                                             # 2048 workgroups: the 16x16x32 kernel takes TWO tiles per workgroup (round 4 / 5)
+                                             (32, 64, False, 32, 256)])
+@pytest.mark.parametrize('shape16', [1, 0], ids=['16x16x32', '32x32x16'])
+def test_split_bf16_conv_is_fp32_accurate(cin, cout, tr, H, N, shape16):
     """conv_x3.hip computes fp32 convolutions on the bf16 matrix cores (3-way exact operand split, 6 products): measured
     against an fp64 reference its error must be at the level of the fp32-MFMA kernel's own rounding (not bf16's 4e-3),
-    on data with a wide dynamic range, in forward (with BatchNorm partial sums) and dgrad; the two modes agree to 2e-6."""
+    on data with a wide dynamic range, in forward (with BatchNorm partial sums) and dgrad; the two modes agree to 2e-6.
+    Both MFMA shapes of the kernel (jvae_conv2d_set_split_shape16: 16x16x32 is the default up to 32-wide maps, 32x32x16 serves
+    64-wide ones and - through the switch - everything)."""
     from jvae_hip import lib, ops
     L = lib.load()
+    if shape16 == 0 and N > 16:
+        pytest.skip('the large case is the two-tiles-per-workgroup form of the 16x16x32 kernel')
     g = torch.Generator().manual_seed(cin * 7 + cout + H)
     x = torch.randn(N, cin, H, H, generator=g) * torch.exp(2 * torch.randn(N, cin, 1, 1, generator=g))
     w = torch.randn((cin, cout, 5, 5) if tr else (cout, cin, 5, 5), generator=g) / math.sqrt(cin * 25)
@@ -167,6 +174,7 @@ def test_split_bf16_conv_is_fp32_accurate(cin, cout, tr, H, N):
     xd, wd, bd, gyd = x.to(DEV), w.to(DEV), b.to(DEV), gy.to(DEV)
     out = {}
     old = L.jvae_conv2d_set_split_bf16(1)
+    old_shape = L.jvae_conv2d_set_split_shape16(shape16)
     try:
         for mode in (1, 0):
             L.jvae_conv2d_set_split_bf16(mode)
@@ -183,6 +191,7 @@ def test_split_bf16_conv_is_fp32_accurate(cin, cout, tr, H, N):
             out[mode] = (rel(y, ref), rel(dx, gref), y, dx)
     finally:
         L.jvae_conv2d_set_split_bf16(old)
+        L.jvae_conv2d_set_split_shape16(old_shape)
     assert out[1][0] < 3e-6 and out[1][1] < 3e-6, out[1][:2]          # split bf16: measured 2e-7 .. 1.3e-6 (K = 1600 .. 3200)
     assert out[0][0] < 5e-6 and out[0][1] < 5e-6, out[0][:2]          # fp32 MFMA (k-ordered fmaf chain): up to 1.5e-6
     assert out[1][0] < 2 * out[0][0] + 1e-7 and out[1][1] < 2 * out[0][1] + 1e-7, (out[1][:2], out[0][:2])
@@ -776,10 +785,13 @@ def test_conv_kernels_are_run_to_run_deterministic(N, cin, cout, H, s, tr):
         ops.conv_wgrad_raw(x, gy, spec, wshape, False, gw, None, aff=aff if ops.conv_affine_ok(spec, N, H, H) else None)
         return gw
     cases = {'forward': lambda: ops.conv_fwd_raw(x, w, b, spec),
+             'forward with BatchNorm sums': lambda: ops.conv_fwd_stats_raw(x, w, b, spec)[0],
              'dgrad': lambda: ops.conv_dgrad_raw(gy, w, spec, x.shape),
              'weight gradient': wgrad}
     if ops.conv_affine_ok(spec, N, H, H):
         cases['forward, deferred BatchNorm'] = lambda: ops.conv_fwd_aff_raw(x, w, b, spec, aff, True)[0]
+        # (round 5: the new 4-phase kernel lost the bias of 16 outputs in a first launch WITHOUT the BatchNorm sums only)
+        cases['forward, deferred BatchNorm, no sums'] = lambda: ops.conv_fwd_aff_raw(x, w, b, spec, aff, False)[0]
     if ops_b8.native_mask(spec, N, H, H) == 7 and ops_b8.conv_affine_ok(spec, N, H, H):
         xb, gyb = ops_b8.pack(x), ops_b8.pack(gy)
         C8 = (cin + 7) // 8 * 8

@@ -9,4 +9,4 @@ O=$R/gpurun_out/$TAG
 rm -rf $O; mkdir -p $O
 rocprofv3 --output-format csv --kernel-trace --stats -d $O/trace -- python3 $R/tools/bench_no_overlap.py --steps 30 --warmup 5 "$@" > $O/bench.json 2> $O/bench.err
 find $O -name "*_kernel_trace.csv" -delete; find $O -name "*_agent_info.csv" -delete; find $O -name "*domain_stats.csv" -delete
-python3 $R/tools/step_stats.py $(find $O -name "*kernel_stats.csv") 35
+python3 $R/tools/step_stats.py $(find $O -name "*kernel_stats.csv")

@@ -1,15 +1,16 @@
 """Per-step kernel time by family from a rocprofv3 kernel_stats.csv of a bench.py run.
-usage: python tools/step_stats.py KERNEL_STATS.csv STEPS_TRACED"""
+usage: python tools/step_stats.py KERNEL_STATS.csv [STEPS_TRACED]   (default: the number of adam_kernel launches, one per step)"""
 import csv
 import re
 import sys
 
 csv.field_size_limit(1 << 30)
 rows = list(csv.DictReader(open(sys.argv[1])))
-steps = float(sys.argv[2])
+steps = float(sys.argv[2]) if len(sys.argv) > 2 else float(sum(int(r['Calls']) for r in rows if 'adam_kernel' in r['Name']))
+print(f'{steps:.0f} steps traced')
 fam = {}
 FAMS = [('bn_bwd_apply', 'BN bwd apply'), ('bn_bwd_reduce', 'BN bwd reduce'), ('conv5_wgrad_x3', 'wgrad x3'), ('conv5_wgrad_kernel', 'wgrad f32'),
-        ('wgrad_reduce', 'wgrad slab reduce'), ('conv5_x3_kernel', 'conv x3 (fwd/dgrad s1)'), ('convt2_x3', 'conv 4-phase x3'),
+        ('wgrad_reduce', 'wgrad slab reduce'), ('conv5_x3_kernel', 'conv x3 (fwd/dgrad s1)'), ('convt2_x3', 'conv 4-phase x3'), ('convt2s_x3', 'conv 4-phase x3'), ('t2s_wpack', 'weight packs'),
         ('conv5_fwd_kernel', 'conv f32 mfma'), ('convt2_kernel', 'conv 4-phase f32'), ('gemm_kernel', 'dense products (gemm + split-K fold)'),
         ('gemm_x3_kernel', 'dense products (gemm + split-K fold)'), ('splitk_fold', 'dense products (gemm + split-K fold)'), ('small_transpose', 'unfold/fold'), ('pack_refresh', 'weight packs'), ('unfold', 'unfold/fold'),
         ('fold_kernel', 'unfold/fold'), ('smallco', '3-channel layers on the vector ALUs'), ('smallci', '3-channel layers on the vector ALUs'), ('sci_wpack', 'weight packs'), ('wpack', 'weight packs'), ('pack_kernel', 'weight packs'),
