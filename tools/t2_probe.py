@@ -1,6 +1,6 @@
 """GPU box: the 4-phase stride-2 transposed kernel (conv_t2_x3.hip) on the four launches of config 2 - D2 / D4 forward with the
 deferred BatchNorm of their input and the BatchNorm sums of their output, E1 / E3 dgrad - checked against an fp64 reference at a small
-ragged batch (outputs AND the folded BatchNorm sums), then timed at the step's batch.  JVAE_T2_V1=1 selects the first kernel (A/B)."""
+ragged batch (outputs AND the folded BatchNorm sums), then timed at the step's batch."""
 import math, os, sys, torch
 import torch.nn.functional as F
 REPO = os.environ.get('GRAFT_REPO_ROOT', os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -17,7 +17,7 @@ def timeit(f, reps=20):
     for _ in range(reps): f()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e3
-tag = 'v1 ' if os.environ.get('JVAE_T2_V1') == '1' else 'new'
+tag = 't2s'
 for name, N, cin, cout, H, fwd in CASES:
     g = torch.Generator().manual_seed(cin + H)
     n = 5 if H == 16 else 19                                   # ragged: partially filled tiles
