@@ -209,7 +209,11 @@ __device__ __forceinline__ f32x4 aff4_kind(f32x4 v, float s, float t, int kind) 
 typedef __bf16 jvae_bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int jvae_u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ jvae_u32x4 aff8(jvae_u32x4 u, const float* sc8, const float* sh8, int relu) {
-    // sc8 / sh8: 16-byte aligned LDS tables - four 16-byte reads instead of sixteen dependent 4-byte ones (round 4, conv_x3.hip)
+    // sc8 / sh8: 16-byte aligned LDS tables - four 16-byte reads instead of sixteen dependent 4-byte ones (round 4: config 5 bf16
+    // 4.29 -> 4.15 ms).  Wide reads of such a table are safe; what was not (rounds 4-5, profiles/NOTES.md) is the packed fp32 FMA the
+    // compiler may form behind them with the HIGH register of a coefficient pair selected for its LOW result half - the build fails
+    // if any kernel contains that form (tools/isa_opsel_scan.py, run by the Makefile); here each product is a scalar FMA on a
+    // converted bf16 value, and no such instruction exists.
     const f32x4 c0 = *reinterpret_cast<const f32x4*>(sc8), c1 = *reinterpret_cast<const f32x4*>(sc8 + 4);
     const f32x4 h0 = *reinterpret_cast<const f32x4*>(sh8), h1 = *reinterpret_cast<const f32x4*>(sh8 + 4);
     jvae_bf16x8 v = __builtin_bit_cast(jvae_bf16x8, u);

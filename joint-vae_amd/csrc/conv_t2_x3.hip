@@ -351,9 +351,11 @@ __global__ __launch_bounds__(256, 2) void convt2s_x3_kernel(T2X3P p) {
     // The BatchNorm sums (pivot = bias) are taken from the bias-free accumulators first (registers only); then the bias goes INTO the
     // accumulators, four channels at a time, and the two column phases of a row are stored as 8-byte pairs.  Round 5: the first
     // version added the bias while forming each pair - `make_float2(acc0 + b, acc1 + b)` became `v_pk_add_f32 ... op_sel:[0,1]`
-    // (one bias register broadcast to both halves) two instructions in front of the `global_store_dwordx2` of its result - and,
-    // timing-dependent, lanes 48-63 of the low half reached memory WITHOUT the bias (exactly -bias[c] on 16 outputs of channel
-    // 13 / 29, mostly in a process's first launch: tools/t2_err_probe.py; profiles/NOTES.md).
+    // for the odd register of a bias pair (its HIGH register selected for the LOW result half) - and, rarely, 16 lanes of that low
+    // half came out as if the bias were 0 (exactly -bias[c] on 16 outputs of channel 13 / 29: tools/t2_err_probe.py).  The same
+    // operand-select form is what made round 4's 16-byte coefficient reads nondeterministic (profiles/NOTES.md, round 5:
+    // the 2x2 experiment); the Makefile rejects any object that contains it (tools/isa_opsel_scan.py).  Adding a whole f32x4 of
+    // bias to a whole accumulator quadruple needs no operand select at all.
     constexpr int HB = 2 * G::HS, WB = 2 * WS;
     float sv[16];                                              // [sum | sum of squares][channel tile][register]
     if (p.stats) {
@@ -377,8 +379,6 @@ __global__ __launch_bounds__(256, 2) void convt2s_x3_kernel(T2X3P p) {
         f32x4 bv[2];
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) bv[ct] = *reinterpret_cast<const f32x4*>(&bias_s[ct * 16 + kq * 4]);
-        // 32 idle cycles between the arrival of these two broadcast reads and their first use (see the note above)
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7" : "+v"(bv[0]), "+v"(bv[1]) :: "memory");
 #pragma unroll
         for (int ph = 0; ph < 4; ++ph)
 #pragma unroll
