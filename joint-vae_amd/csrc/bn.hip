@@ -476,8 +476,8 @@ int jvae_bn_bwd_f32(const float* dy, const float* x, const float* gamma, const f
     // Traversal order against the 256 MB Infinity Cache: the reduction walks the image parts DOWNWARDS - it starts on the part of dy
     // that the producing dgrad kernel wrote last - and the apply pass walks them upwards, i.e. starts on what the reduction
     // read last: 113-118 us instead of 120-124 for the 134 MB activation (two 268 MB sweeps), about 1 % of the step.
-    // JVAE_BN_ORDER (bit 0: reduce downwards, bit 1: apply downwards; default 1) is the A/B switch; 0 and 3 measure alike.
-    static const int order = [] { const char* e = getenv("JVAE_BN_ORDER"); return e ? atoi(e) : 1; }();     // (thread-safe static init)
+    // (order bit 0: reduce downwards, bit 1: apply downwards; 0 and 3 measured alike, profiles/NOTES.md round 4)
+    const int order = 1;
     relu = jvae_act_kind(relu);
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C, ns), dim3(256), 0, st, dy, x, gamma, beta, save_mean, save_invstd,
                        partial, N, C, P, ns, relu, order & 1);

@@ -267,10 +267,8 @@ int launch_wg(const WgP& p, hipStream_t st) {
     return 0;
 }
 
-static int g_wide = -1;      // JVAE_WGRAD_WIDE=0 disables the 32-channel (25 tiles / 28 slots) variant: tuning knob
-inline bool wide_ok(int S, int WS, int Cb) {
-    if (g_wide < 0) { const char* e = getenv("JVAE_WGRAD_WIDE"); g_wide = (e && e[0] == '0') ? 0 : 1; }
-    return g_wide && S == 1 && (WS == 16 || WS == 32) && Cb % 32 == 0;
+inline bool wide_ok(int S, int WS, int Cb) {          // the 32-channel (25 tiles / 28 slots) variant
+    return S == 1 && (WS == 16 || WS == 32) && Cb % 32 == 0;
 }
 inline int pick_cb(int S, int WS, int Cb) {
     if (Cb <= 4) return 4;                      // 3-channel tensors (image side of the first / last layer)

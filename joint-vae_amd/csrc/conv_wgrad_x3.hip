@@ -649,13 +649,10 @@ int slab_count_x3(int N, int Ca, int Cb, int S) {
     return (N + imgs - 1) / imgs;
 }
 
-int g_wgx3 = -1;             // JVAE_WGRAD_X3=0: weight gradients stay on the fp32 matrix-core kernel (A/B switch)
-
 }  // namespace
 
 bool jvae_conv5_wgrad_x3_ok(int Ca, int HS, int WS, int Cb, int HB, int WB, int S, int P) {
-    if (g_wgx3 < 0) { const char* e = getenv("JVAE_WGRAD_X3"); g_wgx3 = (e && e[0] == '0') ? 0 : 1; }
-    if (!g_wgx3 || !jvae_conv5_x3_enabled()) return false;
+    if (!jvae_conv5_x3_enabled()) return false;           // jvae_conv2d_set_split(0) / JVAE_X3=0: the fp32 matrix-core kernels
     if (S != 1 && S != 2) return false;
     if (HS != WS || HB != WB || WB != WS * S) return false;
     if (WS != 8 && WS != 16 && WS != 32) return false;
@@ -693,11 +690,8 @@ int jvae_conv5_wgrad_x3(const float* ps, const float* q, float* dw, int accumula
     return jvae_wgrad_slab_reduce(ws, dw, p.G, Ca, Cb, accumulate, swapflip, st, 1);
 }
 
-// ---- the one-plane form for bf16 "B8" operands (conv_wgrad_b8.hip dispatches here; JVAE_WGRAD_B8X=0: its own older kernel)
+// ---- the one-plane form for bf16 "B8" operands (conv_wgrad_b8.hip dispatches here; its own older kernel takes what this one refuses)
 bool jvae_conv5_wgrad_b8x_ok(int Ca, int HS, int WS, int Cb, int HB, int WB, int S, int P) {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("JVAE_WGRAD_B8X"); on = (e && e[0] == '0') ? 0 : 1; }
-    if (!on) return false;
     if (S != 1 && S != 2) return false;
     if (HS != WS || HB != WB || WB != WS * S) return false;
     if (WS != 8 && WS != 16 && WS != 32 && !(WS == 64 && S == 1)) return false;

@@ -720,23 +720,19 @@ int launch_x3(const X3P& p, hipStream_t st) {
 static unsigned long long* g_x3_dbg = nullptr;
 extern "C" void jvae_x3_set_stamp_buffer(void* buf) { g_x3_dbg = (unsigned long long*)buf; }     // diagnostic build only
 #endif
-static int g_x3 = -1;        // JVAE_X3=0: keep every layer on the fp32 matrix-core kernels (A/B switch)
+// JVAE_X3=0 (read once, when the library is loaded) or jvae_conv2d_set_split(0): every layer, dense product and weight gradient
+// stays on the fp32 matrix-core kernels - the one selector left, exercised by the parity tests through the setter
+static int g_x3 = [] { const char* e = getenv("JVAE_X3"); return (e && e[0] == '0') ? 0 : 1; }();
 static int g_x3_sh16 = 1;    // jvae_conv2d_set_split_shape16(0): the 32x32x16 MFMA shape also for maps up to 32 wide (tests run both)
 
 // Layers the split kernel takes over from conv_mfma.hip: stride 1, at least one full K step of input channels.
-static void x3_init() {
-    if (g_x3 < 0) { const char* e = getenv("JVAE_X3"); g_x3 = (e && e[0] == '0') ? 0 : 1; }
-}
-
 int jvae_conv5_x3_set(int mode) {
-    x3_init();
     const int old = g_x3;
     g_x3 = mode ? 1 : 0;
     return old;
 }
 
 bool jvae_conv5_x3_enabled() {
-    x3_init();
     return g_x3 != 0;
 }
 
@@ -761,7 +757,6 @@ int jvae_conv5_x3_wpack(const float* w, float* ws, int C, int O, int swap, int f
 }
 
 bool jvae_conv5_x3_ok(int Cin, int H, int W, int Cout, int OH, int OW, int S, int P) {
-    x3_init();
     if (!g_x3) return false;
     if (Cin < 16 || Cin > 256) return false;
     // Stride-2 forward-type layers (E1 / E3 forward, D2 / D4 dgrad of conv32 / deconv32) stay on the fp32 matrix-core kernel: their

@@ -244,7 +244,7 @@ struct GxImg {
 // forces s_waitcnt vmcnt(0)).  Measured (round 3, profiles/r03_step_trace_no_overlap.txt): -9 ... +7 % per product, -3 us per
 // step - these products are bound neither by load latency nor by the operand split but by the L2 / Infinity-Cache traffic of
 // 64 x 64 tiles ((64 + 64) K operand elements per 64 * 64 * K multiplications: the 7x7 head's forward moves 205 MB for 32 MB of
-// distinct data).  JVAE_GEMM_DEPTH=1 selects the one-stage form.
+// distinct data).  (The one-stage form takes what the 16-byte loads cannot.)
 template <bool AK, bool BNC, int DEPTH = 1>
 __global__ __launch_bounds__(256, 4) void gemm_x3_kernel(GemmP p) {
     using IA = GxImg<AK>;
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(256, 4) void gemm_x3_kernel(GemmP p) {
     const int half = lane >> 5, l31 = lane & 31;
     const int cg = (lane >> 4) & 1, q4 = (lane & 15) >> 2, pp = lane & 3;      // transposed-read roles
     const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
-    // XCD-aware tile order (JVAE_GEMM_XCD, default on): consecutive workgroup ids go round-robin to the 8 XCDs, so the tiles of
+    // XCD-aware tile order: consecutive workgroup ids go round-robin to the 8 XCDs, so the tiles of
     // one (batch, K slice) - which share their A rows and B columns - used to be spread over all eight L2s.  Workgroup
     // w = (xcd, k) takes tile xcd * (tiles / 8) + k of the (z, y, x) order: one XCD works through whole (batch, K slice) planes.
     unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
@@ -460,24 +460,18 @@ int launch_x3_variant(const GemmP& p, int batch, hipStream_t st) {
     return 0;
 }
 
-static int g_gemm_depth = -1;    // JVAE_GEMM_DEPTH=1: one K step in flight (the round-2 kernel; A/B switch)
-
 template <bool AK, bool BNC>
 int launch_x3_ab(const GemmP& p, int batch, hipStream_t st) {
-    if (g_gemm_depth < 0) { const char* e = getenv("JVAE_GEMM_DEPTH"); g_gemm_depth = (e && e[0] == '1') ? 1 : 3; }
     // deep prefetch: 16-byte loads on both operands, K range a multiple of 4 (kchunk is a multiple of 32)
-    const bool deep = g_gemm_depth > 1 && p.vecA && p.vecB && p.K % 4 == 0
+    const bool deep = p.vecA && p.vecB && p.K % 4 == 0
                       && (AK || p.M % 4 == 0) && (!BNC || p.N % 4 == 0);
     if (deep) return launch_x3_variant<AK, BNC, 3>(p, batch, st);
     return launch_x3_variant<AK, BNC, 1>(p, batch, st);
 }
 
-static int g_gemm_xcd = -1;      // JVAE_GEMM_XCD=0: hardware tile order (A/B switch)
-
 int launch_x3(const GemmP& p0, int batch, hipStream_t st) {
-    if (g_gemm_xcd < 0) { const char* e = getenv("JVAE_GEMM_XCD"); g_gemm_xcd = (e && e[0] == '0') ? 0 : 1; }
     GemmP p = p0;
-    p.xcd = g_gemm_xcd;
+    p.xcd = 1;                                                 // XCD-aware tile order
     const bool ak = (p.sAk == 1), bnc = (p.sBn == 1);
     if (ak && bnc) return launch_x3_ab<true, true>(p, batch, st);
     if (ak) return launch_x3_ab<true, false>(p, batch, st);
@@ -485,10 +479,8 @@ int launch_x3(const GemmP& p0, int batch, hipStream_t st) {
     return launch_x3_ab<false, false>(p, batch, st);
 }
 
-static int g_gemm_x3 = -1;       // JVAE_GEMM_X3=0: dense products stay on the fp32 matrix-core kernel (A/B switch)
-inline bool gemm_x3_on(int K) {
-    if (g_gemm_x3 < 0) { const char* e = getenv("JVAE_GEMM_X3"); g_gemm_x3 = (e && e[0] == '0') ? 0 : 1; }
-    return g_gemm_x3 && K >= 64 && jvae_conv5_x3_enabled();
+inline bool gemm_x3_on(int K) {                               // jvae_conv2d_set_split(0): the fp32 matrix-core kernel
+    return K >= 64 && jvae_conv5_x3_enabled();
 }
 
 }  // namespace

@@ -539,11 +539,14 @@ class ClassificationVariationalNetwork(nn.Module):
         Opened by evaluate() and by a stand-alone forward(); closed when the call returns if no backward can follow (eval
         mode / no_grad), else by the backward pass itself (ops._close_span_after_backward), by Optimizer.zero_grad() /
         step(), and by everything that rewrites the weights wholesale (load_state_dict, load_weights, .to()/_apply).  A
-        nested call (forward() inside evaluate()) belongs to the outer span."""
+        nested call (forward() inside evaluate()) belongs to the outer span.  A convolution FORWARD called outside any such call
+        (a submodule invoked directly) disarms a cache left armed for a backward that has not come yet and packs per call
+        (ops._Conv.forward): the weights may have changed through .data in between."""
         if getattr(self, '_span_open', False) or not x.is_cuda:     # CPU tensors: the ops raise their own "no CPU fallback" error
             yield
             return
         self._span_open = True
+        _lib.span_depth += 1
         try:
             ws = getattr(self, '_conv_weights', None)
             if ws is None:
@@ -555,6 +558,7 @@ class ClassificationVariationalNetwork(nn.Module):
             yield
         finally:
             self._span_open = False
+            _lib.span_depth -= 1
             if not (self.training and torch.is_grad_enabled()):
                 _lib.pack_cache_end()            # no backward will follow: stop vouching for the weights now
 

@@ -195,6 +195,7 @@ def workspace(nbytes, device):
 # ---- per-step cache of the re-packed convolution weights (csrc/pack_cache.hip) ---------------------------------------------
 PACK_CACHE_BYTES = int(os.environ.get('JVAE_PACK_CACHE_MB', '64')) << 20       # JVAE_PACK_CACHE_MB=0: off (A/B switch)
 _pack_cache = {}
+span_depth = 0        # > 0 while a model-level forward()/evaluate() is running (cvae._constant_weights): see ops._Conv.forward
 
 
 def pack_cache_begin(weights, device):

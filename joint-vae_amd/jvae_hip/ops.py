@@ -318,7 +318,9 @@ class _Conv(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, spec, dead_bias, stats_out, aff=None):
         x = _c(_f32(x, 'conv'))
-        ctx.w_ref, ctx.b_ref = w, b
+        if not L.span_depth:               # a convolution called outside forward() / evaluate() (net.imager(z), a raw module call):
+            L.pack_cache_end()             # nobody vouches for the weights now - an armed cache (train-mode evaluate() without its
+        ctx.w_ref, ctx.b_ref = w, b        # backward yet) may predate a change through .data; pack per call
         w = _c(w)
         ctx.aff = aff
         if aff is not None:                # x is a pre-BatchNorm tensor: normalise (+ReLU) while staging it

@@ -418,7 +418,8 @@ def test_b8_conv_with_deferred_batchnorm_input(cin, cout, k, s, p, op, tr, H):
     assert rel(gw, wr.grad) < 2e-3
 
 
-def test_b8_training_sequence_tracks_fp32():
+@pytest.mark.parametrize('dseed,nseed,strict', [(6, 9, True), (1, 7, False)])
+def test_b8_training_sequence_tracks_fp32(dseed, nseed, strict):
     """BASELINE configs[4] (bf16 mode, 3x64x64 geometry): 24 optimiser steps on the same data with the same noise seed, bf16
     compute against fp32 compute from the same initial weights.  The restated tolerance for a step SEQUENCE (north_star's
     1e-4 is an fp32 figure): EVERY step within 25 % while the loss halves (measured: worst 6.5 %), the median step within 5 %
@@ -431,13 +432,17 @@ def test_b8_training_sequence_tracks_fp32():
     loss spike at a single step, clipped by the gradient-norm bound and gone the step after, the trajectories landing within
     0.25 - 2.1 % regardless).  That is a property of the model's loss, present in fp32-vs-fp32 comparisons with different
     summation orders as well, so this test keeps to a sequence without it instead of allowing for it (round 3 allowed 'one
-    outlier step')."""
+    outlier step').
+
+    ADVICE r4: an ordinary, un-chosen sequence must stay guarded too - the second case runs the first seed pair of that
+    diagnostic's list with round 3's robust bar: the median step within 5 %, AT MOST ONE step beyond 25 %, the last six steps
+    within 3 % (the pairs of the diagnostic land within 0.25 - 2.1 %), both runs falling, bit-reproducible."""
     from oracle.cases import get_case
     from oracle.det_init import load_det_state
     from cvae import ClassificationVariationalNetwork as Net
     kw = get_case('c5_n4')['net']
     N = 32
-    torch.manual_seed(6)
+    torch.manual_seed(dseed)
     data = torch.rand(4, N, *kw['input_shape'], device=DEV)
     lab = torch.randint(0, kw['num_labels'], (4, N), device=DEV)
 
@@ -446,8 +451,8 @@ def test_b8_training_sequence_tracks_fp32():
         load_det_state(net, seed=0)
         net.to(DEV).train()
         net.set_compute_dtype(dtype)
-        torch.manual_seed(9)
-        torch.cuda.manual_seed(9)
+        torch.manual_seed(nseed)
+        torch.cuda.manual_seed(nseed)
         hist = []
         for step in range(24):
             losses, _ = net.train_step(data[step % 4], lab[step % 4])
@@ -462,7 +467,10 @@ def test_b8_training_sequence_tracks_fp32():
     diffs = sorted(abs(a - b) / abs(a) for a, b in zip(h32, h16))
     worst, median = diffs[-1], diffs[len(diffs) // 2]
     tail = abs(sum(h16[-6:]) - sum(h32[-6:])) / sum(h32[-6:])
-    assert worst < 0.25 and median < 0.05 and tail < 1e-2, (worst, median, tail, h32, h16)
+    if strict:
+        assert worst < 0.25 and median < 0.05 and tail < 1e-2, (worst, median, tail, h32, h16)
+    else:
+        assert diffs[-2] < 0.25 and median < 0.05 and tail < 3e-2, (diffs[-2:], median, tail, h32, h16)
     assert all(np.isfinite(h16)) and all(np.isfinite(h32))
     assert h32[-1] < 0.7 * h32[0] and h16[-1] < 0.7 * h16[0]
     print(f'bf16 vs fp32 over 24 steps: worst per-step difference {worst:.2e}, median {median:.2e}, last six steps {tail:.2e}')

@@ -161,8 +161,10 @@ def test_full_size_step_matches_reference_golden(name, golden_dir):
         # the reference's own fp32 value is.  Second clause (round 4): on c5_n256 the reference's fp32 norm of features.1.bias
         # is itself 1.11e-3 off its fp64 norm; the 32x32x16 kernels land at -2.6e-4 of fp64 (8.6e-4 from ref32), the 16x16x32
         # ones at +1.4e-4 of fp64 (1.25e-3 from ref32): closer to the exact gradient, further from the reference's rounding.
+        # The second clause is bounded: even then the norm stays within 2e-3 of the reference's fp32 value.
         assert (abs(mine - ref32) <= 1e-3 * max(ref32, 1e-3 * tot)
-                or abs(mine - ref64) <= abs(ref32 - ref64)), (k, mine, ref32, ref64)
+                or (abs(mine - ref64) <= abs(ref32 - ref64)
+                    and abs(mine - ref32) <= 2e-3 * max(ref32, 1e-3 * tot))), (k, mine, ref32, ref64)
         if 'grad64.' + k in g.files:
             g64 = g['grad64.' + k].astype(np.float64)
             d_ref = np.linalg.norm(g['grad.' + k].astype(np.float64) - g64) / max(ref64, 1e-4 * tot)
@@ -1110,15 +1112,37 @@ def test_pack_cache_span_closes_without_an_optimizer_step():
         return out, s1['hits'] - s0['hits'], s1['misses'] - s0['misses'], s1['entries'] - s0['entries']
 
     z = torch.randn(4, *net.imager.input_shape, device=DEV)
-    # (i) evaluate + backward, no step: afterwards a stray convolution is not served from the cache
-    net.optimizer.zero_grad()
-    losses = net.evaluate(x, y, epsilon=eps, with_beta=True)[2]
-    _, hits, misses, _ = served(lambda: net.imager(z))
-    assert hits > 0 and misses == 0                      # still inside the span: backward has not run
-    losses['total'].mean().backward()
-    torch.cuda.synchronize()
+    # (i) evaluate + backward, no step.  A convolution called OUTSIDE forward() / evaluate() - a submodule invoked directly - is
+    # never served from the cache, not even between evaluate() and its backward (the weights may have changed through
+    # .data since the cache was armed); it disarms the cache, and the backward that follows packs per call and gives the same
+    # gradients bit for bit
+    def grads(stray):
+        net.optimizer.zero_grad()
+        losses = net.evaluate(x, y, epsilon=eps, with_beta=True)[2]
+        if stray:
+            _, hits, misses, _ = served(lambda: net.imager(z))
+            assert (hits, misses) == (0, 0)
+        losses['total'].mean().backward()
+        torch.cuda.synchronize()
+        return net.optimizer._groups[0].g.clone()
+    g_plain, g_stray = grads(False), grads(True)
+    assert torch.equal(g_plain, g_stray)
     _, hits, misses, _ = served(lambda: net.imager(z))
     assert (hits, misses) == (0, 0)
+    # ... and sees a weight change made through .data while the cache was still armed
+    net.optimizer.zero_grad()
+    net.evaluate(x, y, epsilon=eps, with_beta=True)       # train mode, no backward: the cache stays armed
+    with torch.no_grad():
+        before = net.imager(z).clone()
+    net.evaluate(x, y, epsilon=eps, with_beta=True)
+    net.imager[3].weight.data.mul_(2.)
+    with torch.no_grad():
+        after = net.imager(z).clone()
+    L.pack_cache_end()
+    with torch.no_grad():
+        uncached = net.imager(z).clone()
+    net.imager[3].weight.data.mul_(0.5)
+    assert not torch.equal(before, after) and torch.equal(after, uncached)
     # (ii) loss-only call, then a .data change, then a stand-alone forward()
     net.evaluate(x, y, epsilon=eps, with_beta=True)
     with torch.no_grad():

@@ -1,5 +1,5 @@
 """GPU box: raw strided products of the dense / unfolded layers of config 2 (E4 = 7x7 head as a GEMM, D0, the latent heads)
-for K-slice counts 1..32, split-bf16 (JVAE_GEMM_X3=1) vs fp32-MFMA kernel (JVAE_GEMM_X3=0)."""
+for K-slice counts 1..32, split-bf16 (default) vs fp32-MFMA kernel (JVAE_X3=0)."""
 import os, sys, torch
 REPO = os.environ.get('GRAFT_REPO_ROOT', os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [REPO, os.path.join(REPO, 'joint-vae_amd')]

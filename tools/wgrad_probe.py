@@ -1,6 +1,6 @@
 """GPU box: launch the weight gradient of one config-2 layer a few times as the training step launches it (deferred
 BatchNorm on the layer input, accumulation into an existing gradient).  LAYER = D5 (default) | D3 | D1 | E2 | E1 | D4.
-Run under rocprofv3 (--kernel-trace --stats, then separate --pmc passes); JVAE_WGRAD_X3=0 selects the fp32-MFMA kernel."""
+Run under rocprofv3 (--kernel-trace --stats, then separate --pmc passes); JVAE_X3=0 selects the fp32-MFMA kernel."""
 import os, sys, torch
 REPO = os.environ.get('GRAFT_REPO_ROOT', os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [REPO, os.path.join(REPO, 'joint-vae_amd')]
