@@ -14,8 +14,6 @@ RELU, SIGMOID, IDENT, LEAKY = 1, 2, 0, 3          # jvae_act_* kinds (LEAKY: nn.
 # the `relu` / `in_relu` argument of the BatchNorm and convolution entry points: 0 none, 1 ReLU, 2 leaky ReLU (jvae_hip.h)
 BN_ACT = {IDENT: 0, RELU: 1, LEAKY: 2}
 OVERLAP_WGRAD = True          # weight-gradient kernels on a second HIP stream (see _Conv.backward)
-LAST_WGRAD_ON_MAIN = __import__('os').environ.get('JVAE_LAST_WGRAD_MAIN', '1') != '0'     # A/B switch, see _Conv.backward
-WGRAD_FORK_BEFORE_DGRAD = __import__('os').environ.get('JVAE_WGRAD_FORK_EARLY', '1') != '0'   # A/B switch, see _Conv.backward
 ACT_KIND = {'relu': RELU, 'sigmoid': SIGMOID, 'linear': IDENT, 'leaky': LEAKY, None: IDENT}
 
 
@@ -352,9 +350,9 @@ class _Conv(torch.autograd.Function):
             b_slot = _grad_slot(ctx.b_ref) if want_b else None
             # the first layer of the model (its input needs no gradient) is the END of the backward chain: its weight
             # gradient stays on the main stream, where it runs beside the side stream's last kernels instead of behind them
-            on_side = (OVERLAP_WGRAD and (ctx.needs_input_grad[0] or not LAST_WGRAD_ON_MAIN) and w_slot is not None
+            on_side = (OVERLAP_WGRAD and ctx.needs_input_grad[0] and w_slot is not None
                        and (b_slot is not None or not want_b))
-        if on_side and WGRAD_FORK_BEFORE_DGRAD:
+        if on_side:
             # the weight gradient needs gy and x, not this layer's dgrad: the side stream forks off BEFORE the dgrad is
             # queued.  In a captured graph the dgrad is then the first successor of gy's producer and stays on the
             # launch queue (the runtime moves later successors to other queues: a 10 us hand-over per hop of the chain)
@@ -367,10 +365,6 @@ class _Conv(torch.autograd.Function):
             if on_side:
                 # in-place into the flat gradient buffer: nothing downstream of this node consumes the result before
                 # the optimiser, so the kernel goes to the side stream and overlaps the rest of backward
-                if not WGRAD_FORK_BEFORE_DGRAD:
-                    main = torch.cuda.current_stream(x.device)
-                    side = L.side_stream(x.device)
-                    side.wait_stream(main)
                 with torch.cuda.stream(side):
                     conv_wgrad_raw(x, gy, ctx.spec, w.shape, want_b, w_slot, b_slot, ctx.aff)
                 x.record_stream(side)

@@ -1245,3 +1245,31 @@ def test_accuracy_loop_records_and_recovers(tmp_path):
     acc2 = net.accuracy(data, batch_size=32, recorder=again)               # recovered from the record: nothing is evaluated
     assert acc2 == acc
     assert isinstance(net.accuracy(data, batch_size=32, method='closest'), float)
+
+
+def test_batchnorm_as_its_own_pass_matches_the_deferred_form(monkeypatch):
+    """HipConvStack.defer_batchnorm (JVAE_DEFER_BN=0 in the environment): BatchNorm + activation as their own kernels instead of
+    inside the next convolution's staging and the previous one's epilogue.  Same arithmetic per element (one fmaf, the same
+    batch statistics up to the order of their partial sums): losses within 1e-5, every gradient within 2e-4 of its norm - at a
+    ragged batch, for ReLU and for the leaky ReLU."""
+    from module.vae_layers.conv import HipConvStack
+    for act in ('relu', 'leaky'):
+        case = full_config(2, 37)
+        case['net'] = dict(case['net'], activation=act)
+        x, y, eps = (t.to(DEV) for t in det_inputs(37, (3, 32, 32), 10, 1, 64, seed=11))
+        out = {}
+        for defer in (True, False):
+            monkeypatch.setattr(HipConvStack, 'defer_batchnorm', defer)
+            net = build(case)
+            net.optimizer.zero_grad()
+            losses = net.evaluate(x, y, epsilon=eps, with_beta=True)[2]
+            losses['total'].mean().backward()
+            torch.cuda.synchronize()
+            out[defer] = ({k: v.detach().clone() for k, v in losses.items()},
+                          {n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None})
+        for k in ('total', 'cross_x', 'kl'):
+            assert rel(out[False][0][k], out[True][0][k]) < 1e-5, (act, k)
+        assert out[False][1].keys() == out[True][1].keys()
+        for n, g in out[True][1].items():
+            d = float((out[False][1][n] - g).norm()) / max(float(g.norm()), 1e-6 * float(torch.cat([t.flatten() for t in out[True][1].values()]).norm()))
+            assert d < 2e-4, (act, n, d)
