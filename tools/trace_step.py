@@ -20,7 +20,8 @@ for r in rows[lo:hi]:
         gaps += gap
     last_end = max(last_end or 0, int(r['End_Timestamp']))
     nm = re.sub(r'\(anonymous namespace\)::', '', r['Kernel_Name'])
-    nm = re.sub(r'\(.*', '', nm)[:60]
+    nm = re.sub(r'std::array<char\*, \d+ul>|at::native::|\(anonymous namespace\)::', '', nm)
+    nm = (nm if 'elementwise' in nm or 'reduce_kernel' in nm else re.sub(r'\(.*', '', nm))[:150]
     print(f'{d:8.1f} us  gap {gap:6.1f}  grid {r.get("Grid_Size", "?"):>9s}  wg {r.get("Workgroup_Size", "?"):>4s}  {nm}')
 print(f'{tot / 1e3:8.3f} ms total, {hi - lo} dispatches; idle gaps between them {gaps / 1e3:.3f} ms; '
       f'span {(last_end - first) / 1e6:.3f} ms (under the profiler)')
