@@ -967,6 +967,15 @@ class ClassificationVariationalNetwork(nn.Module):
             return packed
 
     # ------------------------------------------------------------------------------------ training loop
+    def _mean_backward(self, tot):
+        """tot.mean().backward() without the reduction kernels of a mean nobody reads and the expand of its backward:
+        d(mean)/d(tot_i) = 1/numel, handed to autograd as a cached constant (the same fp32 value as torch's own)."""
+        key = (tot.shape, tot.device)
+        if getattr(self, '_mean_grad_key', None) != key:
+            self._mean_grad = torch.ones_like(tot.detach()) / tot.numel()
+            self._mean_grad_key = key
+        torch.autograd.backward(tot, grad_tensors=self._mean_grad)
+
     def train_step(self, x, y, batch=0, current_measures=None, kl_var_weighting=1., gamma_weighting=1., epsilon=None):
         """One iteration of the reference's hot loop (cvae.py:2429-2461): zero_grad, evaluate, backward, clip, step."""
         self.optimizer.zero_grad()
@@ -978,12 +987,7 @@ class ClassificationVariationalNetwork(nn.Module):
         # backward: d(mean)/d(total_i) = 1/N, handed to autograd as a cached constant (same fp32 value as torch's own)
         if self.optimizer.check_nonfinite():     # cvae.py:2454-2457: a NaN / Inf parameter ends the run BEFORE backward
             _grad_nan_exit()
-        tot = losses['total']
-        key = (tot.shape, tot.device)
-        if getattr(self, '_mean_grad_key', None) != key:
-            self._mean_grad = torch.ones_like(tot.detach()) / tot.numel()
-            self._mean_grad_key = key
-        torch.autograd.backward(tot, grad_tensors=self._mean_grad)
+        self._mean_backward(losses['total'])
         self.optimizer.clip(self.parameters())
         self.optimizer.step()
         return losses, measures
@@ -1009,7 +1013,7 @@ class ClassificationVariationalNetwork(nn.Module):
             self.optimizer.zero_grad()
             _, _, losses, raw = self.evaluate(sx, sy, batch=0, with_beta=True, kl_var_weighting=kl_var_weighting,
                                               gamma_weighting=gamma_weighting, _raw_measures=True)
-            losses['total'].mean().backward()
+            self._mean_backward(losses['total'])    # (the constant is created by the eager warm-up passes, not captured)
             return losses, raw
 
         def update():
@@ -1059,6 +1063,7 @@ class ClassificationVariationalNetwork(nn.Module):
                 return losses, Measures(packed, has_dict, _grad_nan_exit, from_main=True)
 
             step.graph = (ga, gb)
+            step.constants = (self._mean_grad,)         # the captured graphs read it: alive as long as the step is
             return step
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
@@ -1074,6 +1079,7 @@ class ClassificationVariationalNetwork(nn.Module):
             return losses, Measures(packed, has_dict, _grad_nan_exit, from_main=True)
 
         step.graph = graph
+        step.constants = (self._mean_grad,)             # the captured graph reads it: alive as long as the step is
         return step
 
     def train_model(self, trainset=None, transformer=None, data_augmentation=None, optimizer=None, epochs=50,
