@@ -1,4 +1,4 @@
-"""GPU box: WHAT the round-4 nondeterministic staging variant (nd_old/libjvae_old_V.so, tools/nd_old_V.patch) gets wrong.  Inputs that
+"""GPU box: WHAT the round-4 nondeterministic staging variant (nd_old/libjvae_old_V.so, tools/nd_old_variants.patch (-DND_VARIANT=0..3)) gets wrong.  Inputs that
 make every output name the coefficient-table entry it was built from: x = 1 (or 0), one centre tap that copies input channel o % Cin
 to output channel o, scale[c] = c + 1 (or shift[c] = c + 1): the expected output is (o % Cin) + 1 everywhere, exactly.
 usage: JVAE_HIP_LIB=nd_old/libjvae_old_V.so python tools/nd_old_which.py"""
