@@ -49,6 +49,10 @@ def scan(text):
 
 
 def main(objs):
+    import shutil
+    if not (os.path.exists(LLVM + '/llvm-objdump') and os.path.exists(LLVM + '/clang-offload-bundler') and shutil.which('objcopy')):
+        print('isa_opsel_scan: llvm-objdump / clang-offload-bundler / objcopy not found - scan skipped')
+        return 0
     objs = objs or sorted(glob.glob(os.path.join(REPO, 'joint-vae_amd', 'csrc', 'build', '*.o')))
     with ThreadPoolExecutor(8) as ex:
         texts = list(ex.map(device_isa, objs))
