@@ -57,7 +57,7 @@ size_t jvae_conv2d_workspace_bytes(int N, int Cin, int H, int W, int Cout, int K
  * below the fp32 FMA chain's own rounding); mode 0 = v_mfma_f32_32x32x2_f32 (csrc/conv_mfma.hip).  Same tensors, same
  * results to fp32 rounding; returns the previous mode.  Same reference ops as jvae_conv2d_fwd_f32. */
 int jvae_conv2d_set_split_bf16(int mode);
-/* MFMA shape of that split-bf16 kernel on maps up to 32 wide: on = 1 (default; JVAE_X3_SH16=0 in the environment sets 0) =
+/* MFMA shape of that split-bf16 kernel on maps up to 32 wide: on = 1 (default) =
  * v_mfma_f32_16x16x32_bf16 with K = 2 taps x 16 channels, on = 0 = v_mfma_f32_32x32x16_bf16 with K = 16 channels of one tap.
  * Same six products per fp32 product, same fp32 accumulation order per output up to the pairing of taps; returns the
  * previous setting (A/B switch for tests and benches). */
