@@ -4,6 +4,8 @@ A one-GPU box cannot host two RCCL ranks, so this drives every RCCL call of the 
 device_id, the asynchronous early-bucket all-reduce issued on the side stream from the hook on z, the two remaining
 slices in reduce_gradients(), barrier, the MAX reduction of bench.py) on a world of one, where AVG is the identity:
 the losses and parameters must then be bit-identical to the non-distributed step.  Optional: --sync-bn.
+--graph: the captured form of the step instead (graph_train_step: two HIP graphs with ONE eager RCCL all-reduce between them -
+what `bench.py --gpus N` runs by default since round 5), captured and replayed with the RCCL communicator and its watchdog alive.
 """
 import os
 import sys
@@ -17,7 +19,7 @@ import torch.distributed as dist  # noqa: E402
 import bench  # noqa: E402
 
 
-def run(distributed, sync_bn, steps=6, bs=128):
+def run(distributed, sync_bn, steps=6, bs=128, graph=False):
     dev = torch.device('cuda', 0)
     net = bench.build_model(dev, 2)
     if distributed:
@@ -30,10 +32,16 @@ def run(distributed, sync_bn, steps=6, bs=128):
     torch.manual_seed(7)
     torch.cuda.manual_seed(7)
     meas, tot = None, []
+    replay = net.graph_train_step(x, y) if graph else None
+    torch.manual_seed(7)
+    torch.cuda.manual_seed(7)
     torch.cuda.synchronize()
     t0 = time.time()
     for i in range(steps):
-        losses, meas = net.train_step(x, y, batch=i, current_measures=meas)
+        if graph:
+            losses, meas = replay(x, y)
+        else:
+            losses, meas = net.train_step(x, y, batch=i, current_measures=meas)
         tot.append(losses['total'].detach().clone())
     torch.cuda.synchronize()
     if distributed:
@@ -49,14 +57,15 @@ def main():
     torch.cuda.set_device(0)
     dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
     sync_bn = '--sync-bn' in sys.argv
-    t_ref, p_ref, dt_ref = run(False, False)
-    t_dp, p_dp, dt_dp = run(True, sync_bn)
+    graph = '--graph' in sys.argv
+    t_ref, p_ref, dt_ref = run(False, False, graph=graph)
+    t_dp, p_dp, dt_dp = run(True, sync_bn, graph=graph)
     t = torch.tensor([dt_dp], device='cuda', dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     ok_l = torch.equal(t_ref, t_dp)
     ok_p = torch.equal(p_ref, p_dp)
     rel = float((t_ref - t_dp).abs().max() / t_ref.abs().max())
-    print(f'rccl one-rank rehearsal: sync_bn={sync_bn} losses bit-identical={ok_l} (max rel diff {rel:.2e}) '
+    print(f'rccl one-rank rehearsal: graph={graph} sync_bn={sync_bn} losses bit-identical={ok_l} (max rel diff {rel:.2e}) '
           f'params bit-identical={ok_p}  ms/step plain={dt_ref * 1e3:.2f} dp={float(t) * 1e3:.2f}')
     dist.barrier()
     dist.destroy_process_group()
